@@ -1,0 +1,156 @@
+/*
+ * matten_hip.h -- C ABI of libmatten_hip.so: MI355X (gfx950) kernels for MatTen's equivariant
+ * message-passing hot path.
+ *
+ * The reference (wengroup/matten) has no FFI for this path: it calls e3nn / torch_scatter Python
+ * ops.  Each entry point below replaces one of those call sites (cited as reference file:line,
+ * relative to the reference repository root) and is what a ctypes / pybind stub on the reference
+ * side would bind -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); no allocation inside
+ *   - kernels are enqueued on `stream` and never synchronise; the library keeps no global state
+ *   - return value: 0 on success, negative MATTEN_E* on a host-detectable error
+ *     (data-dependent errors, e.g. an unsupported atomic number, are reported through a device
+ *     `int32_t* err_flag` the caller reads back when it wants to)
+ *   - fp32 data, int32 indices inside the library; the backbone boundary's int64 tensors
+ *     (edge_index, atomic_numbers, batch, ptr -- reference data/_dtype.py:4) are read as int64
+ *   - irreps data layout: blocks concatenated, each block [mul, 2l+1] row-major (e3nn "mul_ir")
+ */
+#ifndef MATTEN_HIP_H
+#define MATTEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* matten_stream_t; /* hipStream_t */
+
+#define MATTEN_OK 0
+#define MATTEN_EINVAL (-1)  /* bad argument (null pointer, negative size, unsupported shape) */
+#define MATTEN_ELAUNCH (-2) /* hipGetLastError() != hipSuccess after a launch */
+#define MATTEN_ENOMEM (-3)  /* caller-provided workspace too small */
+
+/* ABI version of this header; bumped on any signature change. */
+int matten_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph indexing.  Replaces the implicit ordering torch_scatter.scatter(msg, edge_dst) relies
+ * on (nn/conv.py:113-114): builds a destination-sorted CSR so that the neighbour sum is a
+ * segmented reduction with a fixed (stable => deterministic) summation order.
+ *   edge_index [2,E] int64: row 0 = centre i ("src"), row 1 = neighbour j ("dst") -- data/data.py:297-301
+ *   perm[E]      : sorted position -> original edge id (stable sort by dst)
+ *   rowptr[N+1]  : CSR offsets into the sorted edge list
+ *   src_sorted[E]: edge_index[0][perm[e]]
+ * workspace: matten_csr_workspace_bytes(E, N) bytes.
+ * Out-of-range node ids set err_flag bit 0.
+ * ------------------------------------------------------------------------------------------ */
+size_t matten_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
+int matten_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, int32_t* perm,
+                     int32_t* rowptr, int32_t* src_sorted, void* workspace, size_t workspace_bytes,
+                     int32_t* err_flag, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SpeciesEmbedding.forward (nn/embedding.py:85-110) + _AtomicNumberToIndex.forward (:230-259)
+ *   species_index[n] = z_to_index[Z[n] - min_z]           (int64 out, reference dtype)
+ *   node_feats[n,:]  = W[:, species] + b                   (Linear on a one-hot == column lookup)
+ *   node_attrs (one-hot [N,S]) is written only if node_attrs != NULL.
+ * err_flag bit 1: Z outside [min_z,max_z]; bit 2: Z maps to -1 (unsupported species).
+ * ------------------------------------------------------------------------------------------ */
+int matten_species_embed(const int64_t* atomic_numbers, int64_t n_nodes, const int64_t* z_to_index,
+                         int64_t min_z, int64_t max_z, int64_t n_species, const float* weight /*[dim,S]*/,
+                         const float* bias /*[dim]*/, int64_t dim, int64_t* species_index, int32_t* species_i32,
+                         float* node_feats, float* node_attrs, int32_t* err_flag, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * with_edge_vectors (nn/_nequip.py:214-268) + o3.SphericalHarmonics (nn/_nequip.py:167-174)
+ * + soft_one_hot_linspace bessel * sqrt(nb) (nn/embedding.py:185-199), fused, per edge.
+ *   vec = pos[dst] - pos[src] + shift . cell[batch[src]]
+ * Sorted-order outputs (consumed by the kernels below; e = sorted position, o = perm[e]):
+ *   geom_sorted[E,4] = (vx, vy, vz, |v|)
+ *   sh_sorted[E, (lmax+1)^2]  real SH of v/|v|, l-major, m=-l..l, 'component' normalised
+ * Optional original-order outputs for the backbone's data dict (NULL to skip):
+ *   edge_vectors[E,3], edge_lengths[E], edge_attrs[E,(lmax+1)^2], edge_embedding[E,nb]
+ * cell is [B,3,3] (rows = lattice vectors) or NULL; n_cells==1 uses cell 0 for every edge.
+ * ------------------------------------------------------------------------------------------ */
+int matten_edge_geom(const float* pos, const int64_t* edge_index, const float* edge_cell_shift,
+                     const float* cell, int64_t n_cells, const int64_t* batch, const int32_t* perm,
+                     int64_t n_edges, int lmax, int n_basis, float r_start, float r_end,
+                     float* geom_sorted, float* sh_sorted, float* edge_vectors, float* edge_lengths,
+                     float* edge_attrs, float* edge_embedding, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Radial MLP: e3nn FullyConnectedNet([nb, h, h, W], act=silu) applied to the Bessel embedding
+ * (nn/utils.py:246-251,260 <- nn/conv.py:113).  fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ *   in : geom_sorted[E,4] (uses |v|); the Bessel basis is recomputed in the prologue
+ *   w0p[nb_pad, h], w1p[h, h], w2p[h, w_pad]: weights pre-scaled by 1/sqrt(fan_in) and by the
+ *        normalize2mom constant of the *previous* activation, row-major, zero padded
+ *        (nb_pad multiple of 4, h == 32, w_pad multiple of 16)
+ *   out: w_edge[E, w_pad]
+ * ------------------------------------------------------------------------------------------ */
+int matten_radial_mlp(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
+                      const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden, int w_pad,
+                      float act_cst, float* w_edge, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 'uvu' TensorProduct + gather + scatter-add + neighbour normalisation, fused
+ * (nn/utils.py:230-237,263; nn/conv.py:113-120):
+ *   agg[n, slot(p,u,k)] = norm_n * sum_{e in in(n)} w[e, woff_p+u] * sum_i x[src_e, xoff_p+u*d1+i] * M_e^{t(p)}[i,k]
+ *   M_e^{t}[i,k] = sqrt(2 l3+1) * sum_j C^{l1 l2 l3}_{ijk} Y_{l2,j}(e)
+ *   norm_n = 1/sqrt(avg_num_neighbors) if avg_num_neighbors > 0 else 1/sqrt(num_neigh[n])
+ * Plan tables (built once per layer on the host, immutable):
+ *   m_terms_idx[m_total, m_nterms] (uint8 index into Y), m_terms_coef[m_total, m_nterms]
+ *   out_meta[d_mid] int4 {x_base, w_index, m_base, d1 | d3<<8}
+ * ------------------------------------------------------------------------------------------ */
+int matten_tp_scatter(const float* x /*[N,d_in]*/, int64_t d_in, const float* w_edge /*[E,w_pad]*/, int64_t w_pad,
+                      const float* sh_sorted, int64_t sh_dim, const int32_t* rowptr, const int32_t* src_sorted,
+                      int64_t n_nodes, const uint8_t* m_terms_idx, const float* m_terms_coef, int64_t m_total,
+                      int64_t m_nterms, const int32_t* out_meta, int64_t d_mid, float avg_num_neighbors,
+                      const float* num_neigh, float* agg /*[N,d_mid]*/, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FullyConnectedTensorProduct(x, one_hot(species)) == species-indexed per-irrep linear
+ * (nn/conv.py:59-61,77-79,84-86 called :109,112,123), and e3nn o3.Linear when species == NULL
+ * (nn/nodewise.py:111-117, model_factory/tfn_scalar_tensor.py:49-51,68).
+ *   out[n, o] = (add ? add[n,o] : 0) + sum_{u<mul_in(o)} Wp[species[n]*w_stride + w_base(o) + u*w_step(o)] * x[n, x_base(o) + u*x_step(o)]
+ *   out_meta[d_out] int4 {x_base, x_step | mul_in<<16, w_base, w_step}; mul_in==0 => zero output
+ *   Wp: weights repacked per species with the path normalisation folded in.
+ * ------------------------------------------------------------------------------------------ */
+int matten_species_linear(const float* x, int64_t d_in, const int32_t* species, const float* wp, int64_t w_stride,
+                          const int32_t* out_meta, int64_t d_out, const float* add, int64_t n_rows, float* out,
+                          matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * e3nn Gate (nn/utils.py:134-140,158-159 <- nn/conv.py:209) fused with e3nn BatchNorm in eval
+ * mode (nn/utils.py:418,432-433 <- nn/conv.py:211).
+ *   meta[d_out] int4 {src, gate(-1: scalar), act (0 none,1 silu,2 tanh,3 sigmoid,4 ssp,5 abs) | gate_act<<8, bn_idx | mean_idx<<16 (0xFFFF: none)}
+ *   out = act(x[src])*c_act                      (scalars)
+ *       = x[src] * gate_act(x[gate])*c_gate      (gated irreps)
+ *   then, if bn_weight != NULL: (out - running_mean[mean_idx]) * rsqrt(running_var[bn_idx]+eps)*bn_weight[bn_idx] + bn_bias[mean_idx]
+ *   act_cst[8]: normalize2mom constants indexed by act code.
+ * ------------------------------------------------------------------------------------------ */
+int matten_gate_bn(const float* x, int64_t d_in, const int32_t* meta, int64_t d_out, const float* act_cst,
+                   const float* running_mean, const float* running_var, const float* bn_weight,
+                   const float* bn_bias, float eps, int64_t n_rows, float* out, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NodewiseReduce: torch_scatter.scatter(x, batch, reduce=mean|sum) over contiguous crystals
+ * (nn/nodewise.py:142-148).  ptr[B+1] int64 (PyG convention).  mean divides by max(count,1).
+ * ------------------------------------------------------------------------------------------ */
+int matten_segment_reduce(const float* x, int64_t dim, const int64_t* ptr, int64_t n_segments, int mean,
+                          float* out, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CartesianTensor.to_cartesian (utils.py:123-124, predict.py:145): out[b,:] = x[b,:] @ Q
+ *   Q [n_in, n_out] row-major (n_in = 21, n_out = 81 for ijkl=jikl=klij)
+ * ------------------------------------------------------------------------------------------ */
+int matten_dense_rows(const float* x, int64_t n_in, const float* q, int64_t n_out, int64_t n_rows, float* out,
+                      matten_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATTEN_HIP_H */

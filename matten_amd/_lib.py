@@ -1,0 +1,72 @@
+"""
+ctypes binding of libmatten_hip.so (C ABI declared in include/matten_hip.h).
+
+There is no fallback: if the shared library is missing or a symbol is absent, importing the
+compute path fails loudly.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C matten_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
+
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); must match include/matten_hip.h
+P = c_void_p
+SIGNATURES = {
+    "matten_abi_version": (c_int, []),
+    "matten_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "matten_csr_build": (c_int, [P, c_int64, c_int64, P, P, P, P, c_size_t, P, P]),
+    "matten_species_embed": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_int64, P, P, P, P, P, P]),
+    "matten_edge_geom": (c_int, [P, P, P, P, c_int64, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P]),
+    "matten_radial_mlp": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, P, c_int, c_int, c_float, P, P]),
+    "matten_tp_scatter": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, P, c_int64, c_float, P, P, P]),
+    "matten_species_linear": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, P, P]),
+    "matten_gate_bn": (c_int, [P, c_int64, P, c_int64, P, P, P, P, P, c_float, c_int64, P, P]),
+    "matten_segment_reduce": (c_int, [P, c_int64, P, c_int64, c_int, P, P]),
+    "matten_dense_rows": (c_int, [P, c_int64, P, c_int64, c_int64, P, P]),
+}
+
+_lib = None
+
+
+class MattenHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and return the library with argtypes set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MattenHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. matten_amd has no CPU fallback; "
+            "run `make -C matten_amd/csrc` (needs hipcc, --offload-arch=gfx950)."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MattenHipError(f"symbol {name} missing from {LIB_PATH}") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.matten_abi_version()
+    if v != ABI_VERSION:
+        raise MattenHipError(f"ABI version mismatch: library {v}, python binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+_ERRORS = {-1: "MATTEN_EINVAL (bad argument)", -2: "MATTEN_ELAUNCH (HIP launch failed)", -3: "MATTEN_ENOMEM (workspace too small)"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise MattenHipError(f"{what} failed: {_ERRORS.get(rc, rc)}")

@@ -1,0 +1,154 @@
+// Node-side operators of the conv stack.
+//   species_linear : e3nn FullyConnectedTensorProduct(x, one_hot)  reference nn/conv.py:59-61,77-79,84-86
+//                    and e3nn o3.Linear (species == NULL)           reference nn/nodewise.py:111-117
+//   gate_bn        : e3nn Gate + BatchNorm(eval)                    reference nn/conv.py:209-211
+//   segment_reduce : NodewiseReduce                                 reference nn/nodewise.py:142-148
+//   dense_rows     : CartesianTensor.to_cartesian                   reference utils.py:123-124
+#include "common.h"
+
+namespace {
+
+__global__ void species_linear_kernel(const float* __restrict__ x, int d_in, const int32_t* __restrict__ species,
+                                      const float* __restrict__ wp, int64_t w_stride,
+                                      const int4* __restrict__ out_meta, int d_out, const float* __restrict__ add,
+                                      int64_t n_rows, float* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * d_out) return;
+    int64_t n = idx / d_out;
+    int o = (int)(idx - n * d_out);
+    int4 m = out_meta[o];
+    int x_step = m.y & 0xffff, mul_in = m.y >> 16;
+    const float* xp = x + n * d_in + m.x;
+    const float* w = wp + (species ? (int64_t)species[n] * w_stride : 0) + m.z;
+    float s = add ? add[idx] : 0.0f;
+    float a = 0.0f;
+    for (int u = 0; u < mul_in; ++u) a += w[(int64_t)u * m.w] * xp[u * x_step];
+    out[idx] = s + a;
+}
+
+__device__ __forceinline__ float apply_act(int code, float v) {
+    switch (code) {
+        case 1: return v / (1.0f + expf(-v));                          // silu
+        case 2: return tanhf(v);                                       // tanh
+        case 3: return 1.0f / (1.0f + expf(-v));                       // sigmoid
+        case 4: return (v > 20.0f ? v : log1pf(expf(v))) - 0.6931471805599453f;  // shifted softplus
+        case 5: return fabsf(v);                                       // abs
+        default: return v;
+    }
+}
+
+__global__ void gate_bn_kernel(const float* __restrict__ x, int d_in, const int4* __restrict__ meta, int d_out,
+                               const float* __restrict__ act_cst, const float* __restrict__ running_mean,
+                               const float* __restrict__ running_var, const float* __restrict__ bn_weight,
+                               const float* __restrict__ bn_bias, float eps, int64_t n_rows,
+                               float* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * d_out) return;
+    int64_t n = idx / d_out;
+    int o = (int)(idx - n * d_out);
+    int4 m = meta[o];
+    const float* xr = x + n * d_in;
+    float v = xr[m.x];
+    int act = m.z & 0xff, gact = (m.z >> 8) & 0xff;
+    if (m.y < 0) {
+        if (act) v = apply_act(act, v) * act_cst[act];
+    } else {
+        float gte = xr[m.y];
+        if (gact) gte = apply_act(gact, gte) * act_cst[gact];
+        v = v * gte;
+    }
+    if (bn_weight) {
+        int bn_idx = m.w & 0xffff, mean_idx = (m.w >> 16) & 0xffff;
+        float scale = bn_weight[bn_idx] / sqrtf(running_var[bn_idx] + eps);
+        if (mean_idx != 0xffff) v = (v - running_mean[mean_idx]) * scale + bn_bias[mean_idx];
+        else v = v * scale;
+    }
+    out[idx] = v;
+}
+
+__global__ void segment_reduce_kernel(const float* __restrict__ x, int dim, const int64_t* __restrict__ ptr,
+                                      int64_t n_seg, int mean, float* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_seg * dim) return;
+    int64_t b = idx / dim;
+    int c = (int)(idx - b * dim);
+    int64_t beg = ptr[b], end = ptr[b + 1];
+    float s = 0.0f;
+    for (int64_t n = beg; n < end; ++n) s += x[n * dim + c];
+    if (mean) {
+        float cnt = (float)(end - beg);
+        s = s / (cnt < 1.0f ? 1.0f : cnt);
+    }
+    out[idx] = s;
+}
+
+__global__ void dense_rows_kernel(const float* __restrict__ x, int n_in, const float* __restrict__ q, int n_out,
+                                  int64_t n_rows, float* __restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * n_out) return;
+    int64_t b = idx / n_out;
+    int c = (int)(idx - b * n_out);
+    float s = 0.0f;
+    for (int k = 0; k < n_in; ++k) s += x[b * n_in + k] * q[k * n_out + c];
+    out[idx] = s;
+}
+
+}  // namespace
+
+extern "C" int matten_species_linear(const float* x, int64_t d_in, const int32_t* species, const float* wp,
+                                     int64_t w_stride, const int32_t* out_meta, int64_t d_out, const float* add,
+                                     int64_t n_rows, float* out, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows < 0 || d_in <= 0 || d_out <= 0) return MATTEN_EINVAL;
+    if (n_rows == 0) return MATTEN_OK;
+    if (!x || !wp || !out_meta || !out) return MATTEN_EINVAL;
+    const int T = 256;
+    species_linear_kernel<<<(unsigned)matten_cdiv(n_rows * d_out, T), T, 0, stream>>>(
+        x, (int)d_in, species, wp, w_stride, (const int4*)out_meta, (int)d_out, add, n_rows, out);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_gate_bn(const float* x, int64_t d_in, const int32_t* meta, int64_t d_out, const float* act_cst,
+                              const float* running_mean, const float* running_var, const float* bn_weight,
+                              const float* bn_bias, float eps, int64_t n_rows, float* out, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows < 0 || d_in <= 0 || d_out <= 0) return MATTEN_EINVAL;
+    if (n_rows == 0) return MATTEN_OK;
+    if (!x || !meta || !act_cst || !out) return MATTEN_EINVAL;
+    if (bn_weight && (!running_var || !running_mean || !bn_bias)) return MATTEN_EINVAL;
+    const int T = 256;
+    gate_bn_kernel<<<(unsigned)matten_cdiv(n_rows * d_out, T), T, 0, stream>>>(
+        x, (int)d_in, (const int4*)meta, (int)d_out, act_cst, running_mean, running_var, bn_weight, bn_bias, eps,
+        n_rows, out);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_segment_reduce(const float* x, int64_t dim, const int64_t* ptr, int64_t n_segments, int mean,
+                                     float* out, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_segments < 0 || dim <= 0) return MATTEN_EINVAL;
+    if (n_segments == 0) return MATTEN_OK;
+    if (!x || !ptr || !out) return MATTEN_EINVAL;
+    const int T = 256;
+    segment_reduce_kernel<<<(unsigned)matten_cdiv(n_segments * dim, T), T, 0, stream>>>(x, (int)dim, ptr, n_segments,
+                                                                                        mean, out);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_dense_rows(const float* x, int64_t n_in, const float* q, int64_t n_out, int64_t n_rows,
+                                 float* out, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows < 0 || n_in <= 0 || n_out <= 0) return MATTEN_EINVAL;
+    if (n_rows == 0) return MATTEN_OK;
+    if (!x || !q || !out) return MATTEN_EINVAL;
+    const int T = 256;
+    dense_rows_kernel<<<(unsigned)matten_cdiv(n_rows * n_out, T), T, 0, stream>>>(x, (int)n_in, q, (int)n_out, n_rows,
+                                                                                  out);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_abi_version(void) { return 1; }

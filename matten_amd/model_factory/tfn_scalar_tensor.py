@@ -1,0 +1,189 @@
+"""
+Scalar / tensor target model for crystals on MI355X: same assembly, names and hyper-parameter
+keys as the reference factory (model_factory/tfn_scalar_tensor.py:32-195), with every layer backed
+by the gfx950 kernels.  ``ScalarTensorModel`` keeps the reference's
+``forward(batch, mode=None, task_name=...) -> (preds, labels)`` / ``decode`` / ``backbone`` /
+``extra_layers_dict['out_layer']`` / ``to_cartesian`` surface (model/model.py:143-184) without
+depending on Lightning: it is a ``torch.nn.Module``.
+"""
+from collections import OrderedDict
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ..nn._nequip import SphericalHarmonicEdgeAttrs
+from ..nn.conv import PointConv, PointConvWithActivation
+from ..nn.embedding import EdgeLengthEmbedding, SpeciesEmbedding
+from ..nn.nodewise import NodewiseLinear, NodewiseReduce
+from ..nn.utils import SpeciesLinear
+from ..o3 import Irreps
+from ..utils import CartesianTensor, ToCartesian
+from .utils import create_sequential_module
+
+OUT_FIELD_NAME = "my_model_output"
+
+
+def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any]):
+    use_atom_feats = hparams.get("use_atom_feats", False)
+    atom_feats_dim = dataset_hparams.get("atom_feats_size", None)
+    materialize = bool(hparams.get("materialize_intermediates", False))
+
+    layers = OrderedDict()
+    layers["one_hot"] = (
+        SpeciesEmbedding,
+        {
+            "embedding_dim": hparams["species_embedding_dim"],
+            "allowed_species": dataset_hparams["allowed_species"],
+            "use_atom_feats": use_atom_feats,
+            "atom_feats_dim": atom_feats_dim,
+            "materialize": materialize,
+        },
+    )
+    layers["spharm_edges"] = (
+        SphericalHarmonicEdgeAttrs,
+        {"irreps_edge_sh": hparams["irreps_edge_sh"], "materialize": materialize},
+    )
+    layers["radial_basis"] = (
+        EdgeLengthEmbedding,
+        {
+            "num_basis": hparams["num_radial_basis"],
+            "start": hparams["radial_basis_start"],
+            "end": hparams["radial_basis_end"],
+            "basis": hparams["radial_basis_type"],
+            "materialize": materialize,
+        },
+    )
+
+    num_neigh = hparams["average_num_neighbors"]
+    if isinstance(num_neigh, str) and num_neigh.lower() == "auto":
+        num_neigh = dataset_hparams["average_num_neighbors"]
+
+    conv_kwargs = {
+        "conv_layer_irreps": hparams["conv_layer_irreps"],
+        "fc_num_hidden_layers": hparams["invariant_layers"],
+        "fc_hidden_size": hparams["invariant_neurons"],
+        "avg_num_neighbors": num_neigh,
+    }
+    for i in range(hparams["num_layers"]):
+        layers[f"layer{i}_convnet"] = (
+            PointConvWithActivation,
+            dict(conv_kwargs, activation_type=hparams["nonlinearity_type"], normalization=hparams["normalization"]),
+        )
+    layers["conv_layer_last"] = (PointConv, dict(conv_kwargs))
+    layers["conv_to_output_hidden"] = (
+        NodewiseLinear,
+        {"irreps_out": hparams["conv_to_output_hidden_irreps_out"], "out_field": OUT_FIELD_NAME},
+    )
+    layers["output_pooling"] = (
+        NodewiseReduce,
+        {"field": OUT_FIELD_NAME, "out_field": OUT_FIELD_NAME, "reduce": hparams["reduce"]},
+    )
+    return create_sequential_module(modules=layers)
+
+
+class ScalarTensorModel(torch.nn.Module):
+    def __init__(
+        self,
+        tasks=None,
+        backbone_hparams: Dict[str, Any] = None,
+        dataset_hparams: Dict[str, Any] = None,
+        optimizer_hparams: Dict[str, Any] = None,
+        lr_scheduler_hparams: Dict[str, Any] = None,
+        trainer_hparams: Dict[str, Any] = None,
+        data_hparams: Dict[str, Any] = None,
+        **kwargs,
+    ):
+        super().__init__()
+        self.hparams = {
+            "tasks": tasks,
+            "backbone_hparams": backbone_hparams,
+            "dataset_hparams": dataset_hparams,
+            "optimizer_hparams": optimizer_hparams,
+            "lr_scheduler_hparams": lr_scheduler_hparams,
+            "trainer_hparams": trainer_hparams,
+            "data_hparams": data_hparams,
+        }
+        self.optimizer_hparams = optimizer_hparams
+        self.lr_scheduler_hparams = lr_scheduler_hparams
+        self.backbone, extra = self.init_backbone(backbone_hparams, dataset_hparams)
+        self.extra_layers_dict = torch.nn.ModuleDict(extra)
+        self.tasks = self.init_tasks(tasks)
+
+    # --- reference: ScalarTensorModel.init_backbone, tfn_scalar_tensor.py:33-61 -----------------
+    def init_backbone(self, backbone_hparams, dataset_hparams=None) -> Tuple[torch.nn.Module, Dict]:
+        backbone = create_model(backbone_hparams, dataset_hparams)
+        formula = backbone_hparams["output_formula"].lower()
+        irreps_out = Irreps("0e") if formula == "scalar" else CartesianTensor(formula=formula)
+        irreps_in = backbone_hparams["conv_to_output_hidden_irreps_out"]
+        extra = {"out_layer": SpeciesLinear(irreps_in, None, irreps_out)}
+        if backbone_hparams["output_format"] == "cartesian" and formula != "scalar":
+            self.to_cartesian = ToCartesian(formula)
+        else:
+            self.to_cartesian = None
+        return backbone, extra
+
+    # --- reference: BaseModel.init_tasks, model/model.py:126-141 -------------------------------
+    @staticmethod
+    def init_tasks(tasks) -> Dict[str, Any]:
+        if tasks is None:
+            return {"elastic_tensor_full": None}
+        if isinstance(tasks, str):
+            return {tasks: None}
+        if isinstance(tasks, dict):
+            return tasks
+        if isinstance(tasks, (list, tuple)):
+            return {getattr(t, "name", t): t for t in tasks}
+        return {tasks.name: tasks}
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    # --- reference: ModelForPyGData.preprocess_batch, model/model.py:493-518 --------------------
+    def preprocess_batch(self, batch):
+        if hasattr(batch, "to") and not isinstance(batch, dict):
+            batch = batch.to(self.device)
+        if hasattr(batch, "tensor_property_to_dict"):
+            y = getattr(batch, "y", None) or {}
+            labels = {name: y[name] for name in self.tasks if name in y}
+            graphs = batch.tensor_property_to_dict()
+        else:
+            graphs = {k: (v.to(self.device) if isinstance(v, Tensor) else v) for k, v in batch.items()}
+            labels = {name: graphs[name] for name in self.tasks if name in graphs}
+        return graphs, labels
+
+    # --- reference: ScalarTensorModel.decode, tfn_scalar_tensor.py:63-79 ------------------------
+    def decode(self, model_input) -> Dict[str, Tensor]:
+        out = self.backbone(model_input)[OUT_FIELD_NAME]
+        out = self.extra_layers_dict["out_layer"](out)
+        if self.to_cartesian is not None:
+            out = self.to_cartesian(out)
+        names = list(self.tasks.keys())
+        assert len(names) == 1, f"only works for 1 target, get{len(names)}"
+        return {names[0]: out}
+
+    def transform_prediction(self, preds, task_name: str = "elastic_tensor_full"):
+        task = self.tasks.get(task_name)
+        normalizer = getattr(task, "normalizer", None)
+        if normalizer is not None:
+            return {task_name: normalizer.inverse(preds[task_name])}
+        return {task_name: preds[task_name]}
+
+    def transform_target(self, target, task_name: str = "elastic_tensor_full"):
+        if task_name not in target:
+            return target
+        return self.transform_prediction(target, task_name)
+
+    # --- reference: BaseModel.forward, model/model.py:143-184 -----------------------------------
+    def forward(self, batch, mode: Optional[str] = None, task_name: str = "elastic_tensor_full", **kwargs):
+        graphs, labels = self.preprocess_batch(batch)
+        if mode is None or mode.lower() == "none":
+            preds = self.decode(graphs, **kwargs)
+            preds = self.transform_prediction(preds, task_name=task_name)
+            labels = self.transform_target(labels, task_name=task_name)
+        elif mode == "backbone":
+            preds = self.backbone(graphs, **kwargs)
+        else:
+            raise ValueError(f"Expect mode to be one of {(None, 'backbone')}; got {mode}")
+        return preds, labels

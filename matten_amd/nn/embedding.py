@@ -1,0 +1,157 @@
+"""
+Input embeddings of the backbone on MI355X.
+
+  SpeciesEmbedding     mirrors reference nn/embedding.py:12-110: atomic number -> species index
+                       (LUT) -> one-hot -> Linear.  The one-hot times Linear is a column lookup, so
+                       the kernel never builds the [N,S] one-hot unless asked to.
+  EdgeLengthEmbedding  mirrors reference nn/embedding.py:158-203 (Bessel basis * sqrt(num_basis)).
+                       The radial MLP recomputes the basis in its prologue, so this module only
+                       records the basis parameters (and materialises the tensors on request).
+"""
+from typing import Dict, List, Tuple
+
+import torch
+
+from .. import ops
+from ..data.irreps import DataKey, ModuleIrreps
+from ..o3 import Irreps
+
+
+class _AtomicNumberToIndex(torch.nn.Module):
+    """Non-consecutive atomic numbers -> consecutive species indices (reference nn/embedding.py:206-263)."""
+
+    def __init__(self, allowed_atomic_numbers: List[int]):
+        super().__init__()
+        allowed = torch.as_tensor(sorted(allowed_atomic_numbers), dtype=torch.long)
+        lut = torch.full((int(allowed.max() - allowed.min()) + 1,), -1, dtype=torch.long)
+        lut[allowed - allowed.min()] = torch.arange(len(allowed), dtype=torch.long)
+        self.register_buffer("_min_Z", allowed.min())
+        self.register_buffer("_max_Z", allowed.max())
+        self.register_buffer("_num_species", torch.as_tensor(len(allowed)))
+        self.register_buffer("_Z_to_index", lut)
+        # host copies: kernel arguments must not force a device sync
+        self._host = (int(allowed.min()), int(allowed.max()), len(allowed))
+        self._allowed = [int(z) for z in allowed]
+
+    @property
+    def num_species(self):
+        return self._num_species
+
+    def raise_for_flags(self, flags: int, atomic_numbers: torch.Tensor):
+        """Same messages as the reference's forward (nn/embedding.py:238-257)."""
+        if flags & 2:
+            raise RuntimeError(
+                "Invalid atomic numbers. Expect atomic numbers to be in the range "
+                f"[{self._host[0]}, {self._host[1]}], but got min {int(atomic_numbers.min())} "
+                f"and max {int(atomic_numbers.max())}"
+            )
+        if flags & 4:
+            z = atomic_numbers.cpu()
+            for i, n in enumerate(z.tolist()):
+                if n not in self._allowed:
+                    raise RuntimeError(
+                        f"Expect atomic numbers to be in {self._allowed}, "
+                        f"got invalid atomic numbers `{n}` for data point `{i}`."
+                    )
+
+    def forward(self, atomic_numbers: torch.Tensor) -> torch.Tensor:
+        # standalone use (the reference's unit test): pure index arithmetic, any device
+        lo, hi, _ = self._host
+        if atomic_numbers.min() < lo or atomic_numbers.max() > hi:
+            self.raise_for_flags(2, atomic_numbers)
+        index = self._Z_to_index[atomic_numbers - lo]
+        if index.min() < 0:
+            self.raise_for_flags(4, atomic_numbers)
+        return index
+
+
+class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
+    def __init__(
+        self,
+        irreps_in: Dict[str, Irreps] = None,
+        embedding_dim: int = 16,
+        num_species: int = None,
+        allowed_species: List[int] = None,
+        out_fields: Tuple[str] = (DataKey.NODE_ATTRS, DataKey.NODE_FEATURES),
+        use_atom_feats: bool = False,
+        atom_feats_dim: int = None,
+        materialize: bool = False,
+        check_species: bool = True,
+    ):
+        super().__init__()
+        if allowed_species is not None and num_species is not None:
+            raise ValueError("allowed_species and num_species cannot both be provided.")
+        if allowed_species is None:
+            raise NotImplementedError("matten_amd needs `allowed_species` (every shipped config provides it)")
+        if use_atom_feats:
+            raise NotImplementedError("use_atom_feats=True is outside the accelerated path")
+        self.embedding_dim = embedding_dim
+        self.out_fields = out_fields
+        self.materialize = materialize
+        self.check_species = check_species
+        self.atomic_number_to_index = _AtomicNumberToIndex(allowed_species)
+        self.num_species = len(allowed_species)
+        self.init_irreps(
+            irreps_in,
+            {DataKey.NODE_ATTRS: Irreps(f"{self.num_species}x0e"), DataKey.NODE_FEATURES: Irreps(f"{embedding_dim}x0e")},
+        )
+        self.linear = torch.nn.Linear(self.num_species, embedding_dim)
+
+    def forward(self, data: DataKey.Type) -> DataKey.Type:
+        a2i = self.atomic_number_to_index
+        lo, hi, S = a2i._host
+        if DataKey.SPECIES_INDEX in data:
+            # already indexed: feed indices through an identity LUT
+            Z = data[DataKey.SPECIES_INDEX]
+            lut = torch.arange(S, dtype=torch.int64, device=Z.device)
+            lo, hi = 0, S - 1
+            provided = True
+        elif DataKey.ATOMIC_NUMBERS in data:
+            Z, lut, provided = data[DataKey.ATOMIC_NUMBERS], a2i._Z_to_index, False
+        else:
+            raise ValueError("Nothing in `data` to encode. Need either species_index or atomic_numbers")
+        sidx, s32, feats, attrs, err = ops.species_embed(
+            Z, lut, lo, hi, S, self.linear.weight, self.linear.bias, want_attrs=self.materialize
+        )
+        if self.check_species:
+            flags = int(err.item())
+            if flags:
+                a2i.raise_for_flags(flags, Z)
+        if not provided:
+            data[DataKey.SPECIES_INDEX] = sidx
+        data[DataKey.AMD_SPECIES] = s32
+        if attrs is not None:
+            data[DataKey.NODE_ATTRS] = attrs
+        data[DataKey.NODE_FEATURES] = feats
+        return data
+
+
+class EdgeLengthEmbedding(ModuleIrreps, torch.nn.Module):
+    REQUIRED_KEYS_IRREPS_IN = [DataKey.POSITIONS, DataKey.EDGE_INDEX]
+
+    def __init__(
+        self,
+        irreps_in: Dict[str, Irreps] = None,
+        out_field: str = DataKey.EDGE_EMBEDDING,
+        num_basis: int = 10,
+        start: float = 0.0,
+        end: float = 5.0,
+        basis: str = "bessel",
+        cutoff: bool = True,
+        materialize: bool = False,
+    ):
+        super().__init__()
+        if basis != "bessel" or not cutoff:
+            raise NotImplementedError("matten_amd implements the Bessel basis with cutoff (all shipped configs)")
+        self.num_basis, self.start, self.end, self.basis, self.cutoff = num_basis, start, end, basis, cutoff
+        self.out_field = out_field
+        self.materialize = materialize
+        self.init_irreps(irreps_in, irreps_out={out_field: Irreps(f"{num_basis}x0e")})
+
+    def forward(self, data: DataKey.Type) -> DataKey.Type:
+        from ._nequip import ensure_edge_geometry
+
+        data[DataKey.AMD_RBF] = torch.tensor([self.num_basis, self.start, self.end], dtype=torch.float64)
+        if self.materialize:
+            ensure_edge_geometry(data, want_lengths=True, want_embedding=True)
+        return data

@@ -1,0 +1,52 @@
+"""Node-wise output head on MI355X (mirrors reference nn/nodewise.py:89-148)."""
+from typing import Dict, Optional
+
+import torch
+
+from .. import ops
+from ..data.irreps import DataKey, ModuleIrreps
+from ..o3 import Irreps
+from ._nequip import with_batch
+from .utils import SpeciesLinear
+
+
+class NodewiseLinear(ModuleIrreps, torch.nn.Module):
+    def __init__(self, irreps_in: Dict[str, Irreps], irreps_out: Irreps = None, field: str = DataKey.NODE_FEATURES,
+                 out_field: Optional[str] = None):
+        super().__init__()
+        self.field = field
+        self.out_field = out_field if out_field is not None else field
+        if irreps_out is None:
+            irreps_out = irreps_in[self.field]
+        self.init_irreps(irreps_in=irreps_in, irreps_out={self.out_field: irreps_out},
+                         required_keys_irreps_in=[self.field])
+        self.linear = SpeciesLinear(self.irreps_in[field], None, self.irreps_out[self.out_field])
+
+    def forward(self, data: DataKey.Type) -> DataKey.Type:
+        data[self.out_field] = self.linear(data[self.field])
+        return data
+
+
+class NodewiseReduce(ModuleIrreps, torch.nn.Module):
+    def __init__(self, irreps_in: Dict[str, Irreps], field: str, out_field: Optional[str] = None, reduce: str = "sum"):
+        super().__init__()
+        assert reduce in ("sum", "mean", "min", "max")
+        if reduce not in ("sum", "mean"):
+            raise NotImplementedError("matten_amd pools with sum or mean (shipped configs use mean)")
+        self.reduce = reduce
+        self.field = field
+        self.out_field = f"{reduce}_{field}" if out_field is None else out_field
+        self.init_irreps(irreps_in=irreps_in, irreps_out={self.out_field: irreps_in[self.field]},
+                         required_keys_irreps_in=[self.field])
+
+    def forward(self, data: DataKey.Type) -> DataKey.Type:
+        with_batch(data)
+        ptr = data.get(DataKey.PTR)
+        if ptr is None:
+            # PyG batches are contiguous per crystal: recover segment offsets from `batch`
+            batch = data[DataKey.BATCH]
+            counts = torch.bincount(batch)
+            ptr = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=batch.device)
+            ptr[1:] = torch.cumsum(counts, 0)
+        data[self.out_field] = ops.segment_reduce(data[self.field], ptr, self.reduce == "mean")
+        return data

@@ -1,0 +1,214 @@
+"""
+Equivariant building blocks of the conv layer on MI355X (mirrors reference nn/utils.py).
+
+  SpeciesLinear        stands in for e3nn ``FullyConnectedTensorProduct(x, one_hot(species))``
+                       (reference nn/conv.py:59-61,77-79,84-86) and, with one species, ``o3.Linear``
+  RadialMLP            e3nn ``FullyConnectedNet`` of the radial weights (reference nn/utils.py:246-251)
+  UVUTensorProduct     reference nn/utils.py:170-277 -- here fused with the gather of x[src], the
+                       scatter onto the destination node and the neighbour normalisation
+  ActivationLayer      reference nn/utils.py:29-167 (Gate)
+  NormalizationLayer   reference nn/utils.py:397-437 (BatchNorm)
+
+Parameters keep the reference's names, shapes and flat layouts.
+"""
+from typing import Callable, Dict, List, Optional
+
+import torch
+from torch import Tensor
+
+from .. import ops, plan as _plan
+from ..data.irreps import DataKey
+from ..o3 import Irrep, Irreps
+from ._activation import act_const_table, normalize2mom_const
+from ._tables import DerivedWeight, DeviceTables
+
+# activation *names* per parity class (reference nn/utils.py:14-26 holds the callables)
+ACTIVATION = {"e": {"ssp": "ssp", "silu": "silu", "sigmoid": "sigmoid"}, "o": {"abs": "abs", "tanh": "tanh"}}
+
+tp_path_exists = _plan.tp_path_exists
+
+
+class SpeciesLinear(torch.nn.Module):
+    """out[n] = sum_u W[u, species(n), w] x[n,u] / sqrt(fan_in), per irrep; flat ``weight`` as in e3nn."""
+
+    def __init__(self, irreps_in, n_species: Optional[int], irreps_out):
+        super().__init__()
+        if n_species is None:
+            self.plan = _plan.plan_linear(irreps_in, irreps_out)
+        else:
+            self.plan = _plan.plan_fctp(irreps_in, n_species, irreps_out)
+        self.irreps_in, self.irreps_out = self.plan.irreps_in, self.plan.irreps_out
+        self.n_species = n_species
+        self.weight = torch.nn.Parameter(torch.randn(self.plan.weight_numel))
+        self._tables = DeviceTables(
+            gather=self.plan.gather, scale=self.plan.scale, **{f"meta{i}": m for i, m in enumerate(self.plan.passes)}
+        )
+        self._packed = DerivedWeight(self._pack)
+
+    def _pack(self, weight: Tensor) -> Tensor:
+        dev = weight.device
+        return (weight[self._tables.get("gather", dev)] * self._tables.get("scale", dev)).contiguous()
+
+    def forward(self, x: Tensor, species_i32: Optional[Tensor] = None, add: Optional[Tensor] = None) -> Tensor:
+        if self.n_species is not None and species_i32 is None:
+            raise ValueError("species index required")
+        wp = self._packed.get(self.weight)
+        metas = [self._tables.get(f"meta{i}", x.device) for i in range(len(self.plan.passes))]
+        return ops.species_linear(x, species_i32 if self.n_species is not None else None, wp, self.plan.w_stride,
+                                  metas, add)
+
+
+class _RadialLayer(torch.nn.Module):
+    def __init__(self, h_in: int, h_out: int):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(h_in, h_out))
+
+
+class RadialMLP(torch.nn.Module):
+    """Bias-free MLP [n_basis, h, h, W]: x <- c*silu(x @ W/sqrt(h_in)) on hidden layers."""
+
+    def __init__(self, hs: List[int], act: str = "silu"):
+        super().__init__()
+        if len(hs) != 4 or hs[1] != 32 or hs[2] != 32:
+            raise NotImplementedError(f"radial MLP must be [nb, 32, 32, W] (invariant_layers=2, neurons=32); got {hs}")
+        if act != "silu":
+            raise NotImplementedError("radial MLP activation must be silu (reference nn/conv.py:72)")
+        self.hs = list(hs)
+        self.act_cst = normalize2mom_const(act)
+        for i, (a, b) in enumerate(zip(hs, hs[1:])):
+            setattr(self, f"layer{i}", _RadialLayer(a, b))
+        self._packed = DerivedWeight(self._pack)
+
+    def _pack(self, w0: Tensor, w1: Tensor, w2: Tensor):
+        nb, h, W = self.hs[0], self.hs[1], self.hs[3]
+        nb_pad, w_pad = (nb + 3) // 4 * 4, (W + 15) // 16 * 16
+        w0p = w0.new_zeros(nb_pad, h)
+        w0p[:nb] = w0 / nb**0.5
+        w1p = (w1 * (self.act_cst / h**0.5)).contiguous()
+        w2p = w2.new_zeros(h, w_pad)
+        w2p[:, :W] = w2 * (self.act_cst / h**0.5)
+        return w0p, w1p, w2p
+
+    def forward(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float) -> Tensor:
+        if n_basis != self.hs[0]:
+            raise ValueError(f"radial basis size {n_basis} != MLP input {self.hs[0]}")
+        w0p, w1p, w2p = self._packed.get(self.layer0.weight, self.layer1.weight, self.layer2.weight)
+        return ops.radial_mlp(geom_sorted, n_basis, r_start, r_end, w0p, w1p, w2p)
+
+
+class UVUTensorProduct(torch.nn.Module):
+    def __init__(
+        self,
+        irreps_in1: Irreps,
+        irreps_in2: Irreps,
+        irreps_out: Irreps,
+        *,
+        internal_and_share_weights: bool = False,
+        mlp_input_size: int = None,
+        mlp_hidden_size: int = 8,
+        mlp_num_hidden_layers: int = 1,
+        mlp_activation: str = "ssp",
+    ):
+        super().__init__()
+        if internal_and_share_weights:
+            raise NotImplementedError("internal shared weights are not used by the model factories")
+        assert mlp_input_size is not None, (
+            "Expect `mlp_input_size` be provided when `internal_and_share_weights` is set to `False`, got `None`"
+        )
+        self.plan = _plan.plan_uvu(irreps_in1, irreps_in2, irreps_out)
+        self.irreps_mid = self.plan.irreps_mid
+        self.weight_numel = self.plan.weight_numel
+        layer_sizes = [mlp_input_size] + mlp_num_hidden_layers * [mlp_hidden_size] + [self.weight_numel]
+        self.weight_nn = RadialMLP(layer_sizes, act=mlp_activation)
+        self._tables = DeviceTables(
+            m_idx=self.plan.m_terms_idx, m_coef=self.plan.m_terms_coef, out_meta=self.plan.out_meta
+        )
+
+    @property
+    def irreps_out(self) -> Irreps:
+        return self.irreps_mid.simplify()
+
+    def forward(self, node_feats: Tensor, data: DataKey.Type, avg_num_neighbors=None) -> Tensor:
+        """sum over incoming edges of TP(x[src], Y(edge), MLP(rbf(edge))), normalised; [N, d_mid]."""
+        nb, r0, r1 = data[DataKey.AMD_RBF].tolist()
+        w_edge = self.weight_nn(data[DataKey.AMD_GEOM], int(nb), r0, r1)
+        dev = node_feats.device
+        return ops.tp_scatter(
+            node_feats, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
+            self._tables.get("m_idx", dev), self._tables.get("m_coef", dev), self._tables.get("out_meta", dev),
+            avg_num_neighbors if avg_num_neighbors is not None else 0.0,
+            None if avg_num_neighbors is not None else data[DataKey.NUM_NEIGH],
+        )
+
+
+class ActivationLayer(torch.nn.Module):
+    def __init__(
+        self,
+        tp_irreps_in1: Irreps,
+        tp_irreps_in2: Irreps,
+        tp_irreps_out: Irreps,
+        *,
+        activation_type: str = "gate",
+        activation_scalars: Dict[str, str] = None,
+        activation_gates: Dict[str, str] = None,
+    ):
+        super().__init__()
+        key = {"e": 1, "o": -1}
+        scal = {1: "ssp", -1: "tanh"} if activation_scalars is None else {
+            key[k]: ACTIVATION[k][v] for k, v in activation_scalars.items()
+        }
+        gat = {1: "ssp", -1: "abs"} if activation_gates is None else {
+            key[k]: ACTIVATION[k][v] for k, v in activation_gates.items()
+        }
+        if activation_type != "gate":
+            supported = ("gate",)
+            raise NotImplementedError(
+                f"matten_amd supports `activation_type` in {supported} (all shipped configs), got {activation_type}"
+            )
+        self.plan = _plan.plan_gate(tp_irreps_in1, tp_irreps_in2, tp_irreps_out, scal, gat)
+        self._tables = DeviceTables(meta=self.plan.meta, act_cst=act_const_table().numpy())
+
+    @property
+    def irreps_in(self) -> Irreps:
+        return self.plan.irreps_in
+
+    @property
+    def irreps_out(self) -> Irreps:
+        return self.plan.irreps_out
+
+    def forward(self, x: Tensor, norm: "NormalizationLayer" = None) -> Tensor:
+        dev = x.device
+        bn = norm.n if (norm is not None and norm.n is not None) else None
+        if bn is not None and bn.training:
+            raise NotImplementedError("BatchNorm in training mode: call model.eval() (inference path)")
+        return ops.gate_bn(
+            x, self._tables.get("meta", dev), self._tables.get("act_cst", dev),
+            *((bn.running_mean, bn.running_var, bn.weight, bn.bias) if bn is not None else (None, None, None, None)),
+            eps=bn.eps if bn is not None else 1e-5,
+        )
+
+
+class _IrrepBatchNorm(torch.nn.Module):
+    """State of e3nn ``BatchNorm(irreps)``; applied inside the fused gate kernel."""
+
+    def __init__(self, irreps: Irreps, eps: float = 1e-5, momentum: float = 0.1):
+        super().__init__()
+        self.irreps = Irreps(irreps)
+        self.eps, self.momentum = eps, momentum
+        n_scalar = sum(m for m, ir in self.irreps if ir.is_scalar())
+        n_feat = self.irreps.num_irreps
+        self.register_buffer("running_mean", torch.zeros(n_scalar))
+        self.register_buffer("running_var", torch.ones(n_feat))
+        self.weight = torch.nn.Parameter(torch.ones(n_feat))
+        self.bias = torch.nn.Parameter(torch.zeros(n_scalar))
+
+
+class NormalizationLayer(torch.nn.Module):
+    def __init__(self, irreps: Irreps, method: str = None):
+        super().__init__()
+        self.method = method
+        supported = ("batch", "none", None)
+        if method == "instance":
+            raise NotImplementedError("normalization='instance' is outside the accelerated path")
+        assert method in supported, f"Unsupported normalization {method}"
+        self.n = _IrrepBatchNorm(irreps) if method == "batch" else None

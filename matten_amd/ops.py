@@ -1,0 +1,204 @@
+"""
+Thin tensor-level wrappers over the C ABI (include/matten_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; all arithmetic happens in
+libmatten_hip.so.  Every wrapper insists on contiguous CUDA(=HIP) tensors of the right dtype and
+raises if handed anything else -- there is deliberately no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.MattenHipError(
+            f"{name} is on {t.device}: matten_amd runs on MI355X only (no CPU fallback). Move the batch to cuda."
+        )
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def csr_build(edge_index: torch.Tensor, n_nodes: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (perm[E] i32, rowptr[N+1] i32, src_sorted[E] i32, err_flag[1] i32)"""
+    lib = _lib.load()
+    edge_index = _need(edge_index, torch.int64, "edge_index")
+    E = edge_index.shape[1]
+    dev = edge_index.device
+    perm = torch.empty(E, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+    src = torch.empty(E, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    nbytes = lib.matten_csr_workspace_bytes(E, n_nodes)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    _lib.check(
+        lib.matten_csr_build(_ptr(edge_index), E, n_nodes, _ptr(perm), _ptr(rowptr), _ptr(src), _ptr(ws), nbytes,
+                             _ptr(err), _stream()),
+        "matten_csr_build",
+    )
+    return perm, rowptr, src, err
+
+
+def species_embed(atomic_numbers, z_to_index, min_z: int, max_z: int, n_species: int, weight, bias,
+                  want_attrs: bool = False):
+    """-> (species_index i64 [N], species_i32 [N], node_feats [N,dim], node_attrs [N,S] | None, err_flag)"""
+    lib = _lib.load()
+    Z = _need(atomic_numbers, torch.int64, "atomic_numbers")
+    lut = _need(z_to_index, torch.int64, "_Z_to_index")
+    W = _need(weight, torch.float32, "linear.weight")
+    b = _need(bias, torch.float32, "linear.bias")
+    N, dim = Z.shape[0], W.shape[0]
+    dev = Z.device
+    sidx = torch.empty(N, dtype=torch.int64, device=dev)
+    s32 = torch.empty(N, dtype=torch.int32, device=dev)
+    feats = torch.empty(N, dim, dtype=torch.float32, device=dev)
+    attrs = torch.empty(N, n_species, dtype=torch.float32, device=dev) if want_attrs else None
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(
+        lib.matten_species_embed(_ptr(Z), N, _ptr(lut), min_z, max_z, n_species, _ptr(W), _ptr(b), dim, _ptr(sidx),
+                                 _ptr(s32), _ptr(feats), _ptr(attrs), _ptr(err), _stream()),
+        "matten_species_embed",
+    )
+    return sidx, s32, feats, attrs, err
+
+
+def edge_geom(pos, edge_index, edge_cell_shift, cell, batch, perm, lmax: int, n_basis: int = 0, r_start: float = 0.0,
+              r_end: float = 1.0, want_vectors=False, want_lengths=False, want_attrs=False, want_embedding=False):
+    """-> dict(geom_sorted [E,4], sh_sorted [E,(lmax+1)^2], + requested original-order tensors)"""
+    lib = _lib.load()
+    pos = _need(pos, torch.float32, "pos")
+    edge_index = _need(edge_index, torch.int64, "edge_index")
+    E = edge_index.shape[1]
+    dev = pos.device
+    n_cells = 0
+    if cell is not None:
+        cell = _need(cell, torch.float32, "cell").reshape(-1, 3, 3)
+        n_cells = cell.shape[0]
+        edge_cell_shift = _need(edge_cell_shift, torch.float32, "edge_cell_shift")
+        if n_cells > 1:
+            batch = _need(batch, torch.int64, "batch")
+    sh_dim = (lmax + 1) ** 2
+    geom = torch.empty(E, 4, dtype=torch.float32, device=dev)
+    sh = torch.empty(E, sh_dim, dtype=torch.float32, device=dev)
+    out = {"geom_sorted": geom, "sh_sorted": sh}
+    ev = torch.empty(E, 3, dtype=torch.float32, device=dev) if want_vectors else None
+    el = torch.empty(E, dtype=torch.float32, device=dev) if want_lengths else None
+    ea = torch.empty(E, sh_dim, dtype=torch.float32, device=dev) if want_attrs else None
+    ee = torch.empty(E, n_basis, dtype=torch.float32, device=dev) if want_embedding else None
+    _lib.check(
+        lib.matten_edge_geom(_ptr(pos), _ptr(edge_index), _ptr(edge_cell_shift), _ptr(cell), n_cells, _ptr(batch),
+                             _ptr(perm), E, lmax, n_basis, r_start, r_end, _ptr(geom), _ptr(sh), _ptr(ev), _ptr(el),
+                             _ptr(ea), _ptr(ee), _stream()),
+        "matten_edge_geom",
+    )
+    out.update(edge_vectors=ev, edge_lengths=el, edge_attrs=ea, edge_embedding=ee)
+    return out
+
+
+def radial_mlp(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p, w2p) -> torch.Tensor:
+    lib = _lib.load()
+    geom_sorted = _need(geom_sorted, torch.float32, "geom_sorted")
+    w0p, w1p, w2p = (_need(w, torch.float32, n) for w, n in ((w0p, "w0p"), (w1p, "w1p"), (w2p, "w2p")))
+    E = geom_sorted.shape[0]
+    nb_pad, hidden = w0p.shape
+    w_pad = w2p.shape[1]
+    out = torch.empty(E, w_pad, dtype=torch.float32, device=geom_sorted.device)
+    _lib.check(
+        lib.matten_radial_mlp(_ptr(geom_sorted), E, n_basis, r_start, r_end, _ptr(w0p), nb_pad, _ptr(w1p), _ptr(w2p),
+                              hidden, w_pad, 1.0, _ptr(out), _stream()),
+        "matten_radial_mlp",
+    )
+    return out
+
+
+def tp_scatter(x, w_edge, sh_sorted, rowptr, src_sorted, m_idx, m_coef, out_meta, avg_num_neighbors: float,
+               num_neigh=None) -> torch.Tensor:
+    lib = _lib.load()
+    x = _need(x, torch.float32, "node_features")
+    w_edge = _need(w_edge, torch.float32, "w_edge")
+    sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
+    N, d_in = x.shape
+    d_mid = out_meta.shape[0]
+    m_total, m_nterms = m_coef.shape
+    if num_neigh is not None:
+        num_neigh = _need(num_neigh, torch.float32, "num_neigh")
+    agg = torch.empty(N, d_mid, dtype=torch.float32, device=x.device)
+    _lib.check(
+        lib.matten_tp_scatter(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
+                              _ptr(rowptr), _ptr(src_sorted), N, _ptr(m_idx), _ptr(m_coef), m_total, m_nterms,
+                              _ptr(out_meta), d_mid, float(avg_num_neighbors or 0.0), _ptr(num_neigh), _ptr(agg),
+                              _stream()),
+        "matten_tp_scatter",
+    )
+    return agg
+
+
+def species_linear(x, species_i32, wp, w_stride: int, metas, add=None) -> torch.Tensor:
+    """metas: list of int32 [d_out,4] tensors (passes).  out = add + sum_passes."""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    wp = _need(wp, torch.float32, "packed weights")
+    n_rows, d_in = x.shape
+    d_out = metas[0].shape[0]
+    out = torch.empty(n_rows, d_out, dtype=torch.float32, device=x.device)
+    cur_add = add
+    if cur_add is not None:
+        cur_add = _need(cur_add, torch.float32, "add")
+    for meta in metas:
+        _lib.check(
+            lib.matten_species_linear(_ptr(x), d_in, _ptr(species_i32), _ptr(wp), w_stride, _ptr(meta), d_out,
+                                      _ptr(cur_add), n_rows, _ptr(out), _stream()),
+            "matten_species_linear",
+        )
+        cur_add = out
+    return out
+
+
+def gate_bn(x, meta, act_cst, running_mean=None, running_var=None, bn_weight=None, bn_bias=None, eps: float = 1e-5):
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    n_rows, d_in = x.shape
+    d_out = meta.shape[0]
+    out = torch.empty(n_rows, d_out, dtype=torch.float32, device=x.device)
+    _lib.check(
+        lib.matten_gate_bn(_ptr(x), d_in, _ptr(meta), d_out, _ptr(act_cst), _ptr(running_mean), _ptr(running_var),
+                           _ptr(bn_weight), _ptr(bn_bias), eps, n_rows, _ptr(out), _stream()),
+        "matten_gate_bn",
+    )
+    return out
+
+
+def segment_reduce(x, ptr, mean: bool) -> torch.Tensor:
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    ptr = _need(ptr, torch.int64, "ptr")
+    B = ptr.shape[0] - 1
+    out = torch.empty(B, x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(lib.matten_segment_reduce(_ptr(x), x.shape[1], _ptr(ptr), B, int(mean), _ptr(out), _stream()),
+               "matten_segment_reduce")
+    return out
+
+
+def dense_rows(x, q) -> torch.Tensor:
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    q = _need(q, torch.float32, "q")
+    out = torch.empty(x.shape[0], q.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(lib.matten_dense_rows(_ptr(x), x.shape[1], _ptr(q), q.shape[1], x.shape[0], _ptr(out), _stream()),
+               "matten_dense_rows")
+    return out

@@ -1,0 +1,340 @@
+"""
+Host-side planners: turn irreps bookkeeping into the flat integer / float tables the gfx950
+kernels index with (see include/matten_hip.h).  Built once per module at construction.
+
+Each planner mirrors the instruction enumeration of the e3nn class the reference instantiates,
+so parameters keep the reference's flat layout:
+
+  plan_uvu      <- UVUTensorProduct.__init__          reference nn/utils.py:205-237
+  plan_fctp     <- o3.FullyConnectedTensorProduct     reference nn/conv.py:59-61,77-79,84-86
+  plan_linear   <- o3.Linear                          reference nn/nodewise.py:111
+  plan_gate     <- ActivationLayer / nn.Gate          reference nn/utils.py:96-140
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .o3 import Irrep, Irreps, wigner_3j
+
+ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
+
+
+def tp_path_exists(irreps_in1, irreps_in2, ir_out) -> bool:
+    """reference nn/utils.py:358-367"""
+    ir_out = Irrep(ir_out)
+    for _, ir1 in Irreps(irreps_in1).simplify():
+        for _, ir2 in Irreps(irreps_in2).simplify():
+            if ir_out in ir1 * ir2:
+                return True
+    return False
+
+
+# ------------------------------------------------------------------------------------------
+# 'uvu' tensor product with per-edge weights
+# ------------------------------------------------------------------------------------------
+@dataclass
+class UVUPath:
+    i_in1: int
+    i_sh: int
+    l1: int
+    l2: int
+    l3: int
+    p3: int
+    mul: int
+    x_off: int       # offset of the in1 block in the node feature row
+    w_off: int       # offset of this path's weights in the per-edge weight row (instruction order)
+    slot: int        # index of the output slot in the sorted irreps_mid
+    out_off: int     # offset of the output slot in the message row
+    m_off: int       # offset of the (l1,l2,l3) coupling matrix in the per-edge M table
+
+
+@dataclass
+class UVUPlan:
+    irreps_in1: Irreps
+    irreps_sh: Irreps
+    irreps_mid: Irreps           # sorted, NOT simplified: one slot per path
+    irreps_out: Irreps           # irreps_mid.simplify(): what lin2 sees
+    paths: List[UVUPath]
+    weight_numel: int
+    d_in: int
+    d_mid: int
+    sh_dim: int
+    m_total: int
+    m_nterms: int
+    m_terms_idx: np.ndarray      # uint8 [m_total, m_nterms]
+    m_terms_coef: np.ndarray     # f32   [m_total, m_nterms]
+    out_meta: np.ndarray         # int32 [d_mid, 4]
+    cg_nnz: int = 0
+
+
+def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
+    irreps_in1, irreps_sh, irreps_target = Irreps(irreps_in1), Irreps(irreps_sh), Irreps(irreps_target)
+    lmax = len(irreps_sh) - 1
+    if irreps_sh != Irreps.spherical_harmonics(lmax):
+        raise NotImplementedError(
+            f"edge attributes must be the spherical harmonics 0..lmax in order, got {irreps_sh}"
+        )
+
+    # instruction enumeration, reference nn/utils.py:205-213.  (The `or ir_out == Irreps("0e")`
+    # clause there compares an Irrep with an Irreps and never fires.)
+    mid: List[Tuple[int, Irrep]] = []
+    raw = []
+    for i, (mul, ir1) in enumerate(irreps_in1):
+        for j, (_, ir2) in enumerate(irreps_sh):
+            for ir_out in ir1 * ir2:
+                if ir_out in irreps_target:
+                    raw.append((i, j, len(mid)))
+                    mid.append((mul, ir_out))
+    if not mid:
+        raise ValueError(f"{irreps_in1} x {irreps_sh} produces no path into {irreps_target}")
+    irreps_mid, perm, _ = Irreps(mid).sort()  # reference nn/utils.py:222-228
+    mid_off = irreps_mid.offsets()
+    x_offs = irreps_in1.offsets()
+    sh_offs = irreps_sh.offsets()
+
+    triples: Dict[Tuple[int, int, int], int] = {}
+    m_rows_idx: List[List[int]] = []
+    m_rows_coef: List[List[float]] = []
+    cg_nnz = 0
+
+    def m_offset(l1, l2, l3) -> int:
+        nonlocal cg_nnz
+        key = (l1, l2, l3)
+        if key in triples:
+            return triples[key]
+        off = len(m_rows_idx)
+        triples[key] = off
+        C = wigner_3j(l1, l2, l3) * math.sqrt(2 * l3 + 1)  # path coefficient sqrt(2 l3+1), App. A.3
+        for i in range(2 * l1 + 1):
+            for k in range(2 * l3 + 1):
+                js = [j for j in range(2 * l2 + 1) if abs(C[i, j, k]) > 1e-12]
+                cg_nnz += len(js)
+                m_rows_idx.append([sh_offs[l2] + j for j in js])
+                m_rows_coef.append([float(C[i, j, k]) for j in js])
+        return off
+
+    paths: List[UVUPath] = []
+    w_off = 0
+    for i, j, k in raw:
+        mul, ir1 = irreps_in1[i]
+        ir2 = irreps_sh[j].ir
+        slot = perm[k]
+        ir3 = irreps_mid[slot].ir
+        paths.append(
+            UVUPath(i, j, ir1.l, ir2.l, ir3.l, ir3.p, mul, x_offs[i], w_off, slot, mid_off[slot],
+                    m_offset(ir1.l, ir2.l, ir3.l))
+        )
+        w_off += mul
+
+    m_total = len(m_rows_idx)
+    m_nterms = max(1, max(len(r) for r in m_rows_idx))
+    idx = np.zeros((m_total, m_nterms), dtype=np.uint8)
+    coef = np.zeros((m_total, m_nterms), dtype=np.float32)
+    for m, (ri, rc) in enumerate(zip(m_rows_idx, m_rows_coef)):
+        idx[m, : len(ri)] = ri
+        coef[m, : len(rc)] = rc
+
+    d_mid = irreps_mid.dim
+    meta = np.zeros((d_mid, 4), dtype=np.int32)
+    for p in paths:
+        d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
+        for u in range(p.mul):
+            for k in range(d3):
+                o = p.out_off + u * d3 + k
+                meta[o] = (p.x_off + u * d1, p.w_off + u, p.m_off + k, d1 | (d3 << 8))
+    return UVUPlan(
+        irreps_in1=irreps_in1, irreps_sh=irreps_sh, irreps_mid=irreps_mid, irreps_out=irreps_mid.simplify(),
+        paths=paths, weight_numel=w_off, d_in=irreps_in1.dim, d_mid=d_mid, sh_dim=irreps_sh.dim,
+        m_total=m_total, m_nterms=m_nterms, m_terms_idx=idx, m_terms_coef=coef, out_meta=meta, cg_nnz=cg_nnz,
+    )
+
+
+# ------------------------------------------------------------------------------------------
+# species-indexed linear (FCTP with one-hot second operand) and plain o3.Linear
+# ------------------------------------------------------------------------------------------
+@dataclass
+class LinearPlan:
+    irreps_in: Irreps
+    irreps_out: Irreps
+    n_species: int
+    weight_numel: int             # size of the flat reference parameter
+    w_stride: int                 # packed floats per species
+    gather: np.ndarray            # int64 [n_species, w_stride]: packed <- flat parameter index
+    scale: np.ndarray             # f32 [w_stride]: path normalisation
+    passes: List[np.ndarray]      # each int32 [d_out, 4] out_meta; pass p>0 accumulates onto pass p-1
+    d_in: int = 0
+    d_out: int = 0
+    flops_per_row: int = 0
+
+
+def _plan_linear_like(irreps_in: Irreps, irreps_out: Irreps, n_species: int, paths) -> LinearPlan:
+    """paths: list of (i_in, i_out) in the reference's instruction order; weights (mul_in, S, mul_out)."""
+    x_offs, o_offs = irreps_in.offsets(), irreps_out.offsets()
+    fan = {}
+    for i_in, i_out in paths:
+        fan[i_out] = fan.get(i_out, 0) + irreps_in[i_in].mul * n_species
+    flat = 0
+    packed = 0
+    gather_cols: List[np.ndarray] = []
+    scale_cols: List[np.ndarray] = []
+    per_out: Dict[int, List[Tuple[int, int]]] = {}
+    flops = 0
+    for i_in, i_out in paths:
+        mi, mo = irreps_in[i_in].mul, irreps_out[i_out].mul
+        # flat index of W[u, s, w] = flat + (u*S + s)*mo + w ; packed index = packed + u*mo + w
+        u = np.arange(mi)[:, None]
+        w = np.arange(mo)[None, :]
+        s = np.arange(n_species)[:, None, None]
+        g = flat + (u[None] * n_species + s) * mo + w[None]
+        gather_cols.append(g.reshape(n_species, mi * mo))
+        scale_cols.append(np.full(mi * mo, fan[i_out] ** -0.5, dtype=np.float32))
+        per_out.setdefault(i_out, []).append((i_in, packed))
+        flat += mi * n_species * mo
+        packed += mi * mo
+        flops += 2 * mi * mo * irreps_out[i_out].ir.dim
+    n_pass = max([len(v) for v in per_out.values()] + [1])
+    passes = []
+    for ps in range(n_pass):
+        meta = np.zeros((irreps_out.dim, 4), dtype=np.int32)
+        for i_out, lst in per_out.items():
+            if ps >= len(lst):
+                continue
+            i_in, pk = lst[ps]
+            mi, mo = irreps_in[i_in].mul, irreps_out[i_out].mul
+            d = irreps_out[i_out].ir.dim
+            for wv in range(mo):
+                for k in range(d):
+                    meta[o_offs[i_out] + wv * d + k] = (x_offs[i_in] + k, d | (mi << 16), pk + wv, mo)
+        passes.append(meta)
+    gather = np.concatenate(gather_cols, axis=1) if gather_cols else np.zeros((n_species, 0), dtype=np.int64)
+    scale = np.concatenate(scale_cols) if scale_cols else np.zeros(0, dtype=np.float32)
+    return LinearPlan(irreps_in, irreps_out, n_species, flat, packed, gather.astype(np.int64), scale, passes,
+                      irreps_in.dim, irreps_out.dim, flops)
+
+
+def plan_fctp(irreps_in1, n_species: int, irreps_out) -> LinearPlan:
+    """FullyConnectedTensorProduct(in1, f"{S}x0e", out): instruction order for i_1, (i_2,) i_out."""
+    irreps_in1 = Irreps(irreps_in1).simplify()
+    irreps_out = Irreps(irreps_out).simplify()
+    paths = [
+        (i1, io)
+        for i1, (_, ir1) in enumerate(irreps_in1)
+        for io, (_, iro) in enumerate(irreps_out)
+        if iro == ir1
+    ]
+    return _plan_linear_like(irreps_in1, irreps_out, n_species, paths)
+
+
+def plan_linear(irreps_in, irreps_out) -> LinearPlan:
+    """o3.Linear(irreps_in, irreps_out): no simplification, instruction order for i_in, i_out."""
+    irreps_in, irreps_out = Irreps(irreps_in), Irreps(irreps_out)
+    paths = [
+        (ii, io)
+        for ii, (_, iri) in enumerate(irreps_in)
+        for io, (_, iro) in enumerate(irreps_out)
+        if iri == iro
+    ]
+    return _plan_linear_like(irreps_in, irreps_out, 1, paths)
+
+
+# ------------------------------------------------------------------------------------------
+# Gate (+ BatchNorm indices)
+# ------------------------------------------------------------------------------------------
+@dataclass
+class GatePlan:
+    irreps_in: Irreps            # what the preceding conv must produce (sorted, simplified)
+    irreps_out: Irreps           # irreps_scalars + irreps_gated
+    irreps_scalars: Irreps
+    irreps_gates: Irreps
+    irreps_gated: Irreps
+    meta: np.ndarray             # int32 [d_out, 4]
+    n_bn_features: int           # irreps_out.num_irreps
+    n_bn_scalars: int            # number of 0e channels in irreps_out
+
+
+def plan_gate(tp_irreps_in1, tp_irreps_in2, tp_irreps_out, act_scalars: Dict[int, str],
+              act_gates: Dict[int, str]) -> GatePlan:
+    """act_* map parity (+1/-1) -> activation name (keys of ACT_CODE)."""
+    tp_irreps_out = Irreps(tp_irreps_out).sort()[0].simplify()
+    scalars = Irreps(
+        [(m, ir) for m, ir in tp_irreps_out if ir.l == 0 and tp_path_exists(tp_irreps_in1, tp_irreps_in2, ir)]
+    )
+    gated = Irreps(
+        [(m, ir) for m, ir in tp_irreps_out if ir.l > 0 and tp_path_exists(tp_irreps_in1, tp_irreps_in2, ir)]
+    )
+    if gated.dim > 0:
+        if tp_path_exists(tp_irreps_in1, tp_irreps_in2, "0e"):
+            gir = Irrep("0e")
+        elif tp_path_exists(tp_irreps_in1, tp_irreps_in2, "0o"):
+            gir = Irrep("0o")
+        else:
+            raise ValueError(
+                f"tp_irreps_in1={tp_irreps_in1} times tp_irreps_in2={tp_irreps_in2} is unable to produce gates "
+                f"needed for irreps_gated={gated}"
+            )
+        gates = Irreps([(m, gir) for m, _ in gated]).simplify()
+    else:
+        gates = Irreps([])
+    scalars, gates, gated = scalars.simplify(), gates.simplify(), gated.simplify()
+
+    # input layout: stable sort of scalars + gates + gated (e3nn nn.Gate / _Sortcut)
+    cat = scalars + gates + gated
+    sorted_ir, p, _ = cat.sort()
+    offs = sorted_ir.offsets()
+    pos = [offs[p[i]] for i in range(len(cat))]
+    ns, ng = len(scalars), len(gates)
+    irreps_in = sorted_ir.simplify()
+
+    rows: List[Tuple[int, int, int, int]] = []  # (src, gate, act | gate_act << 8, bn_idx | mean_idx << 16)
+    out_ir: List[Tuple[int, Irrep]] = []
+    bn_idx = 0
+    mean_idx = 0
+    for b, (m, ir) in enumerate(scalars):
+        name = act_scalars[ir.p]
+        ir_o = Irrep(0, _scalar_out_parity(name, ir.p))
+        for u in range(m):
+            mi = (mean_idx + u) if ir_o.is_scalar() else 0xFFFF
+            rows.append((pos[b] + u, -1, ACT_CODE[name], (bn_idx + u) | (mi << 16)))
+        if ir_o.is_scalar():
+            mean_idx += m
+        bn_idx += m
+        out_ir.append((m, ir_o))
+    gate_chan: List[Tuple[int, int]] = []  # (position, parity) of every gate channel, in order
+    for b, (m, ir) in enumerate(gates):
+        gate_chan += [(pos[ns + b] + u, ir.p) for u in range(m)]
+    gc = 0
+    for b, (m, ir) in enumerate(gated):
+        d = ir.dim
+        p_gate = 1
+        for u in range(m):
+            gpos, gp = gate_chan[gc]
+            gc += 1
+            gname = act_gates[gp]
+            p_gate = _scalar_out_parity(gname, gp)
+            for k in range(d):
+                rows.append((pos[ns + ng + b] + u * d + k, gpos, ACT_CODE[gname] << 8, (bn_idx + u) | (0xFFFF << 16)))
+        bn_idx += m
+        out_ir.append((m, Irrep(ir.l, ir.p * p_gate)))
+    irreps_out = Irreps(out_ir)
+    meta = np.array(rows, dtype=np.int64).reshape(-1, 4)
+    meta = np.where(meta >= 2**31, meta - 2**32, meta).astype(np.int32)
+    assert meta.shape[0] == irreps_out.dim
+    return GatePlan(irreps_in, irreps_out, scalars, gates, gated, meta, irreps_out.num_irreps,
+                    sum(m for m, ir in irreps_out if ir.is_scalar()))
+
+
+_ACT_PARITY = {"silu": 0, "ssp": 0, "sigmoid": 0, "tanh": -1, "abs": 1}  # even(+1) / odd(-1) / neither(0)
+
+
+def _scalar_out_parity(act_name: str, p_in: int) -> int:
+    """Parity of act(x) for a scalar of parity p_in (e3nn nn.Activation): even input keeps +1."""
+    if p_in == 1:
+        return 1
+    pa = _ACT_PARITY[act_name]
+    if pa == 0:
+        raise ValueError(f"activation {act_name} on an odd scalar violates parity")
+    return pa

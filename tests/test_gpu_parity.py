@@ -1,0 +1,260 @@
+"""
+GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+Tolerances are fp32: the kernels reorder sums (CSR order, MFMA k-order, folded constants), so
+agreement is to a few ulp of the accumulated magnitude, not bitwise; integer/index outputs are
+compared exactly.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import EQUIV_TEST, LMAX2, PAPER, build_pair
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+RTOL = 2e-4  # relative to the largest magnitude of the compared tensor
+
+
+def close(got, want, rtol=RTOL, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(1e-6, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def _fcc(n):
+    from matten_amd.data import synthetic
+
+    return synthetic.fcc64_graphs(n), {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+
+
+def _to(d, dev):
+    return {k: v.to(dev) for k, v in d.items()}
+
+
+def test_csr_is_stable_sort_by_dst():
+    from matten_amd import ops
+    from matten_amd.data.graph import collate
+
+    graphs, _ = _fcc(3)
+    b = collate(graphs, device=DEV)
+    N = b["pos"].shape[0]
+    perm, rowptr, src, err = ops.csr_build(b["edge_index"], N)
+    ei = b["edge_index"].cpu()
+    want_perm = torch.sort(ei[1], stable=True).indices
+    assert torch.equal(perm.cpu().long(), want_perm)
+    counts = torch.bincount(ei[1], minlength=N)
+    assert torch.equal(rowptr.cpu().long()[1:] - rowptr.cpu().long()[:-1], counts)
+    assert torch.equal(src.cpu().long(), ei[0][want_perm])
+    assert int(err.item()) == 0
+
+
+def test_csr_empty_and_bad_index():
+    from matten_amd import ops
+
+    perm, rowptr, src, err = ops.csr_build(torch.zeros(2, 0, dtype=torch.int64, device=DEV), 5)
+    assert rowptr.cpu().tolist() == [0] * 6
+    ei = torch.tensor([[0, 1, 2], [1, 7, 0]], dtype=torch.int64, device=DEV)
+    *_, err = ops.csr_build(ei, 3)
+    assert int(err.item()) & 1
+
+
+def test_edge_geometry_sh_and_bessel_vs_oracle():
+    from matten_amd import ops
+    from matten_amd.data.graph import collate
+    from oracle.matten_ref import nn as rnn
+
+    graphs, _ = _fcc(2)
+    cpu = collate(graphs)
+    ref = dict(cpu)
+    rnn.SphericalHarmonicEdgeAttrs(4)(ref)
+    rnn.EdgeLengthEmbedding(num_basis=8, start=0.0, end=5.0)(ref)
+    g = _to(cpu, DEV)
+    out = ops.edge_geom(g["pos"], g["edge_index"], g["edge_cell_shift"], g["cell"], g["batch"], None, 4, 8, 0.0, 5.0,
+                        want_vectors=True, want_lengths=True, want_attrs=True, want_embedding=True)
+    close(out["edge_vectors"], ref["edge_vectors"], 1e-6, "edge_vectors")
+    close(out["edge_lengths"], ref["edge_lengths"], 1e-6, "edge_lengths")
+    close(out["edge_attrs"], ref["edge_attrs"], 2e-6, "edge_attrs")
+    close(out["edge_embedding"], ref["edge_embedding"], 5e-6, "edge_embedding")
+    # perm == None means identity order
+    close(out["sh_sorted"], ref["edge_attrs"], 2e-6, "sh_sorted")
+    close(out["geom_sorted"][:, 3], ref["edge_lengths"], 1e-6, "geom len")
+
+
+def test_species_embedding_known_answer_and_errors():
+    from matten_amd.nn.embedding import SpeciesEmbedding, _AtomicNumberToIndex
+
+    # reference tests/nn/test_embedding.py:7-13 (runs anywhere)
+    n2i = _AtomicNumberToIndex([6, 1, 8]).to(DEV)
+    idx = n2i(torch.tensor([6, 6, 8, 1, 8], device=DEV))
+    assert idx.dtype == torch.long and idx.cpu().tolist() == [1, 1, 2, 0, 2]
+
+    emb = SpeciesEmbedding(embedding_dim=16, allowed_species=[6, 1, 8], materialize=True).to(DEV)
+    data = emb({"atomic_numbers": torch.tensor([6, 6, 8, 1, 8], device=DEV)})
+    assert data["species_index"].cpu().tolist() == [1, 1, 2, 0, 2]
+    want = torch.nn.functional.one_hot(torch.tensor([1, 1, 2, 0, 2]), 3).float()
+    assert torch.equal(data["node_attrs"].cpu(), want)
+    close(data["node_features"], want @ emb.linear.weight.cpu().T + emb.linear.bias.cpu(), 1e-6, "embedding")
+    with pytest.raises(RuntimeError, match="Invalid atomic numbers"):
+        emb({"atomic_numbers": torch.tensor([6, 9], device=DEV)})
+    with pytest.raises(RuntimeError, match="got invalid atomic numbers `7`"):
+        emb({"atomic_numbers": torch.tensor([6, 7], device=DEV)})
+
+
+@pytest.mark.parametrize("w_out", [80, 452, 842, 1216])
+def test_radial_mlp_mfma_vs_oracle(w_out):
+    from matten_amd.nn.utils import RadialMLP
+    from oracle.e3nn_lite.math import soft_one_hot_linspace
+    from oracle.e3nn_lite.nn import FullyConnectedNet
+
+    torch.manual_seed(w_out)
+    E = 1000 + w_out % 7  # ragged tail
+    ref = FullyConnectedNet([8, 32, 32, w_out], act=torch.nn.functional.silu)
+    mlp = RadialMLP([8, 32, 32, w_out], act="silu")
+    mlp.load_state_dict(ref.state_dict())
+    mlp = mlp.to(DEV)
+    r = torch.rand(E) * 5.5 + 0.3  # includes lengths beyond the cutoff (embedding == 0)
+    geom = torch.zeros(E, 4)
+    geom[:, 3] = r
+    emb = soft_one_hot_linspace(r, 0.0, 5.0, 8, basis="bessel", cutoff=True) * 8**0.5
+    want = ref(emb)
+    got = mlp(geom.to(DEV), 8, 0.0, 5.0)
+    assert got.shape[1] % 16 == 0
+    close(got[:, :w_out], want, 5e-5, "radial mlp")
+
+
+@pytest.mark.parametrize("hp_name", ["paper", "lmax2"])
+def test_conv_layers_vs_oracle(hp_name):
+    """Layer-by-layer node features of the backbone on fcc-64 crystals."""
+    from matten_amd.data.graph import collate
+
+    hp = {"paper": PAPER, "lmax2": LMAX2}[hp_name]
+    graphs, ds = _fcc(2)
+    ref, model = build_pair(hp, ds, randomize_bn=True)
+    cpu = collate(graphs)
+    gpu = collate(graphs, device=DEV)
+    with torch.no_grad():
+        for (name, rmod), (_, pmod) in zip(ref.backbone.named_children(), model.backbone.named_children()):
+            cpu = rmod(cpu)
+            gpu = pmod(gpu)
+            if "node_features" in cpu:
+                close(gpu["node_features"], cpu["node_features"], RTOL, f"{hp_name}:{name}:node_features")
+        close(gpu["my_model_output"], cpu["my_model_output"], RTOL, "pooled")
+
+
+def _run_pair(ref, model, graphs):
+    from matten_amd.data.graph import collate
+
+    with torch.no_grad():
+        want = ref.decode(collate(graphs))
+        preds, _ = model(collate(graphs, device=DEV))
+    return preds["elastic_tensor_full"], want
+
+
+def test_config3_fcc64_end_to_end():
+    graphs, ds = _fcc(8)
+    ref, model = build_pair(PAPER, ds, randomize_bn=True)
+    got, want = _run_pair(ref, model, graphs)
+    assert got.shape == (8, 21)
+    close(got, want, RTOL, "fcc64 [B,21]")
+
+
+def test_config2_n100_end_to_end(golden_dir):
+    from matten_amd.data.graph import average_num_neighbors, crystal_graph
+    from oracle.matten_ref.data import structures_from_json
+
+    structs = structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))
+    graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
+    species = sorted({int(z) for s in structs for z in s["atomic_numbers"]})
+    assert len(species) == 73 and sum(g["edge_index"].shape[1] for g in graphs) == 14380
+    ds = {"allowed_species": species, "average_num_neighbors": average_num_neighbors(graphs)}
+    assert abs(ds["average_num_neighbors"] - 30.4017) < 1e-3
+    ref, model = build_pair(PAPER, ds, randomize_bn=True)
+    got, want = _run_pair(ref, model, graphs)
+    assert got.shape == (100, 21)
+    close(got, want, RTOL, "n100 [B,21]")
+
+
+def test_config1_si_diamond_cubic_symmetry():
+    """README Si cell (reference README.md:34-40): E=56, and the prediction has cubic structure."""
+    from matten_amd.data.graph import crystal_graph
+    from matten_amd.utils import CartesianTensorWrapper
+
+    a = 5.46
+    lat = np.array([[0, a / 2, a / 2], [a / 2, 0, a / 2], [a / 2, a / 2, 0]])
+    pos = np.array([[0.0, 0.0, 0.0], [0.25, 0.25, 0.25]]) @ lat
+    g = crystal_graph(pos, lat, [14, 14], 5.0)
+    assert g["edge_index"].shape[1] == 56
+    ds = {"allowed_species": [14], "average_num_neighbors": 28.0}
+    ref, model = build_pair(PAPER, ds)
+    got, want = _run_pair(ref, model, [g])
+    close(got, want, RTOL, "Si [1,21]")
+    C = CartesianTensorWrapper("ijkl=jikl=klij").to_cartesian(got)[0].cpu().double()
+    scale = C.abs().max().item()
+    c11, c22, c33 = C[0, 0, 0, 0], C[1, 1, 1, 1], C[2, 2, 2, 2]
+    c12, c13, c23 = C[0, 0, 1, 1], C[0, 0, 2, 2], C[1, 1, 2, 2]
+    c44, c55, c66 = C[1, 2, 1, 2], C[0, 2, 0, 2], C[0, 1, 0, 1]
+    for x, y in [(c11, c22), (c11, c33), (c12, c13), (c12, c23), (c44, c55), (c44, c66)]:
+        assert abs(x - y) <= 1e-4 * scale
+
+
+def test_reference_equivariance_test_on_gpu(golden_dir):
+    """reference tests/model/test_tfn_tensor.py:98-139, run through the HIP backbone."""
+    from matten_amd.data.graph import collate, crystal_graph
+    from matten_amd.utils import ToCartesian
+    from oracle.e3nn_lite import o3 as ro3
+    from oracle.matten_ref.data import structures_from_json
+
+    s = structures_from_json(os.path.join(golden_dir, "elastic_tensor_one.json"))[0]
+    torch.manual_seed(35)
+    Q = ro3.rand_matrix().double()
+    g1 = crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0)
+    g2 = crystal_graph(s["cart_coords"] @ Q.numpy().T, s["lattice"] @ Q.numpy().T, s["atomic_numbers"], 5.0)
+    assert g1["edge_index"].shape[1] == 252
+    ref, model = build_pair(EQUIV_TEST, {"allowed_species": [8, 52]})
+    tc = ToCartesian("ijkl=jikl=klij")
+    with torch.no_grad():
+        o1 = tc(model.backbone(collate([g1], device=DEV))["my_model_output"])[0].cpu()
+        o2 = tc(model.backbone(collate([g2], device=DEV))["my_model_output"])[0].cpu()
+        w1 = ref.backbone(collate([g1]))["my_model_output"]
+    close(model.backbone(collate([g1], device=DEV))["my_model_output"], w1, RTOL, "TeO fixture")
+    assert torch.allclose(o1, o1.swapaxes(0, 1))
+    assert torch.allclose(o1, o1.swapaxes(2, 3))
+    assert torch.allclose(o1, o1.swapaxes(0, 2).swapaxes(1, 3))
+    Qf = Q.float()
+    x = torch.einsum("im,jn,kp,lq,mnpq->ijkl", Qf, Qf, Qf, Qf, o1)
+    assert torch.allclose(x, o2, atol=1e-4)
+
+
+def test_edge_order_invariance_and_determinism():
+    """Permuting the edge list must not change the result beyond fp32 reordering; same input twice is bitwise equal."""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _fcc(2)
+    _, model = build_pair(PAPER, ds)
+    b = collate(graphs, device=DEV)
+    with torch.no_grad():
+        y1 = model.decode(dict(b))["elastic_tensor_full"]
+        y1b = model.decode(dict(b))["elastic_tensor_full"]
+        E = b["edge_index"].shape[1]
+        p = torch.randperm(E, generator=torch.Generator().manual_seed(0)).to(DEV)
+        b2 = dict(b)
+        b2["edge_index"] = b["edge_index"][:, p].contiguous()
+        b2["edge_cell_shift"] = b["edge_cell_shift"][p].contiguous()
+        y2 = model.decode(b2)["elastic_tensor_full"]
+    assert torch.equal(y1, y1b)
+    close(y2, y1, 1e-4, "edge permutation")
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from matten_amd import _lib
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _fcc(1)
+    _, model = build_pair(PAPER, ds)
+    with pytest.raises(_lib.MattenHipError, match="no CPU fallback"):
+        model.backbone(collate(graphs))
