@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the MI355X message-passing hot path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one full backbone + out_layer forward (a1-a13 of SURVEY.md section 8) over one batch of
+synthetic 64-atom fcc crystals already resident in HBM (BASELINE.json configs[2]: 1000 crystals,
+cutoff 5 A, 1152 edges each), per rank.  With N ranks the crystals are sharded by batch index
+(rank r owns crystals [r*B, (r+1)*B)), no data-path collective, and each step ends with ONE RCCL
+all_gather_into_tensor of the [B,21] predictions (configs[4]).  value = edge tensor-products/s over
+all ranks: one edge-TP = one (edge, conv layer) evaluation, 4 conv layers => 4 per edge per forward.
+
+Printed by rank 0: one JSON line with the driver contract fields plus
+  "roofline"     -- the dominant kernel (last conv layer's TP+scatter) against the HBM roofline
+  "cpu_baseline" -- the CPU oracle (a restatement of the reference's e3nn path, NOT e3nn itself;
+                    e3nn cannot be installed on either box) timed on a bounded sample, rank 0, N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+B_ALG_PER_EDGE_TP = 4816.0  # mean algorithmic bytes per edge-TP, 2-kernel architecture
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--crystals", type=int, default=1000, help="crystals per rank per step (one batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="crystals in the CPU-oracle sample batch")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_tp_kernel(plan, deg: float) -> float:
+    """Per-edge algorithmic bytes of ONE TP+scatter launch (DESIGN.md 'kernels'): edge ids (8) + edge
+    vector (12) + the per-edge weights read once (4 W) + node rows amortised over the degree."""
+    return 8.0 + 12.0 + 4.0 * plan.weight_numel + 4.0 * (plan.d_in + plan.d_mid) / deg
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from __graft_entry__ import PAPER_HPARAMS
+    from matten_amd import ops
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import collate
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+
+    B = args.crystals
+    # rank r owns crystals [r*B, (r+1)*B) of the global synthetic set (seed offset per shard)
+    graphs = synthetic.fcc64_graphs(B, seed=synthetic.FCC_SEED + rank)
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    torch.manual_seed(35)
+    model = ScalarTensorModel(backbone_hparams=dict(PAPER_HPARAMS), dataset_hparams=ds).to(dev).eval()
+    batch = collate(graphs, device=dev)
+    n_edges = int(batch["edge_index"].shape[1])
+    n_nodes = int(batch["pos"].shape[0])
+    gathered = torch.empty(world * B, 21, dtype=torch.float32, device=dev) if distributed else None
+
+    def step():
+        with torch.no_grad():
+            preds, _ = model(dict(batch))
+            out = preds["elastic_tensor_full"]
+            if distributed:
+                dist.all_gather_into_tensor(gathered, out)
+                return gathered
+            return out
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.enable_event_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ops.event_timings_ms()
+    ops.enable_event_timing(False)
+    assert torch.isfinite(out).all()
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_layers = PAPER_HPARAMS["num_layers"] + 1
+    edge_tp_per_step = n_edges * n_layers * world
+    value = edge_tp_per_step * args.steps / elapsed
+    crystals_per_s = B * world * args.steps / elapsed
+
+    result = {
+        "metric": "edge_tensor_products_per_sec",
+        "value": value,
+        "unit": "edge-TP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "crystals_per_sec": crystals_per_s,
+        "config": {
+            "workload": "configs[2]: synthetic fcc-64 crystals (64 atoms, cutoff 5 A, 1152 edges each), "
+                        "paper hparams lmax=4, eval forward backbone+out_layer, one batch per step per GPU",
+            "crystals_per_gpu_per_step": B,
+            "nodes_per_gpu": n_nodes,
+            "edges_per_gpu": n_edges,
+            "conv_layers": n_layers,
+            "sharding": f"batch-index x{world}, one all_gather of [B,21] per step" if distributed else "single GPU",
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: TP + scatter of the last conv layer ----
+        last = model.backbone.conv_layer_last.tp.plan
+        deg = n_edges / n_nodes
+        key = f"tp_scatter/d_mid={last.d_mid}"
+        per_kernel = {k: sum(v) / len(v) for k, v in kernel_ms.items()}
+        if key in per_kernel:
+            dur_s = per_kernel[key] * 1e-3
+            bytes_per_launch = algorithmic_bytes_tp_kernel(last, deg) * n_edges
+            achieved = bytes_per_launch / dur_s / 1e9
+            result["roofline"] = {
+                "kernel": "tp_scatter_kernel (conv_layer_last: 103 paths, d_mid 4170)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s",
+                "frac": achieved / (HBM_PEAK / 1e9),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": per_kernel[key],
+            }
+        result["kernel_ms_per_launch"] = per_kernel
+        result["path_roofline"] = {
+            "definition": "edge-TP/s x 4816 B (SURVEY 8d two-kernel algorithmic bytes) / 8.0e12 B/s, per GPU",
+            "frac": value / world * B_ALG_PER_EDGE_TP / HBM_PEAK,
+        }
+
+        # ---- CPU baseline: the oracle on a bounded sample of the same workload ----
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.matten_ref.model import ScalarTensorOracle
+
+            # The oracle's per-path einsums are small: beyond ~16 threads it gets slower, not faster
+            # (256 host threads on the MI355X box: >100x slower), so the baseline uses at most 16.
+            nthreads = min(os.cpu_count() or 1, 16)
+            torch.set_num_threads(nthreads)
+            ref = ScalarTensorOracle(dict(PAPER_HPARAMS), ds).eval()
+            ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=False)
+            sample = collate(graphs[: args.cpu_sample])
+            e_sample = int(sample["edge_index"].shape[1])
+            with torch.no_grad():
+                ref.decode(dict(sample))  # warm-up
+                times = []
+                t_budget = time.perf_counter()
+                while len(times) < 5 and (time.perf_counter() - t_budget) < 20.0:
+                    t1 = time.perf_counter()
+                    want = ref.decode(dict(sample))
+                    times.append(time.perf_counter() - t1)
+            times.sort()
+            med = times[len(times) // 2]
+            got = out[: args.cpu_sample].cpu()
+            err = (got - want).abs().max().item()
+            result["cpu_baseline"] = {
+                "value": e_sample * n_layers / med,
+                "unit": "edge-TP/s",
+                "cores": nthreads,
+                "kind": "port",
+                "sample": f"{args.cpu_sample} fcc-64 crystals ({e_sample} edges) per forward, median of {len(times)} "
+                          f"forwards after 1 warm-up; pure-PyTorch fp32 restatement of the e3nn path (not e3nn)",
+                "crystals_per_sec": args.cpu_sample / med,
+                "max_abs_diff_vs_gpu": err,
+            }
+        print(json.dumps(result), flush=True)
+
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

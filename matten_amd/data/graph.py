@@ -16,6 +16,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
+from scipy.spatial import cKDTree
 
 
 def neighbor_list(pos: np.ndarray, cell: np.ndarray, r_cut: float):
@@ -31,28 +32,23 @@ def neighbor_list(pos: np.ndarray, cell: np.ndarray, r_cut: float):
     span = frac.max(0) - frac.min(0) if n else np.zeros(3)
     reach = np.ceil(rc / plane_dist + span).astype(int)
 
-    ii, jj, ss = [], [], []
-    rc2 = rc * rc
-    for sx in range(-reach[0], reach[0] + 1):
-        for sy in range(-reach[1], reach[1] + 1):
-            for sz in range(-reach[2], reach[2] + 1):
-                t = sx * cell[0] + sy * cell[1] + sz * cell[2]
-                d = (pos[None, :, :] + t) - pos[:, None, :]          # [i, j, 3]
-                d2 = np.einsum("ijk,ijk->ij", d, d)
-                ok = np.sqrt(d2) < rc
-                if sx == 0 and sy == 0 and sz == 0:
-                    np.fill_diagonal(ok, False)
-                i, j = np.nonzero(ok)
-                if i.size:
-                    ii.append(i)
-                    jj.append(j)
-                    ss.append(np.broadcast_to(np.array([sx, sy, sz], dtype=np.int64), (i.size, 3)))
-    _ = rc2
-    if not ii:
+    # candidate images: every lattice shift in the reach box; a KD-tree over the image atoms prunes
+    # the pair search, the strict fp64 test below decides (same expression as the brute-force form)
+    rng = [np.arange(-m, m + 1) for m in reach]
+    S = np.stack(np.meshgrid(*rng, indexing="ij"), axis=-1).reshape(-1, 3)
+    T = S @ cell
+    img = (pos[None, :, :] + T[:, None, :]).reshape(-1, 3)  # [ns*n, 3], index = s*n + j
+    tree = cKDTree(img)
+    cand = tree.query_ball_point(pos, rc * (1.0 + 1e-9) + 1e-9)
+    i = np.repeat(np.arange(n), [len(c) for c in cand])
+    flat = np.concatenate([np.asarray(c, dtype=np.int64) for c in cand]) if len(i) else np.zeros(0, dtype=np.int64)
+    sidx, j = flat // n, flat % n
+    d = (pos[j] + T[sidx]) - pos[i]
+    ok = np.sqrt((d * d).sum(-1)) < rc
+    ok &= ~((i == j) & np.all(S[sidx] == 0, axis=1))
+    i, j, s = i[ok], j[ok], S[sidx[ok]]
+    if i.size == 0:
         raise ValueError("After eliminating self edges, no edges remain in this system.")
-    i = np.concatenate(ii)
-    j = np.concatenate(jj)
-    s = np.concatenate(ss)
     order = np.lexsort((s[:, 2], s[:, 1], s[:, 0], j, i))
     return np.stack([i[order], j[order]]).astype(np.int64), s[order].astype(np.int64)
 

@@ -14,6 +14,40 @@ import torch
 from . import _lib
 
 
+# ---- optional HIP-event timing of individual launches (used by bench.py for the roofline line) ----
+_EVENTS = None  # name -> list of (start_event, end_event) recorded on the launch stream
+
+
+def enable_event_timing(flag: bool = True) -> None:
+    global _EVENTS
+    _EVENTS = {} if flag else None
+
+
+def event_timings_ms():
+    """name -> list of elapsed milliseconds (call after torch.cuda.synchronize())."""
+    if _EVENTS is None:
+        return {}
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in _EVENTS.items()}
+
+
+class _timed:
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if _EVENTS is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if _EVENTS is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record(torch.cuda.current_stream())
+            _EVENTS.setdefault(self.name, []).append((self.a, b))
+        return False
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -118,11 +152,10 @@ def radial_mlp(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p
     nb_pad, hidden = w0p.shape
     w_pad = w2p.shape[1]
     out = torch.empty(E, w_pad, dtype=torch.float32, device=geom_sorted.device)
-    _lib.check(
-        lib.matten_radial_mlp(_ptr(geom_sorted), E, n_basis, r_start, r_end, _ptr(w0p), nb_pad, _ptr(w1p), _ptr(w2p),
-                              hidden, w_pad, 1.0, _ptr(out), _stream()),
-        "matten_radial_mlp",
-    )
+    with _timed(f"radial_mlp/w_pad={w_pad}"):
+        rc = lib.matten_radial_mlp(_ptr(geom_sorted), E, n_basis, r_start, r_end, _ptr(w0p), nb_pad, _ptr(w1p),
+                                   _ptr(w2p), hidden, w_pad, 1.0, _ptr(out), _stream())
+    _lib.check(rc, "matten_radial_mlp")
     return out
 
 
@@ -138,13 +171,12 @@ def tp_scatter(x, w_edge, sh_sorted, rowptr, src_sorted, m_idx, m_coef, out_meta
     if num_neigh is not None:
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
     agg = torch.empty(N, d_mid, dtype=torch.float32, device=x.device)
-    _lib.check(
-        lib.matten_tp_scatter(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
-                              _ptr(rowptr), _ptr(src_sorted), N, _ptr(m_idx), _ptr(m_coef), m_total, m_nterms,
-                              _ptr(out_meta), d_mid, float(avg_num_neighbors or 0.0), _ptr(num_neigh), _ptr(agg),
-                              _stream()),
-        "matten_tp_scatter",
-    )
+    with _timed(f"tp_scatter/d_mid={d_mid}"):
+        rc = lib.matten_tp_scatter(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
+                                   _ptr(rowptr), _ptr(src_sorted), N, _ptr(m_idx), _ptr(m_coef), m_total, m_nterms,
+                                   _ptr(out_meta), d_mid, float(avg_num_neighbors or 0.0), _ptr(num_neigh),
+                                   _ptr(agg), _stream())
+    _lib.check(rc, "matten_tp_scatter")
     return agg
 
 

@@ -551,15 +551,28 @@ class TensorProduct(torch.nn.Module):
                 w = weight[..., flat : flat + n].reshape(((-1,) if not self.shared_weights else ()) + ins.path_shape)
                 flat += n
             w3j = wigner_3j(mul_ir_in1.ir.l, mul_ir_in2.ir.l, mul_ir_out.ir.l, dtype=x1.dtype).to(x1.device)
+            # Contraction order: e3nn's generated code contracts each instruction with an optimised
+            # einsum path (opt_einsum_fx); the orders below are such paths, written out.
             if ins.connection_mode == "uvw":
                 assert ins.has_weight
-                r = torch.einsum(f"{z}uvw,ijk,zui,zvj->zwk", w, w3j, a, b)
+                if mul_ir_in2.ir.l == 0 and self.shared_weights:
+                    # scalar second operand (the one-hot species vector of reference nn/conv.py:59-86)
+                    wz = torch.einsum("uvw,zv->zuw", w, b[:, :, 0])
+                    r = torch.einsum("zuw,zui,ik->zwk", wz, a, w3j[:, 0, :])
+                else:
+                    r = torch.einsum(f"{z}uvw,ijk,zui,zvj->zwk", w, w3j, a, b)
             elif ins.connection_mode == "uvu":
                 assert mul_ir_in1.mul == mul_ir_out.mul
-                if ins.has_weight:
-                    r = torch.einsum(f"{z}uv,ijk,zui,zvj->zuk", w, w3j, a, b)
+                m = torch.einsum("ijk,zvj->zvik", w3j, b)  # per-sample coupling matrices
+                if mul_ir_in2.mul == 1:
+                    r = torch.bmm(a, m[:, 0])  # [z,u,k]
+                    if ins.has_weight:
+                        r = r * (w[..., 0, None] if not self.shared_weights else w[None, :, 0, None])
                 else:
-                    r = torch.einsum("ijk,zui,zvj->zuk", w3j, a, b)
+                    if ins.has_weight:
+                        r = torch.einsum(f"{z}uv,zui,zvik->zuk", w, a, m)
+                    else:
+                        r = torch.einsum("zui,zvik->zuk", a, m)
             else:
                 raise NotImplementedError(ins.connection_mode)
             r = ins.path_weight * r
