@@ -112,6 +112,20 @@ int matten_tp_scatter(const float* x /*[N,d_in]*/, int64_t d_in, const float* w_
                       const float* num_neigh, float* agg /*[N,d_mid]*/, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Same operator as matten_tp_scatter (reference nn/utils.py:230-237,263 + nn/conv.py:113-120),
+ * production kernel: one wave per (path, node group), a lane owns one output channel of one
+ * destination node, CG coefficients are compile-time literals (l <= 4).
+ *   path_entries[n_entries, 8] int32 {l1*25+l2*5+l3, x_off, w_off, out_off, mul(<=64), log2(lanes per node), 0, 0}
+ *   unit_start[n_entries+1]   int32  prefix sum of waves per node tile (matten_tp_tile_nodes() nodes per tile)
+ * ------------------------------------------------------------------------------------------ */
+int matten_tp_tile_nodes(void);
+int matten_tp_paths(const float* x, int64_t d_in, const float* w_edge, int64_t w_pad, const float* sh_sorted,
+                    int64_t sh_dim, const int32_t* rowptr, const int32_t* src_sorted, int64_t n_nodes,
+                    const int32_t* path_entries, const int32_t* unit_start, int64_t n_entries,
+                    int64_t units_per_tile, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
+                    float* agg /*[N,d_mid]*/, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * FullyConnectedTensorProduct(x, one_hot(species)) == species-indexed per-irrep linear
  * (nn/conv.py:59-61,77-79,84-86 called :109,112,123), and e3nn o3.Linear when species == NULL
  * (nn/nodewise.py:111-117, model_factory/tfn_scalar_tensor.py:49-51,68).

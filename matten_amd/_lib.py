@@ -26,6 +26,8 @@ SIGNATURES = {
     "matten_edge_geom": (c_int, [P, P, P, P, c_int64, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P]),
     "matten_radial_mlp": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, P, c_int, c_int, c_float, P, P]),
     "matten_tp_scatter": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, P, c_int64, c_float, P, P, P]),
+    "matten_tp_tile_nodes": (c_int, []),
+    "matten_tp_paths": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_float, P, P, P]),
     "matten_species_linear": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, P, P]),
     "matten_gate_bn": (c_int, [P, c_int64, P, c_int64, P, P, P, P, P, c_float, c_int64, P, P]),
     "matten_segment_reduce": (c_int, [P, c_int64, P, c_int64, c_int, P, P]),

@@ -11,6 +11,7 @@ Equivariant building blocks of the conv layer on MI355X (mirrors reference nn/ut
 
 Parameters keep the reference's names, shapes and flat layouts.
 """
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -121,8 +122,12 @@ class UVUTensorProduct(torch.nn.Module):
         layer_sizes = [mlp_input_size] + mlp_num_hidden_layers * [mlp_hidden_size] + [self.weight_numel]
         self.weight_nn = RadialMLP(layer_sizes, act=mlp_activation)
         self._tables = DeviceTables(
-            m_idx=self.plan.m_terms_idx, m_coef=self.plan.m_terms_coef, out_meta=self.plan.out_meta
+            m_idx=self.plan.m_terms_idx, m_coef=self.plan.m_terms_coef, out_meta=self.plan.out_meta,
+            entries=self.plan.path_entries, unit_start=self.plan.unit_start,
         )
+        # "paths": per-path kernel with literal CG coefficients (production);
+        # "table": table-driven kernel (kept as an independent second implementation for tests)
+        self.impl = os.environ.get("MATTEN_TP_IMPL", "paths")
 
     @property
     def irreps_out(self) -> Irreps:
@@ -133,6 +138,14 @@ class UVUTensorProduct(torch.nn.Module):
         nb, r0, r1 = data[DataKey.AMD_RBF].tolist()
         w_edge = self.weight_nn(data[DataKey.AMD_GEOM], int(nb), r0, r1)
         dev = node_feats.device
+        avg = avg_num_neighbors if avg_num_neighbors is not None else 0.0
+        num_neigh = None if avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
+        if self.impl == "paths":
+            return ops.tp_paths(
+                node_feats, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
+                self._tables.get("entries", dev), self._tables.get("unit_start", dev), self.plan.units_per_tile,
+                self.plan.d_mid, avg, num_neigh,
+            )
         return ops.tp_scatter(
             node_feats, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
             self._tables.get("m_idx", dev), self._tables.get("m_coef", dev), self._tables.get("out_meta", dev),

@@ -20,6 +20,8 @@ import numpy as np
 
 from .o3 import Irrep, Irreps, wigner_3j
 
+TP_TILE_NODES = 32  # must equal matten_tp_tile_nodes() of the library (checked at first use)
+
 ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
 
 
@@ -69,6 +71,10 @@ class UVUPlan:
     m_terms_coef: np.ndarray     # f32   [m_total, m_nterms]
     out_meta: np.ndarray         # int32 [d_mid, 4]
     cg_nnz: int = 0
+    # per-path kernel (matten_tp_paths): one entry per <=64-channel chunk of a path
+    path_entries: np.ndarray = None   # int32 [n_entries, 8]
+    unit_start: np.ndarray = None     # int32 [n_entries + 1] waves per node tile, prefix sum
+    units_per_tile: int = 0
 
 
 def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
@@ -146,10 +152,24 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
             for k in range(d3):
                 o = p.out_off + u * d3 + k
                 meta[o] = (p.x_off + u * d1, p.w_off + u, p.m_off + k, d1 | (d3 << 8))
+    entries, ustart = [], [0]
+    for p in paths:
+        d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
+        for u0 in range(0, p.mul, 64):
+            mul_c = min(64, p.mul - u0)
+            cu_log2 = max(0, (mul_c - 1).bit_length())
+            cu = 1 << cu_log2
+            nodes_per_wave = max(1, 64 // cu)
+            waves = -(-TP_TILE_NODES // nodes_per_wave)
+            entries.append((p.l1 * 25 + p.l2 * 5 + p.l3, p.x_off + u0 * d1, p.w_off + u0, p.out_off + u0 * d3, mul_c,
+                            cu_log2, 0, 0))
+            ustart.append(ustart[-1] + waves)
     return UVUPlan(
         irreps_in1=irreps_in1, irreps_sh=irreps_sh, irreps_mid=irreps_mid, irreps_out=irreps_mid.simplify(),
         paths=paths, weight_numel=w_off, d_in=irreps_in1.dim, d_mid=d_mid, sh_dim=irreps_sh.dim,
         m_total=m_total, m_nterms=m_nterms, m_terms_idx=idx, m_terms_coef=coef, out_meta=meta, cg_nnz=cg_nnz,
+        path_entries=np.array(entries, dtype=np.int32), unit_start=np.array(ustart, dtype=np.int32),
+        units_per_tile=ustart[-1],
     )
 
 

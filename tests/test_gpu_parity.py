@@ -258,3 +258,54 @@ def test_cpu_tensors_are_rejected_loudly():
     _, model = build_pair(PAPER, ds)
     with pytest.raises(_lib.MattenHipError, match="no CPU fallback"):
         model.backbone(collate(graphs))
+
+
+@pytest.mark.parametrize("per_node_norm", [False, True])
+def test_tp_kernels_agree_and_match_oracle(per_node_norm):
+    """The per-path kernel (literal CG) and the table-driven kernel are independent implementations of
+    the same operator: both must match the oracle's TensorProduct + scatter on ragged n100 crystals."""
+    from matten_amd import ops, plan as mplan
+    from matten_amd.data.graph import collate, crystal_graph
+    from matten_amd.nn._tables import DeviceTables
+    from matten_amd.o3 import Irreps
+    from oracle.e3nn_lite.scatter import scatter
+    from oracle.matten_ref import nn as rnn
+    from oracle.matten_ref.data import structures_from_json
+
+    structs = structures_from_json(os.path.join(os.path.dirname(__file__), "golden",
+                                                "example_crystal_elasticity_tensor_n100.json"))[:12]
+    graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
+    cpu = collate(graphs)
+    irreps_in = "32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e"
+    sh = Irreps.spherical_harmonics(4)
+    torch.manual_seed(3)
+    ref_tp = rnn.UVUTensorProduct(irreps_in, str(sh), irreps_in, mlp_input_size=8, mlp_hidden_size=32,
+                                  mlp_num_hidden_layers=2, mlp_activation=torch.nn.functional.silu)
+    N, E = cpu["pos"].shape[0], cpu["edge_index"].shape[1]
+    x = torch.randn(N, ref_tp.tp.irreps_in1.dim)
+    w = torch.randn(E, ref_tp.tp.weight_numel)
+    ref = dict(cpu)
+    rnn.SphericalHarmonicEdgeAttrs(4)(ref)
+    msg = ref_tp.tp(x[cpu["edge_index"][0]], ref["edge_attrs"], w)
+    want = scatter(msg, cpu["edge_index"][1], dim_size=N)
+    want = want / (cpu["num_neigh"].reshape(-1, 1) ** 0.5 if per_node_norm else 18.0**0.5)
+
+    p = mplan.plan_uvu(irreps_in, sh, irreps_in)
+    assert p.weight_numel == ref_tp.tp.weight_numel and p.d_mid == msg.shape[1]
+    t = DeviceTables(m_idx=p.m_terms_idx, m_coef=p.m_terms_coef, out_meta=p.out_meta, entries=p.path_entries,
+                     unit_start=p.unit_start)
+    g = _to(cpu, DEV)
+    perm, rowptr, src, _ = ops.csr_build(g["edge_index"], N)
+    geo = ops.edge_geom(g["pos"], g["edge_index"], g["edge_cell_shift"], g["cell"], g["batch"], perm, 4)
+    w_pad = (p.weight_numel + 15) // 16 * 16
+    w_sorted = torch.zeros(E, w_pad, device=DEV)
+    w_sorted[:, : p.weight_numel] = w.to(DEV)[perm.long()]
+    avg = 0.0 if per_node_norm else 18.0
+    nn_ = g["num_neigh"] if per_node_norm else None
+    a = ops.tp_paths(x.to(DEV), w_sorted, geo["sh_sorted"], rowptr, src, t.get("entries", DEV),
+                     t.get("unit_start", DEV), p.units_per_tile, p.d_mid, avg, nn_)
+    b = ops.tp_scatter(x.to(DEV), w_sorted, geo["sh_sorted"], rowptr, src, t.get("m_idx", DEV), t.get("m_coef", DEV),
+                       t.get("out_meta", DEV), avg, nn_)
+    close(a, want, 2e-5, "tp_paths vs oracle")
+    close(b, want, 2e-5, "tp_scatter vs oracle")
+    close(a, b, 2e-5, "tp_paths vs tp_scatter")
