@@ -1,0 +1,170 @@
+"""
+``predict`` / ``evaluate``: the reference's public inference API (predict.py:117-245) on MI355X.
+
+Same signature and semantics: one structure or a list in, one tensor or a list out in input order,
+``None`` (plus a warning) for structures whose graph cannot be built, ``RuntimeError`` for species the
+model was not trained on.  Differences, all forced by the environment: structures are duck-typed
+(``.lattice.matrix`` / ``.cart_coords`` / ``.atomic_numbers``, or dicts with keys ``lattice`` /
+``cart_coords`` / ``atomic_numbers``) so pymatgen is optional -- when it is importable and
+``is_elasticity_tensor`` is set the result is wrapped in ``ElasticTensor`` exactly like the reference,
+otherwise a ``numpy [3,3,3,3]`` array is returned -- and the checkpoint is a plain ``torch.save`` of
+{"state_dict", "hyper_parameters"} or a Lightning ``.ckpt`` with the same two keys.
+"""
+import warnings
+from pathlib import Path
+from typing import Any, Dict, List, Sequence, Union
+
+import numpy as np
+import torch
+
+from .data.graph import collate, crystal_graph
+from .model_factory.tfn_scalar_tensor import ScalarTensorModel
+from .parallel import sharded_apply
+from .utils import CartesianTensorWrapper, yaml_load
+
+
+def get_pretrained_model_dir(identifier: str) -> Path:
+    p = Path(identifier)
+    if p.exists() and p.is_dir():
+        return p
+    return Path(__file__).parent.parent / "pretrained" / identifier
+
+
+def get_pretrained_config(identifier: str, config_filename: str = "config_final.yaml"):
+    return yaml_load(get_pretrained_model_dir(identifier) / config_filename)
+
+
+def get_pretrained_model(identifier: str, checkpoint: str = "model_final.ckpt", model_class=ScalarTensorModel,
+                         device="cuda"):
+    path = get_pretrained_model_dir(identifier) / checkpoint
+    if not path.exists():
+        raise FileNotFoundError(
+            f"{path} not found. (The reference's own pretrained/20230627/model_final.ckpt is a large blob that is "
+            "not shipped with the source tree; pass a directory holding model_final.ckpt + config_final.yaml.)"
+        )
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    hp = ckpt["hyper_parameters"]
+    model = model_class(
+        tasks=hp.get("tasks"), backbone_hparams=hp["backbone_hparams"], dataset_hparams=hp["dataset_hparams"],
+        optimizer_hparams=hp.get("optimizer_hparams"), lr_scheduler_hparams=hp.get("lr_scheduler_hparams"),
+    )
+    missing, unexpected = model.load_state_dict(ckpt["state_dict"], strict=False)
+    tolerated = ("output_mask", "tp.tp.weight")  # e3nn-internal buffers a reference checkpoint carries
+    bad = [k for k in unexpected if not k.endswith(tolerated) and "metrics" not in k]
+    if missing or bad:
+        raise RuntimeError(f"checkpoint does not match the model: missing={missing} unexpected={bad}")
+    return model.to(device).eval()
+
+
+def _fields(s) -> Dict[str, np.ndarray]:
+    if isinstance(s, dict):
+        return {"lattice": np.asarray(s["lattice"]), "cart_coords": np.asarray(s["cart_coords"]),
+                "atomic_numbers": np.asarray(s["atomic_numbers"])}
+    return {"lattice": np.asarray(s.lattice.matrix), "cart_coords": np.asarray(s.cart_coords),
+            "atomic_numbers": np.asarray(s.atomic_numbers)}
+
+
+def check_species(model, structures: Sequence):
+    supported = set(int(z) for z in model.hparams["dataset_hparams"]["allowed_species"])
+    for i, s in enumerate(structures):
+        numbers = set(int(z) for z in _fields(s)["atomic_numbers"])
+        if not numbers.issubset(supported):
+            not_supported = ", ".join(str(z) for z in sorted(numbers - supported))
+            raise RuntimeError(
+                f"Cannot make predictions for structure {i}. It contains species {not_supported} not supported by "
+                f"the model. The model were trained with species {supported}."
+            )
+
+
+def build_graphs(structures: Sequence, r_cut: float):
+    """-> (graphs, failed indices): per-structure try/except like the reference dataset
+    (dataset/structure_scalar_tensor.py:296-362)."""
+    graphs, failed = [], []
+    for i, s in enumerate(structures):
+        try:
+            f = _fields(s)
+            graphs.append(crystal_graph(f["cart_coords"], f["lattice"], f["atomic_numbers"], r_cut))
+        except Exception as e:  # noqa: BLE001
+            warnings.warn(f"Failed converting structure {i}, Skip it. {e}")
+            failed.append(i)
+    if not graphs:
+        raise RuntimeError("Cannot successfully convert any structures.")
+    return graphs, failed
+
+
+def evaluate(model, graphs: List[Dict[str, torch.Tensor]], batch_size: int = 200,
+             tensor_target_name: str = "elastic_tensor_full", tensor_target_formula: str = "ijkl=jikl=klij",
+             distributed: bool = False) -> List[torch.Tensor]:
+    """Batched forward; returns one Cartesian tensor per graph (on the host).  With ``distributed`` the
+    graphs are sharded by index over the ranks and gathered with one collective per call."""
+    converter = CartesianTensorWrapper(tensor_target_formula)
+    device = model.device
+    rank_dims = (3,) * len(tensor_target_formula.split("=")[0].replace("-", ""))
+
+    def run(shard):
+        outs = []
+        with torch.no_grad():
+            for lo in range(0, len(shard), batch_size):
+                batch = collate(shard[lo : lo + batch_size], device=device)
+                preds, _ = model(batch, task_name=tensor_target_name)
+                p = preds[tensor_target_name]
+                if p.dim() == 2:  # irreps -> Cartesian on the GPU
+                    p = converter.to_cartesian(p)
+                outs.append(p)
+        return torch.cat(outs, dim=0)
+
+    model.eval()
+    if distributed:
+        preds = sharded_apply(run, graphs, rank_dims, device)
+    else:
+        preds = run(graphs)
+    return list(preds.cpu())
+
+
+def predict(
+    structure,
+    model_identifier="20230627",
+    checkpoint: str = "model_final.ckpt",
+    batch_size: int = 200,
+    logger_level: str = "ERROR",
+    is_elasticity_tensor: bool = True,
+    is_atomic_tensor: bool = False,
+    model: ScalarTensorModel = None,
+    config: Dict[str, Any] = None,
+):
+    """See the module docstring.  ``model`` / ``config`` let a caller reuse an already loaded model."""
+    if is_atomic_tensor:
+        raise NotImplementedError("the atomic (NMR) tensor model is outside the accelerated path")
+    single = not isinstance(structure, (list, tuple))
+    structures = [structure] if single else list(structure)
+
+    if model is None:
+        model = get_pretrained_model(model_identifier, checkpoint)
+    if config is None:
+        config = get_pretrained_config(model_identifier)
+    check_species(model, structures)
+    graphs, failed = build_graphs(structures, r_cut=config["data"]["r_cut"])
+    predictions = evaluate(
+        model, graphs, batch_size=batch_size,
+        tensor_target_name=config["data"]["tensor_target_name"],
+        tensor_target_formula=config["data"]["tensor_target_formula"],
+    )
+    predictions = [t.numpy() for t in predictions]
+    if is_elasticity_tensor:
+        try:
+            from pymatgen.analysis.elasticity import ElasticTensor
+
+            predictions = [ElasticTensor(t) for t in predictions]
+        except ImportError:
+            pass
+
+    if failed:
+        failed_set, it = set(failed), iter(predictions)
+        out = [None if i in failed_set else next(it) for i in range(len(structures))]
+        warnings.warn(
+            "Cannot make predictions for the following structures. Their returned "
+            f"elasticity tensor set to `None`: {sorted(failed_set)}."
+        )
+    else:
+        out = predictions
+    return out[0] if single else out

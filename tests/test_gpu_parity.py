@@ -309,3 +309,41 @@ def test_tp_kernels_agree_and_match_oracle(per_node_norm):
     close(a, want, 2e-5, "tp_paths vs oracle")
     close(b, want, 2e-5, "tp_scatter vs oracle")
     close(a, b, 2e-5, "tp_paths vs tp_scatter")
+
+
+def test_predict_api_end_to_end(tmp_path):
+    """matten.predict semantics (reference predict.py:151-245): list in -> list out in order, None for
+    structures whose graph cannot be built, single structure -> single tensor; values == oracle."""
+    import yaml
+
+    from matten_amd import predict as P
+    from matten_amd.data import synthetic
+    from oracle.matten_ref import data as rdata
+    from oracle.matten_ref.model import ToCartesian
+
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    hp = dict(PAPER)
+    ref, model = build_pair(hp, ds, randomize_bn=True, device=None)
+    torch.save({"state_dict": model.state_dict(),
+                "hyper_parameters": {"backbone_hparams": hp, "dataset_hparams": ds, "tasks": None}},
+               tmp_path / "model_final.ckpt")
+    cfg = {"data": {"r_cut": 5.0, "tensor_target_name": "elastic_tensor_full",
+                    "tensor_target_formula": "ijkl=jikl=klij", "tensor_target_format": "irreps"}}
+    (tmp_path / "config_final.yaml").write_text(yaml.safe_dump(cfg))
+
+    structs = synthetic.fcc64_structures(3)
+    bad = {"lattice": 50.0 * np.eye(3), "cart_coords": np.zeros((1, 3)), "atomic_numbers": np.array([29])}
+    with pytest.warns(UserWarning):
+        out = P.predict([structs[0], bad, structs[1], structs[2]], model_identifier=str(tmp_path), batch_size=2)
+    assert len(out) == 4 and out[1] is None
+    graphs = [rdata.crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
+    with torch.no_grad():
+        want = ToCartesian("ijkl=jikl=klij")(ref.decode(rdata.collate(graphs)))
+    got = torch.as_tensor(np.stack([np.asarray(out[i]) for i in (0, 2, 3)]))
+    assert got.shape == (3, 3, 3, 3, 3)
+    close(got, want, RTOL, "predict() Cartesian tensors")
+    one = P.predict(structs[0], model_identifier=str(tmp_path))
+    close(torch.as_tensor(np.asarray(one)), want[0], RTOL, "single structure")
+    with pytest.raises(RuntimeError, match="not supported by the model"):
+        P.predict({"lattice": 3.0 * np.eye(3), "cart_coords": np.zeros((1, 3)), "atomic_numbers": [8]},
+                  model_identifier=str(tmp_path))

@@ -1,0 +1,237 @@
+"""
+CPU tests of the host side: irreps algebra and planners, the C-ABI library (loads and exports every
+symbol the header declares -- no kernel is launched), graph construction, batch sharding over a
+2-rank gloo group, and API/state_dict compatibility with the reference's names.
+"""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from common import EQUIV_TEST, LMAX2, PAPER
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from matten_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "matten_hip.h")).read()
+    declared = set(re.findall(r"\b(matten_[a-z0-9_]+)\s*\(", header)) - {"matten_stream_t"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.matten_abi_version() == _lib.ABI_VERSION
+    from matten_amd.plan import TP_TILE_NODES
+
+    assert lib.matten_tp_tile_nodes() == TP_TILE_NODES
+    # host-detectable argument errors are reported without touching a GPU
+    assert lib.matten_radial_mlp(None, -1, 8, 0.0, 5.0, None, 8, None, None, 32, 848, 1.0, None, None) == -1
+    assert lib.matten_species_linear(None, 0, None, None, 0, None, 0, None, 1, None, None) == -1
+
+
+def test_generated_cg_header_is_current():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "matten_amd", "csrc", "gen_cg.py")],
+                         capture_output=True, text=True, check=True).stdout
+    assert out == open(os.path.join(ROOT, "matten_amd", "csrc", "cg_gen.h")).read()
+
+
+def test_product_o3_matches_oracle_tables():
+    from matten_amd import o3 as p
+    from oracle.e3nn_lite import io, o3 as r
+
+    for l1 in range(5):
+        for l2 in range(5):
+            for l3 in range(abs(l1 - l2), l1 + l2 + 1):
+                assert np.allclose(p.wigner_3j(l1, l2, l3), r.wigner_3j(l1, l2, l3, dtype=torch.float64).numpy(),
+                                   atol=1e-13)
+    for f in ("ijkl=jikl=klij", "ij=ji"):
+        irreps, Q = p.cartesian_tensor_basis(f)
+        ct = io.CartesianTensor(f)
+        assert str(irreps) == str(ct)
+        assert np.allclose(Q, ct.change_of_basis(torch.float64).numpy(), atol=1e-13)
+    a = p.Irreps("2x1o+3x0e+1x0o+4x0e")
+    b = r.Irreps("2x1o+3x0e+1x0o+4x0e")
+    assert str(a.sort()[0]) == str(b.sort()[0]) and a.sort()[1] == b.sort()[1]
+    assert str(a.sort()[0].simplify()) == str(b.sort()[0].simplify())
+
+
+@pytest.mark.parametrize("hp,S", [(PAPER, 86), (EQUIV_TEST, 2), (LMAX2, 10)])
+def test_plans_mirror_the_oracle_instruction_lists(hp, S):
+    """Same paths, slots, weight layout and irreps as the oracle's e3nn-style modules, layer by layer."""
+    from matten_amd.model_factory.tfn_scalar_tensor import create_model as create_product
+    from oracle.matten_ref.model import create_model as create_oracle
+
+    ds = {"allowed_species": list(range(1, S + 1)), "average_num_neighbors": 18.0}
+    ref, prod = create_oracle(dict(hp), ds), create_product(dict(hp), ds)
+    names = [n for n, _ in ref.named_children()]
+    assert names == [n for n, _ in prod.named_children()]
+    for name in names:
+        r, p = ref.get_submodule(name), prod.get_submodule(name)
+        for key in r.irreps_out:
+            assert str(r.irreps_out[key]) == str(p.irreps_out[key]), (name, key)
+        conv_r = getattr(r, "conv", r if name == "conv_layer_last" else None)
+        if conv_r is None:
+            continue
+        conv_p = getattr(p, "conv", p)
+        tp_r, plan = conv_r.tp.tp, conv_p.tp.plan
+        assert len(tp_r.instructions) == len(plan.paths) and tp_r.weight_numel == plan.weight_numel
+        assert str(tp_r.irreps_out) == str(plan.irreps_mid)
+        out_offs = [s.start for s in tp_r.irreps_out.slices()]
+        in_offs = [s.start for s in tp_r.irreps_in1.slices()]
+        w = 0
+        for ins, path in zip(tp_r.instructions, plan.paths):
+            assert (ins.i_in1, ins.i_in2) == (path.i_in1, path.i_sh)
+            assert out_offs[ins.i_out] == path.out_off and in_offs[ins.i_in1] == path.x_off and path.w_off == w
+            assert abs(ins.path_weight - (2 * path.l3 + 1) ** 0.5) < 1e-12
+            w += path.mul
+        for lin in ("sc", "lin1", "lin2"):
+            assert getattr(conv_r, lin).weight.numel() == getattr(conv_p, lin).plan.weight_numel
+            assert str(getattr(conv_r, lin).irreps_out) == str(getattr(conv_p, lin).plan.irreps_out)
+        if hasattr(r, "act"):
+            assert str(r.act.irreps_in) == str(p.act.irreps_in) and str(r.act.irreps_out) == str(p.act.irreps_out)
+
+
+def test_state_dict_names_match_reference_contract():
+    """SURVEY.md Appendix C parameter names; oracle <-> product state_dicts interchange."""
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+    from oracle.matten_ref.model import ScalarTensorOracle
+
+    ds = {"allowed_species": [13, 29, 79], "average_num_neighbors": 18.0}
+    ref = ScalarTensorOracle(dict(PAPER), ds)
+    model = ScalarTensorModel(backbone_hparams=dict(PAPER), dataset_hparams=ds)
+    sd = model.state_dict()
+    for k in ("backbone.one_hot.linear.weight", "backbone.one_hot.atomic_number_to_index._Z_to_index",
+              "backbone.layer0_convnet.conv.sc.weight", "backbone.layer1_convnet.conv.lin1.weight",
+              "backbone.layer2_convnet.conv.lin2.weight", "backbone.layer0_convnet.conv.tp.weight_nn.layer2.weight",
+              "backbone.layer2_convnet.norm.n.running_var", "backbone.conv_layer_last.tp.weight_nn.layer0.weight",
+              "backbone.conv_to_output_hidden.linear.weight", "extra_layers_dict.out_layer.weight"):
+        assert k in sd, k
+    assert sd["backbone.conv_to_output_hidden.linear.weight"].numel() == 522
+    assert sd["extra_layers_dict.out_layer.weight"].numel() == 37
+    missing, unexpected = model.load_state_dict(ref.state_dict(), strict=False)
+    assert not missing and all(k.endswith(("output_mask", "tp.tp.weight")) for k in unexpected)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items() if k in sd}
+    assert model.hparams["dataset_hparams"]["allowed_species"] == [13, 29, 79]  # reference predict.py:100
+    assert model.to_cartesian is None and hasattr(model, "backbone") and "out_layer" in model.extra_layers_dict
+
+
+def test_no_cpu_fallback_and_loud_errors():
+    from matten_amd import _lib
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import collate
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    model = ScalarTensorModel(backbone_hparams=dict(PAPER), dataset_hparams=ds).eval()
+    with pytest.raises(_lib.MattenHipError, match="no CPU fallback"):
+        model(collate(synthetic.fcc64_graphs(1)))
+    import glob
+
+    for path in glob.glob(os.path.join(ROOT, "matten_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert "import oracle" not in src and "from oracle" not in src, path
+    with pytest.raises(RuntimeError, match="EdgeLengthEmbedding") as ei:
+        ScalarTensorModel(backbone_hparams=dict(PAPER, radial_basis_type="gaussian"), dataset_hparams=ds)
+    assert isinstance(ei.value.__cause__, NotImplementedError)
+    with pytest.raises(RuntimeError, match="Failed instantiate module"):
+        ScalarTensorModel(backbone_hparams=dict(PAPER, conv_layer_irreps="4x5e"), dataset_hparams=ds)
+
+
+def test_graph_builder_matches_oracle_bit_exact(golden_dir):
+    from matten_amd.data import graph, synthetic
+    from oracle.matten_ref import data as rdata
+
+    structs = rdata.structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))
+    structs += synthetic.fcc64_structures(3)
+    for s in structs:
+        a, b = graph.neighbor_list(s["cart_coords"], s["lattice"], 5.0)
+        c, d = rdata.neighbor_list(s["cart_coords"], s["lattice"], 5.0)
+        assert np.array_equal(a, c) and np.array_equal(b, d)
+    gs = synthetic.fcc64_graphs(4)
+    assert all(g["edge_index"].shape == (2, 1152) and torch.all(g["num_neigh"] == 18) for g in gs)
+    b = graph.collate(gs)
+    want = rdata.collate([rdata.crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0)
+                          for s in synthetic.fcc64_structures(4)])
+    assert set(b) == set(want)
+    for k in want:
+        assert torch.equal(b[k], want[k]) and b[k].dtype == want[k].dtype, k
+    assert b["cell"].shape == (12, 3) and b["ptr"].tolist() == [0, 64, 128, 192, 256]
+    with pytest.raises(ValueError, match="no edges remain"):
+        graph.neighbor_list(np.zeros((1, 3)), 50.0 * np.eye(3), 5.0)
+
+
+def test_shard_bounds_cover_and_balance():
+    from matten_amd.parallel import shard_bounds
+
+    for n in (0, 1, 7, 8, 1000, 8001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _gloo_worker(rank, world, port, n_items, tmp):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from matten_amd.parallel import shard_bounds, sharded_apply
+
+    items = list(range(n_items))
+    calls = []
+
+    def fn(shard):  # stand-in for the per-rank forward: a deterministic function of the crystal index
+        calls.append(list(shard))
+        idx = torch.tensor(shard, dtype=torch.float32)
+        return torch.stack([idx * (k + 1) for k in range(21)], dim=1)
+
+    out = sharded_apply(fn, items, (21,), "cpu")
+    lo, hi = shard_bounds(n_items, rank, world)
+    assert calls == ([items[lo:hi]] if hi > lo else [])
+    torch.save(out, os.path.join(tmp, f"out{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [7, 8, 1])
+def test_two_rank_sharding_gathers_in_batch_order(tmp_path, n_items):
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() + n_items) % 2000
+    mp.spawn(_gloo_worker, args=(2, port, n_items, str(tmp_path)), nprocs=2, join=True)
+    want = torch.stack([torch.arange(n_items, dtype=torch.float32) * (k + 1) for k in range(21)], dim=1)
+    for r in range(2):
+        assert torch.equal(torch.load(os.path.join(tmp_path, f"out{r}.pt")), want)
+
+
+def test_predict_api_surface():
+    import inspect
+
+    from matten_amd import predict as P
+
+    sig = inspect.signature(P.predict)
+    ref_params = ["structure", "model_identifier", "checkpoint", "batch_size", "logger_level", "is_elasticity_tensor",
+                  "is_atomic_tensor"]  # reference predict.py:151-159
+    assert list(sig.parameters)[: len(ref_params)] == ref_params
+    assert sig.parameters["model_identifier"].default == "20230627" and sig.parameters["batch_size"].default == 200
+    with pytest.raises(FileNotFoundError, match="model_final.ckpt"):
+        P.get_pretrained_model("20230627")
+
+    class M:
+        hparams = {"dataset_hparams": {"allowed_species": [14]}}
+
+    with pytest.raises(RuntimeError, match="not supported by the model"):
+        P.check_species(M(), [{"lattice": np.eye(3), "cart_coords": np.zeros((1, 3)), "atomic_numbers": [8]}])
+    graphs, failed = P.build_graphs(
+        [{"lattice": 3.0 * np.eye(3), "cart_coords": np.zeros((1, 3)), "atomic_numbers": [14]},
+         {"lattice": 50.0 * np.eye(3), "cart_coords": np.zeros((1, 3)), "atomic_numbers": [14]}], 5.0)
+    assert len(graphs) == 1 and failed == [1]
