@@ -71,7 +71,8 @@ int matten_species_embed(const int64_t* atomic_numbers, int64_t n_nodes, const i
  *   vec = pos[dst] - pos[src] + shift . cell[batch[src]]
  * Sorted-order outputs (consumed by the kernels below; e = sorted position, o = perm[e]):
  *   geom_sorted[E,4] = (vx, vy, vz, |v|)
- *   sh_sorted[E, (lmax+1)^2]  real SH of v/|v|, l-major, m=-l..l, 'component' normalised
+ *   sh_sorted[E, sh_stride]   real SH of v/|v| in the first (lmax+1)^2 columns, l-major, m=-l..l,
+ *                             'component' normalised; sh_stride >= (lmax+1)^2 (32 keeps rows on 128-B lines)
  * Optional original-order outputs for the backbone's data dict (NULL to skip):
  *   edge_vectors[E,3], edge_lengths[E], edge_attrs[E,(lmax+1)^2], edge_embedding[E,nb]
  * cell is [B,3,3] (rows = lattice vectors) or NULL; n_cells==1 uses cell 0 for every edge.
@@ -79,7 +80,7 @@ int matten_species_embed(const int64_t* atomic_numbers, int64_t n_nodes, const i
 int matten_edge_geom(const float* pos, const int64_t* edge_index, const float* edge_cell_shift,
                      const float* cell, int64_t n_cells, const int64_t* batch, const int32_t* perm,
                      int64_t n_edges, int lmax, int n_basis, float r_start, float r_end,
-                     float* geom_sorted, float* sh_sorted, float* edge_vectors, float* edge_lengths,
+                     float* geom_sorted, float* sh_sorted, int sh_stride, float* edge_vectors, float* edge_lengths,
                      float* edge_attrs, float* edge_embedding, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -124,6 +125,20 @@ int matten_tp_paths(const float* x, int64_t d_in, const float* w_edge, int64_t w
                     const int32_t* path_entries, const int32_t* unit_start, int64_t n_entries,
                     int64_t units_per_tile, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
                     float* agg /*[N,d_mid]*/, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Same operator again, production kernel v3: one wave per (input irrep block, l2 group, node
+ * group); every coupling (l1,l2,l3) that reads the same input block is fed from one gather.
+ *   group_entries[n_entries, 32] int32 {l1*2+g, x_off, mul(<=64), log2(lanes per node), mask, 0,0,0,
+ *                                       w_off[12], out_off[12]}   (coupling order: cg_gen.h Group<l1,g>)
+ *   unit_start[n_entries+1] int32 prefix sum of waves per node tile
+ *   sh_sorted rows must be at least 25 floats apart and readable up to column 25
+ * ------------------------------------------------------------------------------------------ */
+int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t w_pad, const float* sh_sorted,
+                     int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted, int64_t n_nodes,
+                     const int32_t* group_entries, const int32_t* unit_start, int64_t n_entries,
+                     int64_t units_per_tile, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
+                     float* agg /*[N,d_mid]*/, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * FullyConnectedTensorProduct(x, one_hot(species)) == species-indexed per-irrep linear

@@ -13,7 +13,7 @@ __global__ void edge_geom_kernel(const float* __restrict__ pos, const int64_t* _
                                  const float* __restrict__ shift, const float* __restrict__ cell, int64_t n_cells,
                                  const int64_t* __restrict__ batch, const int32_t* __restrict__ perm, int64_t E,
                                  int n_basis, float r_start, float r_end, float4* __restrict__ geom_sorted,
-                                 float* __restrict__ sh_sorted, float* __restrict__ edge_vectors,
+                                 float* __restrict__ sh_sorted, int sh_stride, float* __restrict__ edge_vectors,
                                  float* __restrict__ edge_lengths, float* __restrict__ edge_attrs,
                                  float* __restrict__ edge_embedding) {
     constexpr int SH = (LMAX + 1) * (LMAX + 1);
@@ -39,7 +39,7 @@ __global__ void edge_geom_kernel(const float* __restrict__ pos, const int64_t* _
     float y[SH];
     matten::real_sh<LMAX>(vx, vy, vz, len, y);
 #pragma unroll
-    for (int k = 0; k < SH; ++k) sh_sorted[e * SH + k] = y[k];
+    for (int k = 0; k < SH; ++k) sh_sorted[e * sh_stride + k] = y[k];
 
     if (edge_vectors) {
         edge_vectors[3 * o + 0] = vx;
@@ -107,10 +107,10 @@ extern "C" int matten_species_embed(const int64_t* atomic_numbers, int64_t n_nod
 extern "C" int matten_edge_geom(const float* pos, const int64_t* edge_index, const float* edge_cell_shift,
                                 const float* cell, int64_t n_cells, const int64_t* batch, const int32_t* perm,
                                 int64_t n_edges, int lmax, int n_basis, float r_start, float r_end,
-                                float* geom_sorted, float* sh_sorted, float* edge_vectors, float* edge_lengths,
+                                float* geom_sorted, float* sh_sorted, int sh_stride, float* edge_vectors, float* edge_lengths,
                                 float* edge_attrs, float* edge_embedding, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (n_edges < 0 || lmax < 0 || lmax > 4 || n_basis < 0) return MATTEN_EINVAL;
+    if (n_edges < 0 || lmax < 0 || lmax > 4 || n_basis < 0 || sh_stride < (lmax + 1) * (lmax + 1)) return MATTEN_EINVAL;
     if (n_edges == 0) return MATTEN_OK;
     if (!pos || !edge_index || !geom_sorted || !sh_sorted) return MATTEN_EINVAL;
     if (cell && !edge_cell_shift) return MATTEN_EINVAL;
@@ -119,7 +119,7 @@ extern "C" int matten_edge_geom(const float* pos, const int64_t* edge_index, con
 #define LAUNCH(L)                                                                                              \
     edge_geom_kernel<L><<<grid, T, 0, stream>>>(pos, edge_index, edge_cell_shift, cell, n_cells, batch, perm,  \
                                                 n_edges, n_basis, r_start, r_end, (float4*)geom_sorted,        \
-                                                sh_sorted, edge_vectors, edge_lengths, edge_attrs, edge_embedding)
+                                                sh_sorted, sh_stride, edge_vectors, edge_lengths, edge_attrs, edge_embedding)
     switch (lmax) {
         case 0: LAUNCH(0); break;
         case 1: LAUNCH(1); break;

@@ -72,6 +72,44 @@ def emit_triple(l1, l2, l3, out):
     return min(cost_pair, cost_m), len(nz)
 
 
+# l2 ranges fused into one "group" kernel per input block (registers: sum of 2 l3+1 accumulators)
+GROUPS = {0: [(0, 4)], 1: [(0, 2), (3, 4)], 2: [(0, 2), (3, 4)], 3: [(0, 2), (3, 4)], 4: [(0, 2), (3, 4)]}
+MAX_COMBOS = 12
+
+
+def group_combos(l1, lo, hi):
+    return [(l2, l3) for l2 in range(lo, hi + 1) for l3 in range(abs(l1 - l2), min(LMAX, l1 + l2) + 1)]
+
+
+def emit_group(l1, gi, lo, hi, out):
+    combos = group_combos(l1, lo, hi)
+    assert len(combos) <= MAX_COMBOS, (l1, lo, hi, len(combos))
+    d1 = 2 * l1 + 1
+    offs, o = [], 0
+    for (_, l3) in combos:
+        offs.append(o)
+        o += 2 * l3 + 1
+    y0 = lo * lo
+    ny = (hi + 1) ** 2 - y0
+    out.append(f"// in1 l={l1}, edge harmonics l2={lo}..{hi}: {len(combos)} couplings, {o} accumulators")
+    out.append(f"template <> struct Group<{l1}, {gi}> {{")
+    out.append(f"    static constexpr int NC = {len(combos)}, NACC = {o}, D1 = {d1}, Y0 = {y0}, NY = {ny};")
+    out.append("    static constexpr int L2[NC] = {" + ", ".join(str(c[0]) for c in combos) + "};")
+    out.append("    static constexpr int L3[NC] = {" + ", ".join(str(c[1]) for c in combos) + "};")
+    out.append("    static constexpr int OFF[NC] = {" + ", ".join(str(v) for v in offs) + "};")
+    out.append("    // x[D1]: features of this channel; y[NY]: harmonics l2=lo..hi; w[NC]: per-coupling edge weight")
+    out.append("    static __device__ __forceinline__ void apply(unsigned mask, const float* __restrict__ x, "
+               "const float* __restrict__ y, const float* __restrict__ w, float* __restrict__ acc) {")
+    for c, ((l2, l3), off) in enumerate(zip(combos, offs)):
+        out.append(f"        if (mask & {1 << c}u) {{")
+        out.append(f"            float xw[{d1}];")
+        out.append(f"            _Pragma(\"unroll\") for (int i = 0; i < {d1}; ++i) xw[i] = w[{c}] * x[i];")
+        out.append(f"            CG<{l1}, {l2}, {l3}>::apply(xw, y + {l2 * l2 - y0}, acc + {off});")
+        out.append("        }")
+    out.append("    }")
+    out.append("};")
+
+
 def main():
     out = [
         "// GENERATED by gen_cg.py -- do not edit.  Real Clebsch-Gordan contractions (e3nn convention,",
@@ -93,6 +131,13 @@ def main():
         out.append("")
     out.append(f"// total: {tot_nnz} non-zeros, {tot_ops} VALU ops over all triples")
     out.append("")
+    out.append(f"constexpr int GROUP_MAX_COMBOS = {MAX_COMBOS};")
+    out.append("template <int L1, int G> struct Group;")
+    out.append("")
+    for l1, ranges in GROUPS.items():
+        for gi, (lo, hi) in enumerate(ranges):
+            emit_group(l1, gi, lo, hi, out)
+            out.append("")
     out.append("}  // namespace matten")
     print("\n".join(out))
 

@@ -151,7 +151,7 @@ extern "C" int matten_tp_paths(const float* x, int64_t d_in, const float* w_edge
                                const int32_t* unit_start, int64_t n_entries, int64_t units_per_tile, int64_t d_mid,
                                float avg_num_neighbors, const float* num_neigh, float* agg, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (n_nodes < 0 || d_in <= 0 || w_pad <= 0 || sh_dim <= 0 || sh_dim > 25 || n_entries <= 0 || units_per_tile <= 0 ||
+    if (n_nodes < 0 || d_in <= 0 || w_pad <= 0 || sh_dim <= 0 || sh_dim > 32 || n_entries <= 0 || units_per_tile <= 0 ||
         d_mid <= 0)
         return MATTEN_EINVAL;
     if (n_nodes == 0) return MATTEN_OK;

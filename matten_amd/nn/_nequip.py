@@ -48,7 +48,8 @@ def ensure_edge_geometry(data: DataKey.Type, lmax: int = None, want_vectors=Fals
         return data
     ensure_graph(data)
     if lmax is None:
-        lmax = int(round(data[DataKey.AMD_SH].shape[1] ** 0.5)) - 1 if have else 0
+        lmax = int(data["_amd_lmax"]) if "_amd_lmax" in data else 0
+    data["_amd_lmax"] = lmax
     nb, r0, r1 = 0, 0.0, 1.0
     if DataKey.AMD_RBF in data:
         nb, r0, r1 = data[DataKey.AMD_RBF].tolist()

@@ -124,10 +124,12 @@ class UVUTensorProduct(torch.nn.Module):
         self._tables = DeviceTables(
             m_idx=self.plan.m_terms_idx, m_coef=self.plan.m_terms_coef, out_meta=self.plan.out_meta,
             entries=self.plan.path_entries, unit_start=self.plan.unit_start,
+            gentries=self.plan.group_entries, gstart=self.plan.group_unit_start,
         )
-        # "paths": per-path kernel with literal CG coefficients (production);
-        # "table": table-driven kernel (kept as an independent second implementation for tests)
-        self.impl = os.environ.get("MATTEN_TP_IMPL", "paths")
+        # "blocks": couplings fused per input block, literal CG coefficients (production)
+        # "paths" : one wave per path (same literals, no fusion)
+        # "table" : table-driven kernel, an independent second implementation kept for tests
+        self.impl = os.environ.get("MATTEN_TP_IMPL", "blocks")
 
     @property
     def irreps_out(self) -> Irreps:
@@ -140,6 +142,12 @@ class UVUTensorProduct(torch.nn.Module):
         dev = node_feats.device
         avg = avg_num_neighbors if avg_num_neighbors is not None else 0.0
         num_neigh = None if avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
+        if self.impl == "blocks":
+            return ops.tp_blocks(
+                node_feats, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
+                self._tables.get("gentries", dev), self._tables.get("gstart", dev), self.plan.group_units_per_tile,
+                self.plan.d_mid, avg, num_neigh,
+            )
         if self.impl == "paths":
             return ops.tp_paths(
                 node_feats, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],

@@ -48,6 +48,9 @@ class _timed:
         return False
 
 
+SH_STRIDE = 32  # floats per row of sh_sorted
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -128,7 +131,8 @@ def edge_geom(pos, edge_index, edge_cell_shift, cell, batch, perm, lmax: int, n_
             batch = _need(batch, torch.int64, "batch")
     sh_dim = (lmax + 1) ** 2
     geom = torch.empty(E, 4, dtype=torch.float32, device=dev)
-    sh = torch.empty(E, sh_dim, dtype=torch.float32, device=dev)
+    # rows padded to 32 floats: one 128-byte line per edge, and the fused TP kernel may read any l2 <= 4
+    sh = torch.zeros(E, SH_STRIDE, dtype=torch.float32, device=dev)
     out = {"geom_sorted": geom, "sh_sorted": sh}
     ev = torch.empty(E, 3, dtype=torch.float32, device=dev) if want_vectors else None
     el = torch.empty(E, dtype=torch.float32, device=dev) if want_lengths else None
@@ -136,7 +140,8 @@ def edge_geom(pos, edge_index, edge_cell_shift, cell, batch, perm, lmax: int, n_
     ee = torch.empty(E, n_basis, dtype=torch.float32, device=dev) if want_embedding else None
     _lib.check(
         lib.matten_edge_geom(_ptr(pos), _ptr(edge_index), _ptr(edge_cell_shift), _ptr(cell), n_cells, _ptr(batch),
-                             _ptr(perm), E, lmax, n_basis, r_start, r_end, _ptr(geom), _ptr(sh), _ptr(ev), _ptr(el),
+                             _ptr(perm), E, lmax, n_basis, r_start, r_end, _ptr(geom), _ptr(sh), SH_STRIDE, _ptr(ev),
+                             _ptr(el),
                              _ptr(ea), _ptr(ee), _stream()),
         "matten_edge_geom",
     )
@@ -200,6 +205,29 @@ def tp_paths(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, unit
                                  entries.shape[0], units_per_tile, d_mid, float(avg_num_neighbors or 0.0),
                                  _ptr(num_neigh), _ptr(agg), _stream())
     _lib.check(rc, "matten_tp_paths")
+    return agg
+
+
+def tp_blocks(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, units_per_tile: int, d_mid: int,
+              avg_num_neighbors: float, num_neigh=None) -> torch.Tensor:
+    lib = _lib.load()
+    from .plan import TP_TILE_NODES
+
+    if lib.matten_tp_tile_nodes() != TP_TILE_NODES:
+        raise _lib.MattenHipError("plan.TP_TILE_NODES does not match the library's node tile")
+    x = _need(x, torch.float32, "node_features")
+    w_edge = _need(w_edge, torch.float32, "w_edge")
+    sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
+    N, d_in = x.shape
+    if num_neigh is not None:
+        num_neigh = _need(num_neigh, torch.float32, "num_neigh")
+    agg = torch.empty(N, d_mid, dtype=torch.float32, device=x.device)
+    with _timed(f"tp_scatter/d_mid={d_mid}"):
+        rc = lib.matten_tp_blocks(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
+                                  _ptr(rowptr), _ptr(src_sorted), N, _ptr(entries), _ptr(unit_start),
+                                  entries.shape[0], units_per_tile, d_mid, float(avg_num_neighbors or 0.0),
+                                  _ptr(num_neigh), _ptr(agg), _stream())
+    _lib.check(rc, "matten_tp_blocks")
     return agg
 
 

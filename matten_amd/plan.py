@@ -22,6 +22,9 @@ from .o3 import Irrep, Irreps, wigner_3j
 
 TP_TILE_NODES = 32  # must equal matten_tp_tile_nodes() of the library (checked at first use)
 
+# l2 ranges fused per input-block degree l1; must match GROUPS in matten_amd/csrc/gen_cg.py
+TP_GROUPS = {0: [(0, 4)], 1: [(0, 2), (3, 4)], 2: [(0, 2), (3, 4)], 3: [(0, 2), (3, 4)], 4: [(0, 2), (3, 4)]}
+
 ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
 
 
@@ -75,6 +78,10 @@ class UVUPlan:
     path_entries: np.ndarray = None   # int32 [n_entries, 8]
     unit_start: np.ndarray = None     # int32 [n_entries + 1] waves per node tile, prefix sum
     units_per_tile: int = 0
+    # block-fused kernel (matten_tp_blocks): one entry per (input block chunk, l2 group)
+    group_entries: np.ndarray = None  # int32 [n_groups, 32]
+    group_unit_start: np.ndarray = None
+    group_units_per_tile: int = 0
 
 
 def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
@@ -164,12 +171,42 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
             entries.append((p.l1 * 25 + p.l2 * 5 + p.l3, p.x_off + u0 * d1, p.w_off + u0, p.out_off + u0 * d3, mul_c,
                             cu_log2, 0, 0))
             ustart.append(ustart[-1] + waves)
+    # ---- block-fused groups: all couplings of one input block and one l2 range (cg_gen.h Group<l1,g>) ----
+    gentries, gstart = [], [0]
+    by_block: Dict[int, List[UVUPath]] = {}
+    for p in paths:
+        by_block.setdefault(p.i_in1, []).append(p)
+    for i_in1, plist in by_block.items():
+        l1, mul = plist[0].l1, plist[0].mul
+        d1 = 2 * l1 + 1
+        for gi, (lo, hi) in enumerate(TP_GROUPS[l1]):
+            combos = [(l2, l3) for l2 in range(lo, hi + 1) for l3 in range(abs(l1 - l2), min(4, l1 + l2) + 1)]
+            present = {(p.l2, p.l3): p for p in plist if lo <= p.l2 <= hi}
+            if not present:
+                continue
+            for u0 in range(0, mul, 64):
+                mul_c = min(64, mul - u0)
+                cu_log2 = max(0, (mul_c - 1).bit_length())
+                nodes_per_wave = max(1, 64 // (1 << cu_log2))
+                row = [l1 * 2 + gi, plist[0].x_off + u0 * d1, mul_c, cu_log2, 0, 0, 0, 0] + [0] * 24
+                mask = 0
+                for c, key in enumerate(combos):
+                    if key in present:
+                        pth = present[key]
+                        mask |= 1 << c
+                        row[8 + c] = pth.w_off + u0
+                        row[8 + 12 + c] = pth.out_off + u0 * (2 * pth.l3 + 1)
+                row[4] = mask
+                gentries.append(row)
+                gstart.append(gstart[-1] + -(-TP_TILE_NODES // nodes_per_wave))
     return UVUPlan(
         irreps_in1=irreps_in1, irreps_sh=irreps_sh, irreps_mid=irreps_mid, irreps_out=irreps_mid.simplify(),
         paths=paths, weight_numel=w_off, d_in=irreps_in1.dim, d_mid=d_mid, sh_dim=irreps_sh.dim,
         m_total=m_total, m_nterms=m_nterms, m_terms_idx=idx, m_terms_coef=coef, out_meta=meta, cg_nnz=cg_nnz,
         path_entries=np.array(entries, dtype=np.int32), unit_start=np.array(ustart, dtype=np.int32),
         units_per_tile=ustart[-1],
+        group_entries=np.array(gentries, dtype=np.int64).astype(np.int32), group_unit_start=np.array(gstart, dtype=np.int32),
+        group_units_per_tile=gstart[-1],
     )
 
 
