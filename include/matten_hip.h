@@ -129,8 +129,10 @@ int matten_tp_paths(const float* x, int64_t d_in, const float* w_edge, int64_t w
 /* ------------------------------------------------------------------------------------------
  * Same operator again, production kernel v3: one wave per (input irrep block, l2 group, node
  * group); every coupling (l1,l2,l3) that reads the same input block is fed from one gather.
- *   group_entries[n_entries, 32] int32 {l1*2+g, x_off, mul(<=64), log2(lanes per node), mask, 0,0,0,
- *                                       w_off[12], out_off[12]}   (coupling order: cg_gen.h Group<l1,g>)
+ *   group_entries[n_entries, 32] int32 {l1*2+g, x_off, mul(<=64), log2(lanes per node), mask, w_base, 0,0,
+ *                                       reserved[12], out_off[12]}  (coupling order: cg_gen.h Group<l1,g>)
+ *   w_edge columns are in the FUSED order: entry by entry, [u][c] with c over all couplings of the
+ *   group (absent couplings are zero columns): lane (u) reads w_edge[e, w_base + u*NC .. +NC)
  *   unit_start[n_entries+1] int32 prefix sum of waves per node tile
  *   sh_sorted rows must be at least 25 floats apart and readable up to column 25
  * ------------------------------------------------------------------------------------------ */

@@ -72,9 +72,8 @@ def emit_triple(l1, l2, l3, out):
     return min(cost_pair, cost_m), len(nz)
 
 
-# l2 ranges fused into one "group" kernel per input block (registers: sum of 2 l3+1 accumulators)
-GROUPS = {0: [(0, 4)], 1: [(0, 2), (3, 4)], 2: [(0, 2), (3, 4)], 3: [(0, 2), (3, 4)], 4: [(0, 2), (3, 4)]}
-MAX_COMBOS = 12
+# l2 ranges fused into one "group" per input block: single source of truth is matten_amd/plan.py
+from matten_amd.plan import TP_GROUPS as GROUPS, TP_MAX_COMBOS as MAX_COMBOS  # noqa: E402
 
 
 def group_combos(l1, lo, hi):
@@ -132,7 +131,10 @@ def main():
     out.append(f"// total: {tot_nnz} non-zeros, {tot_ops} VALU ops over all triples")
     out.append("")
     out.append(f"constexpr int GROUP_MAX_COMBOS = {MAX_COMBOS};")
+    out.append("constexpr int GROUP_KIND_STRIDE = 8;  // kind = l1 * GROUP_KIND_STRIDE + group index")
     out.append("template <int L1, int G> struct Group;")
+    out.append("#define MATTEN_FOR_EACH_GROUP(X) " + " ".join(
+        f"X({l1}, {gi})" for l1, ranges in GROUPS.items() for gi in range(len(ranges))))
     out.append("")
     for l1, ranges in GROUPS.items():
         for gi, (lo, hi) in enumerate(ranges):

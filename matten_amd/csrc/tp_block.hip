@@ -7,7 +7,10 @@
 // Per edge it loads, once,
 //      x[src, x_off + u*d1 .. +d1)       its channel of the source node's features
 //      Y_l2(e), l2 = lo..hi              the edge harmonics of its l2 group
-//      w[e, w_off_c + u]                 one radial weight per coupling c of the group
+//      w[e, w_base + u*NC .. +NC)        the radial weights of all NC couplings of the group: the MLP
+//                                        writes its output columns in this [entry][u][c] order, so a
+//                                        lane's weights are contiguous (vector loads) and the lanes of
+//                                        a node read one contiguous mul*NC run
 // and feeds every coupling (l1,l2,l3) of the group from those registers, so the gathers are
 // amortised over up to 12 couplings instead of being repeated per path: ~60 cache-line touches per
 // edge and layer instead of ~400, which is what bounded the per-path kernel (texture-address path,
@@ -26,13 +29,14 @@ constexpr int N_XCD = 8;
 constexpr int MAXC = matten::GROUP_MAX_COMBOS;
 
 struct GroupEntry {  // 32 x int32, built by matten_amd/plan.py
-    int kind;        // l1*2 + group index
+    int kind;        // l1*GROUP_KIND_STRIDE + group index
     int x_off;       // offset of channel 0 of this entry in the node feature row
     int mul;         // channels in this entry (<= 64)
     int cu_log2;     // lanes per node = 1 << cu_log2 >= mul
     unsigned mask;   // bit c set <=> coupling c of the group exists in this layer
-    int pad[3];
-    int w_off[MAXC];    // offset of channel 0's weight of coupling c in the per-edge weight row
+    int w_base;      // offset of this entry's [u][c] weight block in the per-edge weight row
+    int pad[2];
+    int reserved[MAXC];
     int out_off[MAXC];  // offset of channel 0's output of coupling c in the message row
 };
 static_assert(sizeof(GroupEntry) == 32 * 4, "GroupEntry layout");
@@ -65,14 +69,14 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, i
             const int src = a.src_sorted[e];
             const float* xp = a.x + (int64_t)src * a.d_in + xcol;
             const float* yp = a.sh + (int64_t)e * a.sh_stride + G::Y0;
-            const float* wp = a.w_edge + (int64_t)e * a.w_pad + u;
+            const float* wp = a.w_edge + (int64_t)e * a.w_pad + ge.w_base + u * G::NC;
             float x[G::D1], y[G::NY], w[G::NC];
 #pragma unroll
             for (int i = 0; i < G::D1; ++i) x[i] = xp[i];
 #pragma unroll
             for (int j = 0; j < G::NY; ++j) y[j] = yp[j];
 #pragma unroll
-            for (int c = 0; c < G::NC; ++c) w[c] = (mask >> c) & 1u ? wp[ge.w_off[c]] : 0.0f;
+            for (int c = 0; c < G::NC; ++c) w[c] = wp[c];
             G::apply(mask, x, y, w, acc);
         }
     }
@@ -94,7 +98,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, i
 }
 
 #define MATTEN_GROUP_CASE(L1, GI) \
-    case (L1 * 2 + GI): run_group<L1, GI>(a, ge, node, u, valid, beg, deg, maxdeg); break;
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, node, u, valid, beg, deg, maxdeg); break;
 
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void tp_block_kernel(Args a, const GroupEntry* __restrict__ entries,
                                                                         const int* __restrict__ ustart,
@@ -135,11 +139,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void tp_block_kernel(Args a, 
     for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
 
     switch (ge.kind) {
-        MATTEN_GROUP_CASE(0, 0)
-        MATTEN_GROUP_CASE(1, 0) MATTEN_GROUP_CASE(1, 1)
-        MATTEN_GROUP_CASE(2, 0) MATTEN_GROUP_CASE(2, 1)
-        MATTEN_GROUP_CASE(3, 0) MATTEN_GROUP_CASE(3, 1)
-        MATTEN_GROUP_CASE(4, 0) MATTEN_GROUP_CASE(4, 1)
+        MATTEN_FOR_EACH_GROUP(MATTEN_GROUP_CASE)
         default: break;
     }
 }

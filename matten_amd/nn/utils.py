@@ -68,8 +68,11 @@ class _RadialLayer(torch.nn.Module):
 class RadialMLP(torch.nn.Module):
     """Bias-free MLP [n_basis, h, h, W]: x <- c*silu(x @ W/sqrt(h_in)) on hidden layers."""
 
-    def __init__(self, hs: List[int], act: str = "silu"):
+    def __init__(self, hs: List[int], act: str = "silu", out_cols=None):
+        """out_cols (int64 array, optional): emit output column j = reference column out_cols[j] (-1: zeros).
+        The state_dict keeps the reference layout; only the packed copy the kernel reads is permuted."""
         super().__init__()
+        self.out_cols = None if out_cols is None else torch.as_tensor(out_cols, dtype=torch.int64)
         if len(hs) != 4 or hs[1] != 32 or hs[2] != 32:
             raise NotImplementedError(f"radial MLP must be [nb, 32, 32, W] (invariant_layers=2, neurons=32); got {hs}")
         if act != "silu":
@@ -82,12 +85,17 @@ class RadialMLP(torch.nn.Module):
 
     def _pack(self, w0: Tensor, w1: Tensor, w2: Tensor):
         nb, h, W = self.hs[0], self.hs[1], self.hs[3]
+        w2s = w2 * (self.act_cst / h**0.5)
+        if self.out_cols is not None:
+            cols = self.out_cols.to(w2.device)
+            w2s = torch.where(cols[None, :] >= 0, w2s[:, cols.clamp(min=0)], w2s.new_zeros(()))
+            W = cols.numel()
         nb_pad, w_pad = (nb + 3) // 4 * 4, (W + 15) // 16 * 16
         w0p = w0.new_zeros(nb_pad, h)
         w0p[:nb] = w0 / nb**0.5
         w1p = (w1 * (self.act_cst / h**0.5)).contiguous()
         w2p = w2.new_zeros(h, w_pad)
-        w2p[:, :W] = w2 * (self.act_cst / h**0.5)
+        w2p[:, :W] = w2s
         return w0p, w1p, w2p
 
     def forward(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float) -> Tensor:
@@ -120,16 +128,18 @@ class UVUTensorProduct(torch.nn.Module):
         self.irreps_mid = self.plan.irreps_mid
         self.weight_numel = self.plan.weight_numel
         layer_sizes = [mlp_input_size] + mlp_num_hidden_layers * [mlp_hidden_size] + [self.weight_numel]
-        self.weight_nn = RadialMLP(layer_sizes, act=mlp_activation)
+        # "blocks": couplings fused per input block, literal CG coefficients (production); its radial
+        #           weights are laid out [entry][u][coupling] (plan.fused_cols)
+        # "paths" : one wave per path (same literals, no fusion); "table": table-driven kernel; both read
+        #           the reference's weight layout and are kept as independent implementations for tests
+        self.impl = os.environ.get("MATTEN_TP_IMPL", "blocks")
+        self.weight_nn = RadialMLP(layer_sizes, act=mlp_activation,
+                                   out_cols=self.plan.fused_cols if self.impl == "blocks" else None)
         self._tables = DeviceTables(
             m_idx=self.plan.m_terms_idx, m_coef=self.plan.m_terms_coef, out_meta=self.plan.out_meta,
             entries=self.plan.path_entries, unit_start=self.plan.unit_start,
             gentries=self.plan.group_entries, gstart=self.plan.group_unit_start,
         )
-        # "blocks": couplings fused per input block, literal CG coefficients (production)
-        # "paths" : one wave per path (same literals, no fusion)
-        # "table" : table-driven kernel, an independent second implementation kept for tests
-        self.impl = os.environ.get("MATTEN_TP_IMPL", "blocks")
 
     @property
     def irreps_out(self) -> Irreps:

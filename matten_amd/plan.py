@@ -13,6 +13,7 @@ so parameters keep the reference's flat layout (SURVEY.md App. A.3/A.4/A.8, App.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -23,7 +24,15 @@ from .o3 import Irrep, Irreps, wigner_3j
 TP_TILE_NODES = 32  # must equal matten_tp_tile_nodes() of the library (checked at first use)
 
 # l2 ranges fused per input-block degree l1; must match GROUPS in matten_amd/csrc/gen_cg.py
-TP_GROUPS = {0: [(0, 4)], 1: [(0, 2), (3, 4)], 2: [(0, 2), (3, 4)], 3: [(0, 2), (3, 4)], 4: [(0, 2), (3, 4)]}
+_GROUP_SCHEMES = {
+    "A": {0: [(0, 4)], 1: [(0, 2), (3, 4)], 2: [(0, 2), (3, 4)], 3: [(0, 2), (3, 4)], 4: [(0, 2), (3, 4)]},
+    "B": {0: [(0, 4)], 1: [(0, 2), (3, 4)], 2: [(0, 1), (2, 2), (3, 3), (4, 4)], 3: [(0, 1), (2, 2), (3, 3), (4, 4)],
+          4: [(0, 1), (2, 2), (3, 3), (4, 4)]},
+    "C": {l1: [(l2, l2) for l2 in range(5)] for l1 in range(5)},
+}
+TP_GROUPS = _GROUP_SCHEMES[os.environ.get("MATTEN_TP_GROUPS", "A")]
+TP_MAX_COMBOS = 12
+TP_KIND_STRIDE = 8
 
 ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
 
@@ -82,6 +91,7 @@ class UVUPlan:
     group_entries: np.ndarray = None  # int32 [n_groups, 32]
     group_unit_start: np.ndarray = None
     group_units_per_tile: int = 0
+    fused_cols: np.ndarray = None     # int64 [W_fused]: fused weight column -> reference weight column, -1 = zero
 
 
 def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
@@ -173,6 +183,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
             ustart.append(ustart[-1] + waves)
     # ---- block-fused groups: all couplings of one input block and one l2 range (cg_gen.h Group<l1,g>) ----
     gentries, gstart = [], [0]
+    fused_cols: List[int] = []
     by_block: Dict[int, List[UVUPath]] = {}
     for p in paths:
         by_block.setdefault(p.i_in1, []).append(p)
@@ -188,15 +199,18 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                 mul_c = min(64, mul - u0)
                 cu_log2 = max(0, (mul_c - 1).bit_length())
                 nodes_per_wave = max(1, 64 // (1 << cu_log2))
-                row = [l1 * 2 + gi, plist[0].x_off + u0 * d1, mul_c, cu_log2, 0, 0, 0, 0] + [0] * 24
+                row = [l1 * TP_KIND_STRIDE + gi, plist[0].x_off + u0 * d1, mul_c, cu_log2, 0, len(fused_cols), 0, 0] + [0] * 24
                 mask = 0
                 for c, key in enumerate(combos):
                     if key in present:
                         pth = present[key]
                         mask |= 1 << c
-                        row[8 + c] = pth.w_off + u0
                         row[8 + 12 + c] = pth.out_off + u0 * (2 * pth.l3 + 1)
                 row[4] = mask
+                # fused weight layout of this entry: [u][c] -> column of the reference's weight row (-1: absent)
+                for uu in range(mul_c):
+                    for key in combos:
+                        fused_cols.append(present[key].w_off + u0 + uu if key in present else -1)
                 gentries.append(row)
                 gstart.append(gstart[-1] + -(-TP_TILE_NODES // nodes_per_wave))
     return UVUPlan(
@@ -206,7 +220,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         path_entries=np.array(entries, dtype=np.int32), unit_start=np.array(ustart, dtype=np.int32),
         units_per_tile=ustart[-1],
         group_entries=np.array(gentries, dtype=np.int64).astype(np.int32), group_unit_start=np.array(gstart, dtype=np.int32),
-        group_units_per_tile=gstart[-1],
+        group_units_per_tile=gstart[-1], fused_cols=np.array(fused_cols, dtype=np.int64),
     )
 
 

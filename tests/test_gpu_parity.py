@@ -307,7 +307,10 @@ def test_tp_kernels_agree_and_match_oracle(per_node_norm):
                      t.get("unit_start", DEV), p.units_per_tile, p.d_mid, avg, nn_)
     b = ops.tp_scatter(x.to(DEV), w_sorted, geo["sh_sorted"], rowptr, src, t.get("m_idx", DEV), t.get("m_coef", DEV),
                        t.get("out_meta", DEV), avg, nn_)
-    c = ops.tp_blocks(x.to(DEV), w_sorted, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV),
+    cols = torch.as_tensor(p.fused_cols, device=DEV)
+    w_fused = torch.where(cols[None, :] >= 0, w_sorted[:, cols.clamp(min=0)], w_sorted.new_zeros(()))
+    w_fused = torch.nn.functional.pad(w_fused, (0, (-w_fused.shape[1]) % 16)).contiguous()
+    c = ops.tp_blocks(x.to(DEV), w_fused, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV),
                       t.get("gstart", DEV), p.group_units_per_tile, p.d_mid, avg, nn_)
     close(c, want, 2e-5, "tp_blocks vs oracle")
     close(c, a, 2e-5, "tp_blocks vs tp_paths")
