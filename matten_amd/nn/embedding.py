@@ -119,7 +119,10 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
                 a2i.raise_for_flags(flags, Z)
         if not provided:
             data[DataKey.SPECIES_INDEX] = sidx
-        data[DataKey.AMD_SPECIES] = s32
+        # nodes grouped by species (stable): the species-indexed linears walk this order
+        ids = torch.stack([torch.arange(sidx.shape[0], dtype=torch.int64, device=sidx.device), sidx.clamp(min=0)])
+        order, seg, _, _ = ops.csr_build(ids, S)
+        data[DataKey.AMD_SPECIES] = (order, seg)
         if attrs is not None:
             data[DataKey.NODE_ATTRS] = attrs
         data[DataKey.NODE_FEATURES] = feats

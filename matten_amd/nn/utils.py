@@ -50,12 +50,13 @@ class SpeciesLinear(torch.nn.Module):
         dev = weight.device
         return (weight[self._tables.get("gather", dev)] * self._tables.get("scale", dev)).contiguous()
 
-    def forward(self, x: Tensor, species_i32: Optional[Tensor] = None, add: Optional[Tensor] = None) -> Tensor:
-        if self.n_species is not None and species_i32 is None:
-            raise ValueError("species index required")
+    def forward(self, x: Tensor, species_order=None, add: Optional[Tensor] = None) -> Tensor:
+        """species_order = (order, seg): node ids sorted by species + per-species offsets (DataKey.AMD_SPECIES)."""
+        if self.n_species is not None and species_order is None:
+            raise ValueError("species order required")
         wp = self._packed.get(self.weight)
         metas = [self._tables.get(f"meta{i}", x.device) for i in range(len(self.plan.passes))]
-        return ops.species_linear(x, species_i32 if self.n_species is not None else None, wp, self.plan.w_stride,
+        return ops.species_linear(x, species_order if self.n_species is not None else None, wp, self.plan.w_stride,
                                   metas, add)
 
 

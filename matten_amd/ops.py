@@ -231,21 +231,24 @@ def tp_blocks(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, uni
     return agg
 
 
-def species_linear(x, species_i32, wp, w_stride: int, metas, add=None) -> torch.Tensor:
-    """metas: list of int32 [d_out,4] tensors (passes).  out = add + sum_passes."""
+def species_linear(x, species_order, wp, w_stride: int, metas, add=None) -> torch.Tensor:
+    """species_order: None (plain linear) or (order[N] i32, seg[S+1] i32) = nodes sorted by species.
+    metas: list of int32 [d_out,4] tensors (passes).  out = add + sum_passes."""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
     wp = _need(wp, torch.float32, "packed weights")
     n_rows, d_in = x.shape
     d_out = metas[0].shape[0]
     out = torch.empty(n_rows, d_out, dtype=torch.float32, device=x.device)
+    order, seg = species_order if species_order is not None else (None, None)
+    n_species = wp.shape[0] if wp.dim() == 2 else 1
     cur_add = add
     if cur_add is not None:
         cur_add = _need(cur_add, torch.float32, "add")
     for meta in metas:
         _lib.check(
-            lib.matten_species_linear(_ptr(x), d_in, _ptr(species_i32), _ptr(wp), w_stride, _ptr(meta), d_out,
-                                      _ptr(cur_add), n_rows, _ptr(out), _stream()),
+            lib.matten_species_linear(_ptr(x), d_in, _ptr(order), _ptr(seg), n_species, _ptr(wp), w_stride,
+                                      _ptr(meta), d_out, _ptr(cur_add), n_rows, _ptr(out), _stream()),
             "matten_species_linear",
         )
         cur_add = out
