@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the TP+scatter kernel on the last conv layer (fcc-64 x B crystals), per input-block degree l1."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from matten_amd import ops, plan as mplan
+from matten_amd.data import synthetic
+from matten_amd.data.graph import collate
+from matten_amd.o3 import Irreps
+
+B = int(os.environ.get("B", 1000))
+dev = "cuda:0"
+graphs = synthetic.fcc64_graphs(min(B, 64))
+graphs = [graphs[i % len(graphs)] for i in range(B)]
+b = collate(graphs, device=dev)
+N, E = b["pos"].shape[0], b["edge_index"].shape[1]
+irr = "32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e"
+p = mplan.plan_uvu(irr, Irreps.spherical_harmonics(4), irr)
+perm, rowptr, src, _ = ops.csr_build(b["edge_index"], N)
+geo = ops.edge_geom(b["pos"], b["edge_index"], b["edge_cell_shift"], b["cell"], b["batch"], perm, 4)
+x = torch.randn(N, p.d_in, device=dev)
+wpad = (len(p.fused_cols) + 15) // 16 * 16
+w = torch.randn(E, wpad, device=dev)
+ustart_all = torch.from_numpy(p.group_unit_start).to(dev)
+
+def run(entries_np, label):
+    ent = torch.from_numpy(np.ascontiguousarray(entries_np)).to(dev)
+    waves = []
+    for row in entries_np:
+        cu = 1 << int(row[3]); npw = max(1, 64 // cu); waves.append(-(-mplan.TP_TILE_NODES // npw))
+    ust = torch.tensor(np.concatenate([[0], np.cumsum(waves)]), dtype=torch.int32, device=dev)
+    upt = int(ust[-1])
+    for _ in range(2):
+        ops.tp_blocks(x, w, geo["sh_sorted"], rowptr, src, ent, ust, upt, p.d_mid, 18.0)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5):
+        ops.tp_blocks(x, w, geo["sh_sorted"], rowptr, src, ent, ust, upt, p.d_mid, 18.0)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
+    print(f"{label:28s} entries {len(entries_np):2d} waves/tile {upt:3d}  {dt*1e3:7.3f} ms")
+
+run(p.group_entries, "all")
+for l1 in range(5):
+    sel = p.group_entries[p.group_entries[:, 0] // mplan.TP_KIND_STRIDE == l1]
+    run(sel, f"l1={l1}")
+for kind in sorted(set(p.group_entries[:, 0])):
+    run(p.group_entries[p.group_entries[:, 0] == kind], f"kind l1={kind // mplan.TP_KIND_STRIDE} g={kind % mplan.TP_KIND_STRIDE}")
