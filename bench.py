@@ -44,6 +44,16 @@ def parse():
     return ap.parse_args()
 
 
+def _pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC run (profiles/hbm_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, gfx950 x2 correction on FETCH_SIZE), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            return float(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def algorithmic_bytes_tp_kernel(plan, deg: float) -> float:
     """Per-edge algorithmic bytes of ONE TP+scatter launch (DESIGN.md 'kernels'): edge ids (8) + edge
     vector (12) + the per-edge weights read once (4 W) + node rows amortised over the degree."""
@@ -158,13 +168,13 @@ def main():
             bytes_per_launch = algorithmic_bytes_tp_kernel(last, deg) * n_edges
             achieved = bytes_per_launch / dur_s / 1e9
             result["roofline"] = {
-                "kernel": "tp_scatter_kernel (conv_layer_last: 103 paths, d_mid 4170)",
+                "kernel": "tp_block_kernel (conv_layer_last: 103 paths, d_mid 4170)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK / 1e9),
-                "traffic": None,
+                "traffic": _pmc_traffic("tp_block_kernel"),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": per_kernel[key],
             }

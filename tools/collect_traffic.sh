@@ -1,0 +1,35 @@
+#!/bin/bash
+# HBM traffic of the dominant kernel from rocprofv3 PMC counters (separate passes for FETCH_SIZE and
+# WRITE_SIZE, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  Run on the GPU box:
+#   bash tools/collect_traffic.sh <tag>     -> gpurun_out/traffic_<tag>.json
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${TAG}_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
+done
+python3 - <<PY
+import csv, json, collections, re
+R="$R"; TAG="$TAG"
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    rows = list(csv.DictReader(open(f"{R}/gpurun_out/pmc_{TAG}_{c}/p_counter_collection.csv")))
+    per = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] == c:
+            m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+            per[m.group(1) if m else r["Kernel_Name"][:40]].append(float(r["Counter_Value"]))
+    for k, v in per.items():
+        res.setdefault(k, {})[c] = {"max_kb": max(v), "mean_kb": sum(v) / len(v), "launches": len(v)}
+out = {}
+for k, d in res.items():
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2 (guide, section HBM)
+        out[k] = {"fetch_kb_raw_max": d["FETCH_SIZE"]["max_kb"], "write_kb_max": d["WRITE_SIZE"]["max_kb"],
+                  "hbm_bytes_max_launch": 2 * 1024 * d["FETCH_SIZE"]["max_kb"] + 1024 * d["WRITE_SIZE"]["max_kb"],
+                  "launches": d["FETCH_SIZE"]["launches"]}
+json.dump(out, open(f"{R}/gpurun_out/traffic_{TAG}.json", "w"), indent=1)
+for k, v in out.items():
+    if any(s in k for s in ("tp_", "radial", "species_linear")):
+        print(k, v)
+PY
