@@ -143,6 +143,29 @@ int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t 
                      float* agg /*[N,d_mid]*/, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused production path of one conv layer's edge work (reference nn/utils.py:246-251,260,263 +
+ * nn/conv.py:113-120): the per-edge radial weights are never written to memory.
+ *   matten_radial_hidden: rbf(|v|) -> 32 -> 32 (silu), fp32 MFMA; writes h2p[E,32] where column g*8+kk
+ *                         holds hidden feature 16*(kk>>2) + 4*g + (kk&3)
+ *   matten_tp_fused:      per (input block, l2 group, node group) wave: last MLP layer on the matrix
+ *                         cores (w = h2 . W2p) into a wave-private LDS tile, consumed in place by the
+ *                         literal-coefficient CG contraction + CSR neighbour sum
+ *   w2p[32, w_pad]: last layer weights pre-scaled (1/sqrt(32) * normalize2mom(silu)), columns in the
+ *                   fused [entry][u][coupling] order of group_entries, w_pad >= w_cols + 16
+ *   group_entries / unit_start: as matten_tp_blocks, with mul * couplings <= 64 weight columns per entry
+ *   lds_floats_per_wave: max over entries of 16*T*(16*ceil(mul*NC/16)+36), T = max(1, nodes_per_wave/16)
+ *                   (sh_sorted rows must be 32 floats apart: sh_stride == 32)
+ * ------------------------------------------------------------------------------------------ */
+int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
+                         const float* w0p, int nb_pad, const float* w1p, int hidden, float* h2p,
+                         matten_stream_t stream);
+int matten_tp_fused(const float* x, int64_t d_in, const float* h2p, const float* w2p, int64_t w_pad,
+                    const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
+                    int64_t n_nodes, const int32_t* group_entries, const int32_t* unit_start, int64_t n_entries,
+                    int64_t units_per_tile, int64_t lds_floats_per_wave, int64_t d_mid, float avg_num_neighbors,
+                    const float* num_neigh, float* agg /*[N,d_mid]*/, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * FullyConnectedTensorProduct(x, one_hot(species)) == species-indexed per-irrep linear
  * (nn/conv.py:59-61,77-79,84-86 called :109,112,123), and e3nn o3.Linear when species == NULL
  * (nn/nodewise.py:111-117, model_factory/tfn_scalar_tensor.py:49-51,68).

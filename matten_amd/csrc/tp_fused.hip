@@ -1,0 +1,340 @@
+// Fused radial-weight GEMM + 'uvu' Clebsch-Gordan tensor product + gather + neighbour sum (v4).
+// (reference nn/utils.py:246-251,260,263 + nn/conv.py:113-120)
+//
+// The per-edge radial weights w[E, W] are the one operand of the conv layer that does not fit on
+// chip (3.9 GB per layer at 1000 crystals).  This kernel never materialises them: the last layer of
+// the radial MLP is evaluated on the matrix cores right where its output is consumed,
+//
+//      w[e, col] = sum_k h2[e, k] * W2p[k, col]          (h2 = 32 hidden features per edge, 128 B)
+//
+// A wave owns one (input block, l2 group, node group) unit exactly like tp_block_kernel (a lane = one
+// channel u of one destination node, walking the node's CSR segment).  It proceeds in chunks of
+// CH edge slots:
+//   MFMA phase  v_mfma_f32_16x16x4_f32, edges of the chunk as the N dimension, the unit's weight
+//               columns [u][coupling] as M, K = 32.  A = W2p tile (L2-resident, 121 KB per layer),
+//               B = h2 rows.  The D fragment (4 consecutive columns of one edge) goes to a wave-private
+//               LDS tile with one 16-byte store.
+//   VALU phase  each lane reads its NC weights of its node's edge from LDS and contracts them with
+//               x[src] and Y(e) through the literal-coefficient CG code (cg_gen.h).
+// Matrix-core and vector work of different waves overlap on the SIMD; HBM traffic per edge drops from
+// ~7.7 KB (write + read of w) to ~0.3 KB (h2 + harmonics + indices).
+//
+// h2p layout: [E, 32] with column g*8 + kk  <->  hidden feature pi(kk,g) = 16 (kk>>2) + 4 g + (kk&3):
+// exactly the registers lane group g of the hidden-layer kernel holds, and the order in which this
+// kernel's MFMA lane group g consumes the contraction index (A rows follow the same pi).
+#include "cg_gen.h"
+#include "common.h"
+#include "sh.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TILE_NODES = 32;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int N_XCD = 8;
+constexpr int MAXC = matten::GROUP_MAX_COMBOS;
+constexpr int HID = 32;
+
+struct GroupEntry {  // 32 x int32, built by matten_amd/plan.py (same record as tp_block.hip)
+    int kind;        // l1*GROUP_KIND_STRIDE + group index
+    int x_off;       // offset of channel 0 of this entry in the node feature row
+    int mul;         // channels in this entry
+    int cu_log2;     // lanes per node = 1 << cu_log2 >= mul
+    unsigned mask;   // bit c set <=> coupling c of the group exists in this layer
+    int w_base;      // first weight column of this entry ([u][c] order)
+    int pad[2];
+    int reserved[MAXC];
+    int out_off[MAXC];
+};
+static_assert(sizeof(GroupEntry) == 32 * 4, "GroupEntry layout");
+
+struct Args {
+    const float* x;
+    const float* h2p;   // [E, 32] permuted hidden features
+    const float* w2p;   // [32, w_pad] last MLP layer, pre-scaled, fused column order
+    const float* sh;
+    const int* rowptr;
+    const int* src_sorted;
+    const float* num_neigh;
+    float* agg;
+    int d_in, w_pad, sh_stride, d_mid, n_nodes, lds_per_wave;
+    float avg_nn;
+};
+
+template <int L1, int GI>
+__device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, float* __restrict__ tile, int node,
+                                          int lane, bool valid, int beg, int deg_node, int maxdeg) {
+    const int deg = valid ? deg_node : 0;  // edges this lane contracts (idle channel lanes: none)
+    using G = matten::Group<L1, GI>;
+    constexpr int NC = G::NC;
+    float acc[G::NACC];
+#pragma unroll
+    for (int k = 0; k < G::NACC; ++k) acc[k] = 0.0f;
+
+    const unsigned mask = ge.mask;
+    const int cu_log2 = ge.cu_log2;
+    const int cu = 1 << cu_log2;
+    const int npw = 64 >> cu_log2;               // nodes per wave
+    const int ch_log2 = npw >= 16 ? 0 : (4 - (6 - cu_log2));  // CH = max(1, 16 / npw)
+    const int CH = 1 << ch_log2;
+    const int T = npw >= 16 ? (npw >> 4) : 1;     // N tiles of 16 edges per chunk
+    const int ncols = ge.mul * NC;
+    const int MT = (ncols + 15) >> 4;
+    const int ycol = MT * 16;                    // harmonics of the edge live behind its weight columns
+    const int stride = MT * 16 + 32 + 4;         // floats per edge row of the LDS tile (+4: bank spread)
+
+    const int j = lane >> cu_log2;               // consumer role: node slot in the wave, channel
+    const int u = lane & (cu - 1);
+    const int g = lane >> 4, c = lane & 15;      // MFMA role
+    const int xcol = ge.x_off + u * G::D1;
+    // A operand (the entry's weight columns, <= 64 by construction of the plan) stays in registers for the
+    // whole CSR walk: av[mt][kk] = W2p[pi(kk,g)][w_base + 16*mt + c]
+    float av[4][8];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+            av[mt][kk] = (mt < MT) ? a.w2p[(int64_t)k * a.w_pad + ge.w_base + mt * 16 + c] : 0.0f;
+        }
+    }
+
+    for (int s0 = 0; s0 < maxdeg; s0 += CH) {
+        // ---- MFMA: w[edge n, col] = h2[edge n, :] . W2p[:, col] into the wave's LDS tile (edge n = jn*CH + so) ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < T) {
+                const int n = 16 * t + c;
+                const int jn = n >> ch_log2, so = n & (CH - 1);
+                const int begn = __shfl(beg, jn << cu_log2);
+                const int degn = __shfl(deg_node, jn << cu_log2);
+                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+                if (s0 + so < degn) {
+                    const int64_t en = begn + s0 + so;
+                    const f32x4* hp = reinterpret_cast<const f32x4*>(a.h2p + en * HID + g * 8);
+                    b0 = hp[0];
+                    b1 = hp[1];
+                    // stage the edge's harmonics once per edge (4 lanes x 32 B) instead of once per channel lane
+                    const f32x4* yp4 = reinterpret_cast<const f32x4*>(a.sh + en * a.sh_stride + g * 8);
+                    f32x4* yd = reinterpret_cast<f32x4*>(tile + (16 * t + c) * stride + ycol + g * 8);
+                    yd[0] = yp4[0];
+                    yd[1] = yp4[1];
+                }
+#ifndef MATTEN_ABLATE_NO_MFMA
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    if (mt < MT) {
+                        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][kk], b0[kk], d, 0, 0, 0);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][4 + kk], b1[kk], d, 0, 0, 0);
+                        *reinterpret_cast<f32x4*>(tile + (16 * t + c) * stride + mt * 16 + 4 * g) = d;
+                    }
+                }
+#else
+                if (b0[0] == 12345.f) tile[c] = b1[0];
+#endif
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tile is written
+        __builtin_amdgcn_wave_barrier();
+        // ---- VALU: contract this lane's channel for its node's edges of the chunk ----
+#ifndef MATTEN_ABLATE_NO_VALU
+        for (int so = 0; so < CH; ++so) {
+            const int s = s0 + so;
+            if (s < deg) {
+                const int e = beg + s;
+                const int src = a.src_sorted[e];
+                const float* xp = a.x + (int64_t)src * a.d_in + xcol;
+                const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
+                const float* yp = tile + ((j << ch_log2) + so) * stride + ycol + G::Y0;
+                float x[G::D1], y[G::NY], w[NC];
+#pragma unroll
+                for (int i = 0; i < G::D1; ++i) x[i] = xp[i];
+#pragma unroll
+                for (int jj = 0; jj < G::NY; ++jj) y[jj] = yp[jj];
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+                G::apply(mask, x, y, w, acc);
+            }
+        }
+#endif
+        __builtin_amdgcn_wave_barrier();  // LDS is in order per wave: the next chunk's stores follow these reads
+    }
+    if (valid) {
+        const float nn = a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node];
+        const float norm = 1.0f / sqrtf(nn);
+        float* orow = a.agg + (int64_t)node * a.d_mid;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            if ((mask >> cc) & 1u) {
+                const int d3 = 2 * G::L3[cc] + 1;
+                float* op = orow + ge.out_off[cc] + u * d3;
+#pragma unroll
+                for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
+                    if (k < d3) op[k] = acc[G::OFF[cc] + k] * norm;
+            }
+        }
+    }
+}
+
+#define MATTEN_GROUP_CASE(L1, GI) \
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, node, lane, valid, beg, deg, maxdeg); break;
+
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void tp_fused_kernel(Args a, const GroupEntry* __restrict__ entries,
+                                                                        const int* __restrict__ ustart,
+                                                                        int n_entries, int units_per_tile,
+                                                                        int blocks_per_tile, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int xcd = blockIdx.x % N_XCD;
+    const int q = blockIdx.x / N_XCD;
+    const int tile_id = (q / blocks_per_tile) * N_XCD + xcd;
+    if (tile_id >= n_tiles) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = (q % blocks_per_tile) * WAVES_PER_BLOCK + wave;
+    if (unit >= units_per_tile) return;
+    const int lane = threadIdx.x & 63;
+    float* tile = lds + wave * a.lds_per_wave;
+
+    int lo = 0, hi = n_entries;  // last entry with ustart[entry] <= unit (wave-uniform)
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ustart[mid] <= unit) lo = mid; else hi = mid;
+    }
+    const GroupEntry& ge = entries[lo];
+    const int r = unit - ustart[lo];
+
+    const int cu_log2 = ge.cu_log2;
+    const int cu = 1 << cu_log2;
+    const int nodes_per_wave = 64 >> cu_log2;
+    const int g_in_tile = r * nodes_per_wave + (lane >> cu_log2);
+    const int u = lane & (cu - 1);
+    const int node = tile_id * TILE_NODES + g_in_tile;
+    const bool in_range = (g_in_tile < TILE_NODES) && (node < a.n_nodes);
+    const bool valid = in_range && (u < ge.mul);
+    int beg = 0, deg = 0;
+    if (in_range) {  // every lane of a node (also idle channels) knows the segment: the MFMA role needs it
+        beg = a.rowptr[node];
+        deg = a.rowptr[node + 1] - beg;
+    }
+    int maxdeg = deg;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+    switch (ge.kind) {
+        MATTEN_FOR_EACH_GROUP(MATTEN_GROUP_CASE)
+        default: break;
+    }
+}
+
+// Hidden layers of the radial MLP: rbf(|v|) -> 32 -> 32, written as h2p [E,32] (see header comment).
+constexpr int NT = 4;
+__device__ __forceinline__ float silu(float z) { return z / (1.0f + expf(-z)); }
+
+template <int KS0>
+__global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __restrict__ geom, int64_t E, int n_basis,
+                                                            float r_start, float r_end,
+                                                            const float* __restrict__ w0p,
+                                                            const float* __restrict__ w1p, float* __restrict__ h2p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * (NT * 16);
+    if (e0 >= E) return;
+    float a1[2][8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+        a1[0][kk] = w1p[k * HID + c];
+        a1[1][kk] = w1p[k * HID + 16 + c];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t e = e0 + nt * 16 + c;
+        const float len = geom[e < E ? e : E - 1].w;
+        f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS0; ++kk) {
+            int k = 4 * kk + g;
+            float b = (k < n_basis) ? matten::bessel_basis(len, k, n_basis, r_start, r_end) : 0.0f;
+            h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0p[k * HID + c], b, h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0p[k * HID + 16 + c], b, h1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            h0[r] = silu(h0[r]);
+            h1[r] = silu(h1[r]);
+        }
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float b = kk < 4 ? h0[kk & 3] : h1[kk & 3];
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0][kk], b, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1][kk], b, o1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0[r] = silu(o0[r]);
+            o1[r] = silu(o1[r]);
+        }
+        if (e < E) {
+            f32x4* dst = reinterpret_cast<f32x4*>(h2p + e * HID + g * 8);
+            dst[0] = o0;
+            dst[1] = o1;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
+                                    const float* w0p, int nb_pad, const float* w1p, int hidden, float* h2p,
+                                    matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_edges < 0 || hidden != HID || (nb_pad & 3) || nb_pad < n_basis || nb_pad > 16) return MATTEN_EINVAL;
+    if (n_edges == 0) return MATTEN_OK;
+    if (!geom_sorted || !w0p || !w1p || !h2p) return MATTEN_EINVAL;
+    unsigned grid = (unsigned)matten_cdiv(n_edges, 4 * NT * 16);
+#define LAUNCH(K) \
+    radial_hidden_kernel<K><<<grid, 256, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis, r_start, r_end, w0p, w1p, h2p)
+    switch (nb_pad >> 2) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_tp_fused(const float* x, int64_t d_in, const float* h2p, const float* w2p, int64_t w_pad,
+                               const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr,
+                               const int32_t* src_sorted, int64_t n_nodes, const int32_t* group_entries,
+                               const int32_t* unit_start, int64_t n_entries, int64_t units_per_tile,
+                               int64_t lds_floats_per_wave, int64_t d_mid, float avg_num_neighbors,
+                               const float* num_neigh, float* agg, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_nodes < 0 || d_in <= 0 || w_pad <= 0 || sh_stride < 32 || (sh_stride & 3) || n_entries <= 0 ||
+        units_per_tile <= 0 || d_mid <= 0 || lds_floats_per_wave <= 0 || (lds_floats_per_wave & 3))
+        return MATTEN_EINVAL;
+    if (n_nodes == 0) return MATTEN_OK;
+    if (!x || !h2p || !w2p || !sh_sorted || !rowptr || !src_sorted || !group_entries || !unit_start || !agg)
+        return MATTEN_EINVAL;
+    if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
+    const size_t lds = sizeof(float) * (size_t)lds_floats_per_wave * WAVES_PER_BLOCK;
+    if (lds > 64 * 1024) return MATTEN_EINVAL;
+    Args a{x, h2p, w2p, sh_sorted, rowptr, src_sorted, num_neigh, agg, (int)d_in, (int)w_pad, (int)sh_stride,
+           (int)d_mid, (int)n_nodes, (int)lds_floats_per_wave, avg_num_neighbors};
+    const int n_tiles = (int)matten_cdiv(n_nodes, TILE_NODES);
+    const int blocks_per_tile = (int)matten_cdiv(units_per_tile, WAVES_PER_BLOCK);
+    const int64_t grid = matten_cdiv(n_tiles, N_XCD) * N_XCD * (int64_t)blocks_per_tile;
+    if (grid >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+    tp_fused_kernel<<<(unsigned)grid, WAVES_PER_BLOCK * 64, lds, stream>>>(
+        a, (const GroupEntry*)group_entries, unit_start, (int)n_entries, (int)units_per_tile, blocks_per_tile, n_tiles);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}

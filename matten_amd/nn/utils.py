@@ -91,7 +91,8 @@ class RadialMLP(torch.nn.Module):
             cols = self.out_cols.to(w2.device)
             w2s = torch.where(cols[None, :] >= 0, w2s[:, cols.clamp(min=0)], w2s.new_zeros(()))
             W = cols.numel()
-        nb_pad, w_pad = (nb + 3) // 4 * 4, (W + 15) // 16 * 16
+        # +16 spare columns: the fused kernel reads whole 16-column tiles starting at any entry
+        nb_pad, w_pad = (nb + 3) // 4 * 4, (W + 15) // 16 * 16 + 16
         w0p = w0.new_zeros(nb_pad, h)
         w0p[:nb] = w0 / nb**0.5
         w1p = (w1 * (self.act_cst / h**0.5)).contiguous()
@@ -100,10 +101,18 @@ class RadialMLP(torch.nn.Module):
         return w0p, w1p, w2p
 
     def forward(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float) -> Tensor:
+        """Per-edge weights w[E, w_pad] (all three layers)."""
         if n_basis != self.hs[0]:
             raise ValueError(f"radial basis size {n_basis} != MLP input {self.hs[0]}")
         w0p, w1p, w2p = self._packed.get(self.layer0.weight, self.layer1.weight, self.layer2.weight)
         return ops.radial_mlp(geom_sorted, n_basis, r_start, r_end, w0p, w1p, w2p)
+
+    def hidden(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float):
+        """(h2p[E,32], w2p): the two hidden layers evaluated, the last layer left to the fused TP kernel."""
+        if n_basis != self.hs[0]:
+            raise ValueError(f"radial basis size {n_basis} != MLP input {self.hs[0]}")
+        w0p, w1p, w2p = self._packed.get(self.layer0.weight, self.layer1.weight, self.layer2.weight)
+        return ops.radial_hidden(geom_sorted, n_basis, r_start, r_end, w0p, w1p), w2p
 
 
 class UVUTensorProduct(torch.nn.Module):
@@ -129,13 +138,14 @@ class UVUTensorProduct(torch.nn.Module):
         self.irreps_mid = self.plan.irreps_mid
         self.weight_numel = self.plan.weight_numel
         layer_sizes = [mlp_input_size] + mlp_num_hidden_layers * [mlp_hidden_size] + [self.weight_numel]
-        # "blocks": couplings fused per input block, literal CG coefficients (production); its radial
-        #           weights are laid out [entry][u][coupling] (plan.fused_cols)
+        # "fused" : production -- last radial-MLP layer on the matrix cores inside the TP kernel, the per-edge
+        #           weights never reach memory; weight columns in [entry][u][coupling] order (plan.fused_cols)
+        # "blocks": same contraction kernel fed from a materialised w[E, W] (two-kernel architecture)
         # "paths" : one wave per path (same literals, no fusion); "table": table-driven kernel; both read
         #           the reference's weight layout and are kept as independent implementations for tests
-        self.impl = os.environ.get("MATTEN_TP_IMPL", "blocks")
+        self.impl = os.environ.get("MATTEN_TP_IMPL", "fused")
         self.weight_nn = RadialMLP(layer_sizes, act=mlp_activation,
-                                   out_cols=self.plan.fused_cols if self.impl == "blocks" else None)
+                                   out_cols=self.plan.fused_cols if self.impl in ("blocks", "fused") else None)
         self._tables = DeviceTables(
             m_idx=self.plan.m_terms_idx, m_coef=self.plan.m_terms_coef, out_meta=self.plan.out_meta,
             entries=self.plan.path_entries, unit_start=self.plan.unit_start,
@@ -149,10 +159,17 @@ class UVUTensorProduct(torch.nn.Module):
     def forward(self, node_feats: Tensor, data: DataKey.Type, avg_num_neighbors=None) -> Tensor:
         """sum over incoming edges of TP(x[src], Y(edge), MLP(rbf(edge))), normalised; [N, d_mid]."""
         nb, r0, r1 = data[DataKey.AMD_RBF].tolist()
-        w_edge = self.weight_nn(data[DataKey.AMD_GEOM], int(nb), r0, r1)
         dev = node_feats.device
         avg = avg_num_neighbors if avg_num_neighbors is not None else 0.0
         num_neigh = None if avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
+        if self.impl == "fused":
+            h2p, w2p = self.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1)
+            return ops.tp_fused(
+                node_feats, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
+                self._tables.get("gentries", dev), self._tables.get("gstart", dev), self.plan.group_units_per_tile,
+                self.plan.fused_lds_floats_per_wave, self.plan.d_mid, avg, num_neigh,
+            )
+        w_edge = self.weight_nn(data[DataKey.AMD_GEOM], int(nb), r0, r1)
         if self.impl == "blocks":
             return ops.tp_blocks(
                 node_feats, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],

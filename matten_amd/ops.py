@@ -231,6 +231,43 @@ def tp_blocks(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, uni
     return agg
 
 
+def radial_hidden(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p) -> torch.Tensor:
+    lib = _lib.load()
+    geom_sorted = _need(geom_sorted, torch.float32, "geom_sorted")
+    w0p, w1p = _need(w0p, torch.float32, "w0p"), _need(w1p, torch.float32, "w1p")
+    E = geom_sorted.shape[0]
+    h2p = torch.empty(E, 32, dtype=torch.float32, device=geom_sorted.device)
+    with _timed("radial_hidden"):
+        rc = lib.matten_radial_hidden(_ptr(geom_sorted), E, n_basis, r_start, r_end, _ptr(w0p), w0p.shape[0],
+                                      _ptr(w1p), w0p.shape[1], _ptr(h2p), _stream())
+    _lib.check(rc, "matten_radial_hidden")
+    return h2p
+
+
+def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_start, units_per_tile: int,
+             lds_floats_per_wave: int, d_mid: int, avg_num_neighbors: float, num_neigh=None) -> torch.Tensor:
+    lib = _lib.load()
+    from .plan import TP_TILE_NODES
+
+    if lib.matten_tp_tile_nodes() != TP_TILE_NODES:
+        raise _lib.MattenHipError("plan.TP_TILE_NODES does not match the library's node tile")
+    x = _need(x, torch.float32, "node_features")
+    h2p = _need(h2p, torch.float32, "h2p")
+    w2p = _need(w2p, torch.float32, "w2p")
+    sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
+    N, d_in = x.shape
+    if num_neigh is not None:
+        num_neigh = _need(num_neigh, torch.float32, "num_neigh")
+    agg = torch.empty(N, d_mid, dtype=torch.float32, device=x.device)
+    with _timed(f"tp_scatter/d_mid={d_mid}"):
+        rc = lib.matten_tp_fused(_ptr(x), d_in, _ptr(h2p), _ptr(w2p), w2p.shape[1], _ptr(sh_sorted),
+                                 sh_sorted.shape[1], _ptr(rowptr), _ptr(src_sorted), N, _ptr(entries),
+                                 _ptr(unit_start), entries.shape[0], units_per_tile, lds_floats_per_wave, d_mid,
+                                 float(avg_num_neighbors or 0.0), _ptr(num_neigh), _ptr(agg), _stream())
+    _lib.check(rc, "matten_tp_fused")
+    return agg
+
+
 def species_linear(x, species_order, wp, w_stride: int, metas, add=None) -> torch.Tensor:
     """species_order: None (plain linear) or (order[N] i32, seg[S+1] i32) = nodes sorted by species.
     metas: list of int32 [d_out,4] tensors (passes).  out = add + sum_passes."""

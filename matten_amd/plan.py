@@ -92,6 +92,7 @@ class UVUPlan:
     group_unit_start: np.ndarray = None
     group_units_per_tile: int = 0
     fused_cols: np.ndarray = None     # int64 [W_fused]: fused weight column -> reference weight column, -1 = zero
+    fused_lds_floats_per_wave: int = 0  # LDS tile of matten_tp_fused
 
 
 def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
@@ -184,6 +185,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
     # ---- block-fused groups: all couplings of one input block and one l2 range (cg_gen.h Group<l1,g>) ----
     gentries, gstart = [], [0]
     fused_cols: List[int] = []
+    lds_need = 0
     by_block: Dict[int, List[UVUPath]] = {}
     for p in paths:
         by_block.setdefault(p.i_in1, []).append(p)
@@ -195,10 +197,17 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
             present = {(p.l2, p.l3): p for p in plist if lo <= p.l2 <= hi}
             if not present:
                 continue
-            for u0 in range(0, mul, 64):
-                mul_c = min(64, mul - u0)
+            # channels per entry: a power of two <= 64 whose [u][c] weight block stays <= 64 columns, so the
+            # fused kernel keeps the whole A operand (4 MFMA tiles x 8 k-steps) in registers
+            cap = 64
+            while cap > 1 and cap * len(combos) > 64:
+                cap //= 2
+            for u0 in range(0, mul, cap):
+                mul_c = min(cap, mul - u0)
                 cu_log2 = max(0, (mul_c - 1).bit_length())
                 nodes_per_wave = max(1, 64 // (1 << cu_log2))
+                n_tiles16 = max(1, nodes_per_wave // 16)
+                lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(combos)) // 16)) + 32 + 4))
                 row = [l1 * TP_KIND_STRIDE + gi, plist[0].x_off + u0 * d1, mul_c, cu_log2, 0, len(fused_cols), 0, 0] + [0] * 24
                 mask = 0
                 for c, key in enumerate(combos):
@@ -221,6 +230,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         units_per_tile=ustart[-1],
         group_entries=np.array(gentries, dtype=np.int64).astype(np.int32), group_unit_start=np.array(gstart, dtype=np.int32),
         group_units_per_tile=gstart[-1], fused_cols=np.array(fused_cols, dtype=np.int64),
+        fused_lds_floats_per_wave=(lds_need + 3) // 4 * 4,
     )
 
 

@@ -312,6 +312,21 @@ def test_tp_kernels_agree_and_match_oracle(per_node_norm):
     w_fused = torch.nn.functional.pad(w_fused, (0, (-w_fused.shape[1]) % 16)).contiguous()
     c = ops.tp_blocks(x.to(DEV), w_fused, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV),
                       t.get("gstart", DEV), p.group_units_per_tile, p.d_mid, avg, nn_)
+    # fused: w = h2 @ W2 evaluated inside the kernel; feed it a rank-deficient factorisation of the same w
+    h2 = torch.randn(E, 32, device=DEV)
+    w2 = torch.randn(32, p.weight_numel, device=DEV) / 32**0.5
+    w_lr = h2 @ w2                                      # [E(original order), W] reference-layout weights
+    msg_lr = ref_tp.tp(x[cpu["edge_index"][0]], ref["edge_attrs"], w_lr.cpu())
+    want_lr = scatter(msg_lr, cpu["edge_index"][1], dim_size=N)
+    want_lr = want_lr / (cpu["num_neigh"].reshape(-1, 1) ** 0.5 if per_node_norm else 18.0**0.5)
+    w2f = torch.where(cols[None, :] >= 0, w2[:, cols.clamp(min=0)], w2.new_zeros(()))
+    w2f = torch.nn.functional.pad(w2f, (0, (-w2f.shape[1]) % 16 + 16)).contiguous()
+    # h2p column g*8+kk <-> hidden feature 16*(kk>>2) + 4*g + (kk&3)
+    feat = torch.tensor([16 * (kk >> 2) + 4 * g + (kk & 3) for g in range(4) for kk in range(8)], device=DEV)
+    h2p = h2[perm.long()][:, feat].contiguous()
+    f = ops.tp_fused(x.to(DEV), h2p, w2f, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV), t.get("gstart", DEV),
+                     p.group_units_per_tile, p.fused_lds_floats_per_wave, p.d_mid, avg, nn_)
+    close(f, want_lr, 5e-5, "tp_fused vs oracle")
     close(c, want, 2e-5, "tp_blocks vs oracle")
     close(c, a, 2e-5, "tp_blocks vs tp_paths")
     close(a, want, 2e-5, "tp_paths vs oracle")

@@ -44,3 +44,24 @@ for l1 in range(5):
     run(sel, f"l1={l1}")
 for kind in sorted(set(p.group_entries[:, 0])):
     run(p.group_entries[p.group_entries[:, 0] == kind], f"kind l1={kind // mplan.TP_KIND_STRIDE} g={kind % mplan.TP_KIND_STRIDE}")
+
+
+# ---- fused kernel (radial hidden features + in-kernel last MLP layer) ----
+h2p = torch.randn(E, 32, device=dev)
+w2p = torch.randn(32, wpad + 16, device=dev)
+def run_fused(entries_np, label):
+    ent = torch.from_numpy(np.ascontiguousarray(entries_np)).to(dev)
+    waves = []
+    for row in entries_np:
+        cu = 1 << int(row[3]); npw = max(1, 64 // cu); waves.append(-(-mplan.TP_TILE_NODES // npw))
+    ust = torch.tensor(np.concatenate([[0], np.cumsum(waves)]), dtype=torch.int32, device=dev)
+    upt = int(ust[-1])
+    f = lambda: ops.tp_fused(x, h2p, w2p, geo["sh_sorted"], rowptr, src, ent, ust, upt, p.fused_lds_floats_per_wave, p.d_mid, 18.0)
+    for _ in range(2): f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5): f()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
+    print(f"fused {label:22s} entries {len(entries_np):2d} waves/tile {upt:3d}  {dt*1e3:7.3f} ms")
+run_fused(p.group_entries, "all")
+for l1 in range(5):
+    run_fused(p.group_entries[p.group_entries[:, 0] // mplan.TP_KIND_STRIDE == l1], f"l1={l1}")
