@@ -185,7 +185,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
 #define MATTEN_GROUP_CASE(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, node, lane, valid, beg, deg, maxdeg); break;
 
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void tp_fused_kernel(Args a, const GroupEntry* __restrict__ entries,
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 3) void tp_fused_kernel(Args a, const GroupEntry* __restrict__ entries,
                                                                         const int* __restrict__ ustart,
                                                                         int n_entries, int units_per_tile,
                                                                         int blocks_per_tile, int n_tiles) {
