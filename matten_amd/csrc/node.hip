@@ -8,26 +8,28 @@
 
 namespace {
 
-// v3: nodes are visited in species-sorted order so that a workgroup works on rows of ONE species:
-// it stages that species' packed weight table in LDS once (<= ~36 KB at the paper config), then walks
-// its share of the species' rows in chunks of NB rows staged in LDS with coalesced copies.  The inner
-// product loop touches LDS only: weights W[w_base(o) + u*w_step] (consecutive lanes -> consecutive
-// banks) and features xs[r][x_base(o) + u*x_step] (broadcast).  Every input row is read from HBM once.
-//   order[N]   node ids sorted by species (NULL: identity, single weight table)
-//   seg[S+1]   offsets of each species' run in `order`
-constexpr int SL_ROWS_PER_BLOCK = 16;
+// Species-indexed per-irrep linear on the fp32 matrix cores.
+// For one irrep block (mul_in -> mul_out channels, 2l+1 components) and one component k the op is a
+// plain GEMM over rows:  out[row, w] = sum_u x[row, u] W_s[u, w]  with strides (x: d, out: d).  The host
+// enumerates "items" = (irrep block, component, 16-column tile of w); a wave takes an item for a tile
+// of 16 rows and runs ceil(mul_in/4) v_mfma_f32_16x16x4_f32:
+//      A[m = row][k = u]  = x[row, x_off + u*x_step]          (global, L2-resident gathers)
+//      B[k = u][n = w]    = Ws[w_off + u*w_step + n]          (LDS: the species' packed table, staged once)
+//      D[row][w]         -> out[row, o_off + n*o_step] (+ add)
+// Rows are visited in species-sorted order (order/seg) so a workgroup sees ONE weight table.
+struct LinItem {  // 8 x int32
+    int x_off, x_step, mul_in, w_off, w_step, n_cols, o_off, o_step;
+};
+constexpr int SL_ROWS_PER_BLOCK = 64;  // 4 row tiles of 16
 constexpr int SL_THREADS = 512;
+typedef float sl_f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(SL_THREADS) void species_linear_kernel(
-    const float* __restrict__ x, int d_in, int nb, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ seg, int n_species, const float* __restrict__ wp, int w_stride, int w_in_lds,
-    const int4* __restrict__ out_meta, int d_out, const float* __restrict__ add, int n_rows,
-    float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ws = lds;                                   // [w_stride] if w_in_lds
-    float* xs = lds + (w_in_lds ? ((w_stride + 3) & ~3) : 0);  // [nb][d_in]
+    const float* __restrict__ x, int d_in, const int32_t* __restrict__ order, const int32_t* __restrict__ seg,
+    int n_species, const float* __restrict__ wp, int w_stride, int w_in_lds, const LinItem* __restrict__ items,
+    int n_items, int d_out, const float* __restrict__ add, int n_rows, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];
 
-    // which species / which slice of its rows does this block own?
     int b = blockIdx.x, s = 0, lo = 0, hi = 0;
     if (seg) {
         bool found = false;
@@ -51,38 +53,51 @@ __global__ __launch_bounds__(SL_THREADS) void species_linear_kernel(
     const float* wsp = wp + (int64_t)s * w_stride;
     if (w_in_lds) {
         for (int i = threadIdx.x; i < w_stride; i += blockDim.x) ws[i] = wsp[i];
+        __syncthreads();
         wsp = ws;
     }
 
-    for (int c0 = lo; c0 < hi; c0 += nb) {
-        const int rows = min(nb, hi - c0);
-        __syncthreads();  // previous chunk fully consumed (and ws visible on the first pass)
-        for (int r = 0; r < rows; ++r) {
-            const int n = order ? order[c0 + r] : (c0 + r);
-            const float* src = x + (int64_t)n * d_in;
-            for (int i = threadIdx.x; i < d_in; i += blockDim.x) xs[r * d_in + i] = src[i];
-        }
-        __syncthreads();
-        const int total_out = rows * d_out;
-        for (int idx = threadIdx.x; idx < total_out; idx += blockDim.x) {
-            const int r = idx / d_out;
-            const int o = idx - r * d_out;
-            const int4 m = out_meta[o];
-            const int x_step = m.y & 0xffff, mul_in = m.y >> 16;
-            const float* xp = xs + r * d_in + m.x;
-            const float* w = wsp + m.z;
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-            int u = 0;
-            for (; u + 4 <= mul_in; u += 4) {
-                a0 = fmaf(w[(u + 0) * m.w], xp[(u + 0) * x_step], a0);
-                a1 = fmaf(w[(u + 1) * m.w], xp[(u + 1) * x_step], a1);
-                a2 = fmaf(w[(u + 2) * m.w], xp[(u + 2) * x_step], a2);
-                a3 = fmaf(w[(u + 3) * m.w], xp[(u + 3) * x_step], a3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int n_row_tiles = (hi - lo + 15) >> 4;
+    // work = (row tile, item); waves stride through it
+    for (int wk = wave; wk < n_row_tiles * n_items; wk += SL_THREADS / 64) {
+        const int rt = wk / n_items;
+        const LinItem it = items[wk - rt * n_items];
+        // A role: row m = c of the tile
+        const int ra = lo + rt * 16 + c;
+        const bool ra_ok = ra < hi;
+        const int na = ra_ok ? (order ? order[ra] : ra) : 0;
+        const float* xa = x + (int64_t)na * d_in + it.x_off;
+        const float* wb = wsp + it.w_off + c;
+        const bool col_ok = c < it.n_cols;
+        sl_f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        const int ksteps = (it.mul_in + 3) >> 2;
+        // batches of 16 k-steps: 16 independent gathers in flight per lane, then 16 MFMAs
+        for (int k0 = 0; k0 < ksteps; k0 += 16) {
+            float av[16], bv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int u = 4 * (k0 + q) + g;
+                const bool u_ok = u < it.mul_in;
+                av[q] = (ra_ok && u_ok) ? xa[u * it.x_step] : 0.0f;
+                bv[q] = (col_ok && u_ok) ? wb[u * it.w_step] : 0.0f;
             }
-            for (; u < mul_in; ++u) a0 = fmaf(w[u * m.w], xp[u * x_step], a0);
-            const int n = order ? order[c0 + r] : (c0 + r);
-            const int64_t oi = (int64_t)n * d_out + o;
-            out[oi] = (add ? add[oi] : 0.0f) + ((a0 + a1) + (a2 + a3));
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (k0 + q < ksteps) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], d, 0, 0, 0);
+        }
+        // D[row = 4g + r][col = c]
+        if (col_ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = lo + rt * 16 + 4 * g + r;
+                if (rr < hi) {
+                    const int nn = order ? order[rr] : rr;
+                    const int64_t oi = (int64_t)nn * d_out + it.o_off + c * it.o_step;
+                    out[oi] = (add ? add[oi] : 0.0f) + d[r];
+                }
+            }
         }
     }
 }
@@ -157,35 +172,25 @@ __global__ void dense_rows_kernel(const float* __restrict__ x, int n_in, const f
 }  // namespace
 
 extern "C" int matten_species_linear(const float* x, int64_t d_in, const int32_t* order, const int32_t* seg,
-                                     int64_t n_species, const float* wp, int64_t w_stride, const int32_t* out_meta,
-                                     int64_t d_out, const float* add, int64_t n_rows, float* out,
+                                     int64_t n_species, const float* wp, int64_t w_stride, const int32_t* items,
+                                     int64_t n_items, int64_t d_out, const float* add, int64_t n_rows, float* out,
                                      matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (n_rows < 0 || d_in <= 0 || d_out <= 0 || n_species <= 0 || w_stride < 0 || n_rows >= ((int64_t)1 << 31))
+    if (n_rows < 0 || d_in <= 0 || d_out <= 0 || n_species <= 0 || w_stride < 0 || n_items < 0 ||
+        n_rows >= ((int64_t)1 << 31))
         return MATTEN_EINVAL;
     if (n_rows == 0) return MATTEN_OK;
-    if (!x || !wp || !out_meta || !out) return MATTEN_EINVAL;
+    if (!x || !wp || !out || (n_items > 0 && !items)) return MATTEN_EINVAL;
     if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
     if (!order && n_species != 1) return MATTEN_EINVAL;
-    // LDS plan: weight table (if it fits in 64 KiB) + as many rows as fit in the rest of ~96 KiB, <= 8
     const size_t w_bytes = sizeof(float) * (size_t)((w_stride + 3) & ~3);
     const int w_in_lds = w_bytes <= 64 * 1024 ? 1 : 0;
-    const size_t budget = 78 * 1024 - (w_in_lds ? w_bytes : 0);  // two workgroups per CU
-    int nb = (int)(budget / (sizeof(float) * (size_t)d_in));
-    nb = nb > 8 ? 8 : nb;
-    if (nb < 1) nb = 1;
-    const size_t lds = (w_in_lds ? w_bytes : 0) + sizeof(float) * (size_t)nb * (size_t)d_in;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)species_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return MATTEN_ELAUNCH;
-        attr_set = true;
-    }
+    const size_t lds = w_in_lds ? w_bytes : 16;
     const int64_t grid = matten_cdiv(n_rows, SL_ROWS_PER_BLOCK) + (order ? n_species : 0);
-    species_linear_kernel<<<(unsigned)grid, SL_THREADS, lds, stream>>>(x, (int)d_in, nb, order, seg, (int)n_species, wp,
-                                                                 (int)w_stride, w_in_lds, (const int4*)out_meta,
-                                                                 (int)d_out, add, (int)n_rows, out);
+    species_linear_kernel<<<(unsigned)grid, SL_THREADS, lds, stream>>>(x, (int)d_in, order, seg, (int)n_species, wp,
+                                                                       (int)w_stride, w_in_lds,
+                                                                       (const LinItem*)items, (int)n_items,
+                                                                       (int)d_out, add, (int)n_rows, out);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }
@@ -232,4 +237,4 @@ extern "C" int matten_dense_rows(const float* x, int64_t n_in, const float* q, i
     return MATTEN_OK;
 }
 
-extern "C" int matten_abi_version(void) { return 4; }
+extern "C" int matten_abi_version(void) { return 5; }

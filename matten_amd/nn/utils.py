@@ -57,7 +57,7 @@ class SpeciesLinear(torch.nn.Module):
         wp = self._packed.get(self.weight)
         metas = [self._tables.get(f"meta{i}", x.device) for i in range(len(self.plan.passes))]
         return ops.species_linear(x, species_order if self.n_species is not None else None, wp, self.plan.w_stride,
-                                  metas, add)
+                                  metas, self.plan.d_out, add, self.plan.fully_covered)
 
 
 class _RadialLayer(torch.nn.Module):

@@ -268,24 +268,28 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_start, un
     return agg
 
 
-def species_linear(x, species_order, wp, w_stride: int, metas, add=None) -> torch.Tensor:
+def species_linear(x, species_order, wp, w_stride: int, item_tables, d_out: int, add=None,
+                   fully_covered: bool = True) -> torch.Tensor:
     """species_order: None (plain linear) or (order[N] i32, seg[S+1] i32) = nodes sorted by species.
-    metas: list of int32 [d_out,4] tensors (passes).  out = add + sum_passes."""
+    item_tables: list of int32 [n_items,8] tensors (passes).  out = add + sum_passes."""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
     wp = _need(wp, torch.float32, "packed weights")
     n_rows, d_in = x.shape
-    d_out = metas[0].shape[0]
-    out = torch.empty(n_rows, d_out, dtype=torch.float32, device=x.device)
     order, seg = species_order if species_order is not None else (None, None)
     n_species = wp.shape[0] if wp.dim() == 2 else 1
     cur_add = add
     if cur_add is not None:
         cur_add = _need(cur_add, torch.float32, "add")
-    for meta in metas:
+    if fully_covered:
+        out = torch.empty(n_rows, d_out, dtype=torch.float32, device=x.device)
+    else:  # irreps without an input path stay zero (e3nn output_mask semantics)
+        out = cur_add.clone() if cur_add is not None else torch.zeros(n_rows, d_out, dtype=torch.float32, device=x.device)
+    for items in item_tables:
         _lib.check(
             lib.matten_species_linear(_ptr(x), d_in, _ptr(order), _ptr(seg), n_species, _ptr(wp), w_stride,
-                                      _ptr(meta), d_out, _ptr(cur_add), n_rows, _ptr(out), _stream()),
+                                      _ptr(items), items.shape[0], d_out, _ptr(cur_add), n_rows, _ptr(out),
+                                      _stream()),
             "matten_species_linear",
         )
         cur_add = out

@@ -246,7 +246,8 @@ class LinearPlan:
     w_stride: int                 # packed floats per species
     gather: np.ndarray            # int64 [n_species, w_stride]: packed <- flat parameter index
     scale: np.ndarray             # f32 [w_stride]: path normalisation
-    passes: List[np.ndarray]      # each int32 [d_out, 4] out_meta; pass p>0 accumulates onto pass p-1
+    passes: List[np.ndarray]      # each int32 [n_items, 8] item table (matten_species_linear); pass p>0 accumulates
+    fully_covered: bool = True    # False: some output irreps have no input path and must be zero-filled
     d_in: int = 0
     d_out: int = 0
     flops_per_row: int = 0
@@ -280,21 +281,25 @@ def _plan_linear_like(irreps_in: Irreps, irreps_out: Irreps, n_species: int, pat
     n_pass = max([len(v) for v in per_out.values()] + [1])
     passes = []
     for ps in range(n_pass):
-        meta = np.zeros((irreps_out.dim, 4), dtype=np.int32)
+        items = []
         for i_out, lst in per_out.items():
             if ps >= len(lst):
                 continue
             i_in, pk = lst[ps]
             mi, mo = irreps_in[i_in].mul, irreps_out[i_out].mul
             d = irreps_out[i_out].ir.dim
-            for wv in range(mo):
-                for k in range(d):
-                    meta[o_offs[i_out] + wv * d + k] = (x_offs[i_in] + k, d | (mi << 16), pk + wv, mo)
-        passes.append(meta)
+            for k in range(d):
+                for nt in range(-(-mo // 16)):
+                    items.append((x_offs[i_in] + k, d, mi, pk + 16 * nt, mo, min(16, mo - 16 * nt),
+                                  o_offs[i_out] + 16 * nt * d + k, d))
+        # heavy items first: better tail balance when waves stride through (row tile, item) pairs
+        items.sort(key=lambda t: -t[2])
+        passes.append(np.array(items, dtype=np.int32).reshape(-1, 8))
+    fully_covered = all(i in per_out for i in range(len(irreps_out)) if irreps_out[i].dim > 0)
     gather = np.concatenate(gather_cols, axis=1) if gather_cols else np.zeros((n_species, 0), dtype=np.int64)
     scale = np.concatenate(scale_cols) if scale_cols else np.zeros(0, dtype=np.float32)
     return LinearPlan(irreps_in, irreps_out, n_species, flat, packed, gather.astype(np.int64), scale, passes,
-                      irreps_in.dim, irreps_out.dim, flops)
+                      fully_covered, irreps_in.dim, irreps_out.dim, flops)
 
 
 def plan_fctp(irreps_in1, n_species: int, irreps_out) -> LinearPlan:

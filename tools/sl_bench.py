@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of species_linear (lin2 of the last conv layer): species-sorted gather vs identity order."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from matten_amd import ops, plan as mplan
+from matten_amd.o3 import Irreps
+dev = "cuda:0"
+N, S = 64000, 10
+irr = "32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e"
+u = mplan.plan_uvu(irr, Irreps.spherical_harmonics(4), irr)
+lp = mplan.plan_fctp(u.irreps_out, S, irr)
+x = torch.randn(N, lp.d_in, device=dev)
+wp = torch.randn(S, lp.w_stride, device=dev)
+items = [torch.from_numpy(np.ascontiguousarray(m)).to(dev) for m in lp.passes]
+def bench(order, seg, label):
+    f = lambda: ops.species_linear(x, (order, seg), wp, lp.w_stride, items, lp.d_out, None, True)
+    for _ in range(2): f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5): f()
+    torch.cuda.synchronize(); print(f"{label:40s} {(time.perf_counter()-t)/5*1e3:.3f} ms  (d_in {lp.d_in}, items {items[0].shape[0]})")
+species = torch.randint(0, S, (N,), device=dev)
+ids = torch.stack([torch.arange(N, device=dev), species])
+order, seg, _, _ = ops.csr_build(ids, S)
+bench(order, seg, "random species, sorted gather")
+# contiguous species runs: node n has species n // (N/S): order == identity
+species2 = (torch.arange(N, device=dev) * S // N)
+order2, seg2, _, _ = ops.csr_build(torch.stack([torch.arange(N, device=dev), species2]), S)
+bench(order2, seg2, "contiguous species (identity order)")
