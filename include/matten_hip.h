@@ -169,11 +169,11 @@ int matten_tp_fused(const float* x, int64_t d_in, const float* h2p, const float*
  * FullyConnectedTensorProduct(x, one_hot(species)) == species-indexed per-irrep linear
  * (nn/conv.py:59-61,77-79,84-86 called :109,112,123), and e3nn o3.Linear when species == NULL
  * (nn/nodewise.py:111-117, model_factory/tfn_scalar_tensor.py:49-51,68).
- *   out[n, o_off + c*o_step] = (add ? add[..] : 0) + sum_{u<mul_in} Wp[species(n), w_off + u*w_step + c] * x[n, x_off + u*x_step]
- *   for every item and every column c < n_cols.  fp32 MFMA (rows x 16-column tiles).
- *   items[n_items, 8] int32 {x_off, x_step, mul_in, w_off, w_step, n_cols(<=16), o_off, o_step}: one per
- *       (irrep block, component, 16-column tile of the output multiplicity); outputs no item covers are
- *       NOT written (the caller zero-fills unreachable irreps)
+ *   out[n, o_off + w*d + k] = (add ? add[..] : 0) + sum_{u<mul_in} Wp[species(n), w_off + u*mo + w] * x[n, x_off + u*d + k]
+ *   for every segment, w < mo, k < d.  fp32 MFMA over tiles of 16 rows x 16 output channels.
+ *   segs[n_segs, 8] int32 {x_off, d, mul_in, w_off, mo, o_off, 0, 0}: one per (input irrep block ->
+ *       output irrep block) path; outputs no segment covers are NOT written (the caller zero-fills
+ *       unreachable irreps)
  *   Wp[n_species, w_stride]: weights repacked per species with the path normalisation folded in.
  *   order[N] / seg[n_species+1]: node ids sorted by species and the offsets of each species' run
  *   (e.g. perm / rowptr of matten_csr_build over {row0 = node id, row1 = species}); both NULL for a
@@ -181,7 +181,7 @@ int matten_tp_fused(const float* x, int64_t d_in, const float* h2p, const float*
  *   one species is staged on chip once per workgroup; outputs land at their original row.
  * ------------------------------------------------------------------------------------------ */
 int matten_species_linear(const float* x, int64_t d_in, const int32_t* order, const int32_t* seg, int64_t n_species,
-                          const float* wp, int64_t w_stride, const int32_t* items, int64_t n_items, int64_t d_out,
+                          const float* wp, int64_t w_stride, const int32_t* segs, int64_t n_segs, int64_t d_out,
                           const float* add, int64_t n_rows, float* out, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

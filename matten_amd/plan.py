@@ -246,7 +246,7 @@ class LinearPlan:
     w_stride: int                 # packed floats per species
     gather: np.ndarray            # int64 [n_species, w_stride]: packed <- flat parameter index
     scale: np.ndarray             # f32 [w_stride]: path normalisation
-    passes: List[np.ndarray]      # each int32 [n_items, 8] item table (matten_species_linear); pass p>0 accumulates
+    passes: List[np.ndarray]      # each int32 [n_segs, 8] segment table (matten_species_linear); pass p>0 accumulates
     fully_covered: bool = True    # False: some output irreps have no input path and must be zero-filled
     d_in: int = 0
     d_out: int = 0
@@ -281,20 +281,15 @@ def _plan_linear_like(irreps_in: Irreps, irreps_out: Irreps, n_species: int, pat
     n_pass = max([len(v) for v in per_out.values()] + [1])
     passes = []
     for ps in range(n_pass):
-        items = []
+        segs = []
         for i_out, lst in per_out.items():
             if ps >= len(lst):
                 continue
             i_in, pk = lst[ps]
             mi, mo = irreps_in[i_in].mul, irreps_out[i_out].mul
             d = irreps_out[i_out].ir.dim
-            for k in range(d):
-                for nt in range(-(-mo // 16)):
-                    items.append((x_offs[i_in] + k, d, mi, pk + 16 * nt, mo, min(16, mo - 16 * nt),
-                                  o_offs[i_out] + 16 * nt * d + k, d))
-        # heavy items first: better tail balance when waves stride through (row tile, item) pairs
-        items.sort(key=lambda t: -t[2])
-        passes.append(np.array(items, dtype=np.int32).reshape(-1, 8))
+            segs.append((x_offs[i_in], d, mi, pk, mo, o_offs[i_out], 0, 0))
+        passes.append(np.array(segs, dtype=np.int32).reshape(-1, 8))
     fully_covered = all(i in per_out for i in range(len(irreps_out)) if irreps_out[i].dim > 0)
     gather = np.concatenate(gather_cols, axis=1) if gather_cols else np.zeros((n_species, 0), dtype=np.int64)
     scale = np.concatenate(scale_cols) if scale_cols else np.zeros(0, dtype=np.float32)
