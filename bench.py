@@ -168,13 +168,13 @@ def main():
             bytes_per_launch = algorithmic_bytes_tp_kernel(last, deg) * n_edges
             achieved = bytes_per_launch / dur_s / 1e9
             result["roofline"] = {
-                "kernel": "tp_block_kernel (conv_layer_last: 103 paths, d_mid 4170)",
+                "kernel": "tp_fused_kernel (conv_layer_last: radial GEMM + 103 CG paths + neighbour sum, d_mid 4170)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK / 1e9),
-                "traffic": _pmc_traffic("tp_block_kernel"),
+                "traffic": _pmc_traffic("tp_fused_kernel"),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": per_kernel[key],
             }
