@@ -211,6 +211,49 @@ int matten_segment_reduce(const float* x, int64_t dim, const int64_t* ptr, int64
 int matten_dense_rows(const float* x, int64_t n_in, const float* q, int64_t n_out, int64_t n_rows, float* out,
                       matten_stream_t stream);
 
+
+/* ==========================================================================================
+ * Adjoint (backward) operators for the training step (reference: autograd through
+ * model/model.py:276-372 shared_step -> loss.backward()).  fp32.
+ * ========================================================================================== */
+
+/* adjoint of matten_tp_paths / matten_tp_scatter (w_edge in the reference column order):
+ *   dw[e,q]              = norm * sum_ijk C_ijk x[src,x_base+i] Y[e,y_off+j] G[dst,out_base+k]
+ *   dx[src, x_base + i] += norm * w[e,q] * sum_jk C_ijk Y[e,y_off+j] G[dst,out_base+k]     (dx zero-initialised)
+ *   col_meta[n_cols,4] int32 {x_base, out_base, nnz_begin, nnz_count | y_off<<16}; nnz_ijk[nnz,4] uint8 {i,j,k,0};
+ *   nnz_c[nnz] = sqrt(2 l3+1) C_ijk */
+int matten_tp_backward(const float* x, int64_t d_in, const float* w_edge, int64_t w_ld, const float* sh_sorted,
+                       int64_t sh_stride, const int32_t* src_sorted, const int32_t* dst_sorted,
+                       const int32_t* col_meta, int64_t n_cols, const uint8_t* nnz_ijk, const float* nnz_c,
+                       const float* g_agg, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
+                       int64_t n_edges, float* dx, float* dw, int64_t dw_ld, matten_stream_t stream);
+
+/* adjoint of matten_species_linear w.r.t. the packed weights (the adjoint w.r.t. x is matten_species_linear
+ * itself with the transposed segment table and transposed packed weights):
+ *   dWp[s, w_off + u*mo + w] = sum_{rows n of species s} sum_k x[n, x_off+u*d+k] dy[n, o_off+w*d+k] */
+int matten_species_linear_wgrad(const float* x, int64_t d_in, const float* dy, int64_t d_out, const int32_t* order,
+                                const int32_t* seg, int64_t n_species, int64_t n_rows, const int32_t* segs,
+                                int64_t n_segs, int64_t w_stride, float* dwp, matten_stream_t stream);
+
+/* adjoint of the Gate part of matten_gate_bn (bn_weight == NULL forward); dx zero-initialised */
+int matten_gate_bwd(const float* x, int64_t d_in, const int32_t* meta, int64_t d_out, const float* act_cst,
+                    const float* dy, int64_t n_rows, float* dx, matten_stream_t stream);
+
+/* e3nn BatchNorm in training mode (batch statistics over all rows; reference nn/utils.py:418,432-433):
+ *   chan[n_chan,4] int32 {column offset, 2l+1, is_0e, index into bias / running_mean or -1}; col2chan[dim]
+ *   fwd: mean[c] (0e only, else 0), nu[c] = mean_n mean_k (x-mean)^2, y = (x-mean) rsqrt(nu+eps) weight[c] (+ bias)
+ *   bwd: dx (A, B are [n_chan] scratch that return sum dy (x-mean) and sum dy: dweight = A rsqrt(nu+eps), dbias = B) */
+int matten_bn_train_fwd(const float* x, int64_t dim, int64_t n_rows, const int32_t* col2chan, const int32_t* chan,
+                        int64_t n_chan, const float* weight, const float* bias, float eps, float* mean, float* nu,
+                        float* y, matten_stream_t stream);
+int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows, const int32_t* col2chan,
+                        const int32_t* chan, int64_t n_chan, const float* mean, const float* nu, const float* weight,
+                        float eps, float* A, float* B, float* dx, matten_stream_t stream);
+
+/* adjoint of matten_segment_reduce */
+int matten_segment_reduce_bwd(const float* dy, int64_t dim, const int64_t* ptr, int64_t n_segments, int mean, float* dx,
+                              matten_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

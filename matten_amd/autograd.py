@@ -1,0 +1,127 @@
+"""
+torch.autograd bindings of the HIP operators for the training step.
+
+The reference trains by autograd through e3nn's einsums and torch_scatter (model/model.py:276-372).  Here
+each operator's adjoint is a hand-written kernel (matten_amd/csrc/backward.hip); autograd only chains them
+and carries the cheap differentiable re-packings of the parameters (index + scale).  Two pieces of the
+training step are plain dense algebra and go through the library GEMM (rocBLAS via torch.mm), exactly what
+the design rules reserve libraries for: the radial MLP (three bias-free GEMMs over the edges) and the
+16-wide species embedding.
+"""
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class SpeciesLinearFn(torch.autograd.Function):
+    """out = add + x W_species  (matten_species_linear); adjoints: same kernel with W^T, and the weight-gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, x, wp, add, mod, species_order):
+        plan, dev = mod.plan, x.device
+        segs = [mod._tables.get(f"meta{i}", dev) for i in range(len(plan.passes))]
+        ctx.mod, ctx.species_order = mod, species_order
+        ctx.save_for_backward(x, wp)
+        ctx.has_add = add is not None
+        return ops.species_linear(x, species_order, wp, plan.w_stride, segs, plan.d_out, add, plan.fully_covered)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wp = ctx.saved_tensors
+        mod, plan, dev = ctx.mod, ctx.mod.plan, g.device
+        g = g.contiguous()
+        dx = dwp = None
+        if ctx.needs_input_grad[0]:
+            segs_t = [mod._tables.get(f"meta_t{i}", dev) for i in range(len(plan.passes_t))]
+            wp2 = wp.reshape(-1, plan.w_stride)
+            wpt = wp2[:, mod._tables.get("perm_t", dev)].contiguous()
+            dx = ops.species_linear(g, ctx.species_order, wpt, plan.w_stride, segs_t, plan.d_in, None,
+                                    plan.input_covered)
+        if ctx.needs_input_grad[1]:
+            segs = [mod._tables.get(f"meta{i}", dev) for i in range(len(plan.passes))]
+            n_species = wp.shape[0] if wp.dim() == 2 else 1
+            dwp = ops.species_linear_wgrad(x, g, ctx.species_order, n_species, segs, plan.w_stride).reshape(wp.shape)
+        return dx, dwp, (g if ctx.has_add else None), None, None
+
+
+class TensorProductScatterFn(torch.autograd.Function):
+    """agg = sum_{edges -> n} uvu(x[src], Y, w) * norm   with w[E,W] in the reference column order."""
+
+    @staticmethod
+    def forward(ctx, x, w_edge, mod, data, avg, num_neigh):
+        from .data.irreps import DataKey
+
+        dev = x.device
+        p = mod.plan
+        ctx.mod, ctx.avg, ctx.num_neigh = mod, avg, num_neigh
+        ctx.graph = (data[DataKey.AMD_SH], data[DataKey.AMD_SRC], data["_amd_dst_sorted"])
+        ctx.save_for_backward(x, w_edge)
+        return ops.tp_paths(x, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
+                            mod._tables.get("entries", dev), mod._tables.get("unit_start", dev), p.units_per_tile,
+                            p.d_mid, avg, num_neigh)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w_edge = ctx.saved_tensors
+        mod, dev = ctx.mod, g.device
+        sh, src, dst = ctx.graph
+        dx, dw = ops.tp_backward(x, w_edge, sh, src, dst, mod._tables.get("bw_col_meta", dev),
+                                 mod._tables.get("bw_nnz_ijk", dev), mod._tables.get("bw_nnz_c", dev), g.contiguous(),
+                                 ctx.avg, ctx.num_neigh)
+        return dx, dw, None, None, None, None
+
+
+class GateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod):
+        dev = x.device
+        ctx.mod = mod
+        ctx.save_for_backward(x)
+        return ops.gate_bn(x, mod._tables.get("meta", dev), mod._tables.get("act_cst", dev))
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        mod, dev = ctx.mod, g.device
+        return ops.gate_bwd(x, mod._tables.get("meta", dev), mod._tables.get("act_cst", dev), g.contiguous()), None
+
+
+class BatchNormTrainFn(torch.autograd.Function):
+    """e3nn BatchNorm with batch statistics; returns (y, mean, nu) so the caller can update the running stats."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn):
+        dev = x.device
+        y, mean, nu = ops.bn_train_fwd(x, bn._tables.get("col2chan", dev), bn._tables.get("chan", dev), weight, bias,
+                                       bn.eps)
+        ctx.bn = bn
+        ctx.save_for_backward(x, weight, mean, nu)
+        ctx.mark_non_differentiable(mean, nu)
+        return y, mean, nu
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gn):
+        x, weight, mean, nu = ctx.saved_tensors
+        bn, dev = ctx.bn, g.device
+        dx, A, B = ops.bn_train_bwd(x, g.contiguous(), bn._tables.get("col2chan", dev), bn._tables.get("chan", dev),
+                                    mean, nu, weight, bn.eps)
+        dweight = A * torch.rsqrt(nu + bn.eps)
+        dbias = B[bn._tables.get("scalar_chan", dev)]
+        return dx, dweight, dbias, None
+
+
+class SegmentReduceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ptr, mean):
+        ctx.ptr, ctx.mean, ctx.n = ptr, mean, x.shape[0]
+        return ops.segment_reduce(x, ptr, mean)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.segment_reduce_bwd(g.contiguous(), ctx.ptr, ctx.n, ctx.mean), None, None
+
+
+def needs_grad(*tensors: Optional[torch.Tensor]) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

@@ -1,0 +1,358 @@
+// Backward kernels of the conv stack (training step).
+// The reference gets these from autograd through e3nn's einsums and torch_scatter (model/model.py:276-372);
+// here each forward operator has a hand-written adjoint.  Training graphs are small (batch 32 crystals,
+// ~150 nodes, ~4.5 k edges), so these kernels favour simplicity: one thread per output element or per
+// (edge, channel), atomics only where contributions genuinely collide (gather adjoints).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// 'uvu' TP + gather + scatter, adjoint.  forward (per sorted edge e, weight column q = (path p, u)):
+//   agg[dst, out_base + k] += norm(dst) * w[e,q] * sum_ij C_ijk x[src, x_base + i] Y[e, y_off + j]
+// backward given G = d agg:
+//   dw[e,q]              = norm * sum_{ijk} C_ijk x_i Y_j G[dst, out_base + k]
+//   dx[src, x_base + i] += norm * w[e,q] * sum_{jk} C_ijk Y_j G[dst, out_base + k]      (atomic: many edges per src)
+// col_meta[W,4]  = {x_base, out_base, nnz_begin, nnz_count | y_off << 16}
+// nnz_ijk[nnz,4] = {i, j, k, 0} (uint8), nnz_c[nnz] = sqrt(2 l3+1) C_ijk
+// ------------------------------------------------------------------------------------------------
+__global__ void tp_backward_kernel(const float* __restrict__ x, int d_in, const float* __restrict__ w_edge, int w_ld,
+                                   const float* __restrict__ sh, int sh_stride, const int32_t* __restrict__ src_sorted,
+                                   const int32_t* __restrict__ dst_sorted, const int4* __restrict__ col_meta, int W,
+                                   const uchar4* __restrict__ nnz_ijk, const float* __restrict__ nnz_c,
+                                   const float* __restrict__ g_agg, int d_mid, float avg_nn,
+                                   const float* __restrict__ num_neigh, int64_t E, float* __restrict__ dx,
+                                   float* __restrict__ dw, int dw_ld) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * W) return;
+    const int64_t e = idx / W;
+    const int q = (int)(idx - e * W);
+    const int4 m = col_meta[q];
+    const int cnt = m.w & 0xffff, y_off = m.w >> 16;
+    const int src = src_sorted[e], dst = dst_sorted[e];
+    const float norm = 1.0f / sqrtf(avg_nn > 0.0f ? avg_nn : num_neigh[dst]);
+    const float* xp = x + (int64_t)src * d_in + m.x;
+    const float* yp = sh + e * sh_stride + y_off;
+    const float* gp = g_agg + (int64_t)dst * d_mid + m.y;
+    const float wv = w_edge[e * w_ld + q];
+    float dwv = 0.0f;
+    float dxi[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dxi[i] = 0.0f;
+    for (int t = 0; t < cnt; ++t) {
+        const uchar4 ijk = nnz_ijk[m.z + t];
+        const float c = nnz_c[m.z + t];
+        const float yg = c * yp[ijk.y] * gp[ijk.z];
+        dwv = fmaf(yg, xp[ijk.x], dwv);
+        // static-index scatter into the per-lane array
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            if (i == ijk.x) dxi[i] += yg;
+    }
+    dw[e * dw_ld + q] = dwv * norm;
+    float* dxp = dx + (int64_t)src * d_in + m.x;
+    const float s = wv * norm;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        if (dxi[i] != 0.0f) atomicAdd(dxp + i, s * dxi[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// species linear, weight gradient:  dWp[s, w_off + u*mo + w] = sum_{rows n of species s} sum_k x[n, x_off+u*d+k] dY[n, o_off+w*d+k]
+// grid = (n_species, n_segs); threads stride over (u, w) pairs, loop over the species' rows.
+// ------------------------------------------------------------------------------------------------
+struct LinSeg {
+    int x_off, d, mul_in, w_off, mo, o_off, pad0, pad1;
+};
+
+__global__ void species_linear_wgrad_kernel(const float* __restrict__ x, int d_in, const float* __restrict__ dy,
+                                            int d_out, const int32_t* __restrict__ order,
+                                            const int32_t* __restrict__ seg, int n_rows,
+                                            const LinSeg* __restrict__ segs, int w_stride,
+                                            float* __restrict__ dwp) {
+    const int s = blockIdx.x;
+    const LinSeg L = segs[blockIdx.y];
+    const int lo = seg ? seg[s] : 0, hi = seg ? seg[s + 1] : n_rows;
+    for (int p = threadIdx.x; p < L.mul_in * L.mo; p += blockDim.x) {
+        const int u = p / L.mo, w = p - u * L.mo;
+        float a = 0.0f;
+        for (int r = lo; r < hi; ++r) {
+            const int n = order ? order[r] : r;
+            const float* xp = x + (int64_t)n * d_in + L.x_off + u * L.d;
+            const float* gp = dy + (int64_t)n * d_out + L.o_off + w * L.d;
+            for (int k = 0; k < L.d; ++k) a = fmaf(xp[k], gp[k], a);
+        }
+        dwp[(int64_t)s * w_stride + L.w_off + p] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gate, adjoint (forward: node.hip gate_bn_kernel without BatchNorm)
+// meta[d_out] int4 {src, gate(-1: scalar), act | gate_act<<8, unused}
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float act_f(int code, float v) {
+    switch (code) {
+        case 1: return v * sigmoidf_(v);
+        case 2: return tanhf(v);
+        case 3: return sigmoidf_(v);
+        case 4: return (v > 20.0f ? v : log1pf(expf(v))) - 0.6931471805599453f;
+        case 5: return fabsf(v);
+        default: return v;
+    }
+}
+__device__ __forceinline__ float act_df(int code, float v) {
+    switch (code) {
+        case 1: { float s = sigmoidf_(v); return s * (1.0f + v * (1.0f - s)); }
+        case 2: { float t = tanhf(v); return 1.0f - t * t; }
+        case 3: { float s = sigmoidf_(v); return s * (1.0f - s); }
+        case 4: return sigmoidf_(v);
+        case 5: return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+        default: return 1.0f;
+    }
+}
+
+__global__ void gate_bwd_kernel(const float* __restrict__ x, int d_in, const int4* __restrict__ meta, int d_out,
+                                const float* __restrict__ act_cst, const float* __restrict__ dy, int64_t n_rows,
+                                float* __restrict__ dx) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * d_out) return;
+    int64_t n = idx / d_out;
+    int o = (int)(idx - n * d_out);
+    int4 m = meta[o];
+    const float* xr = x + n * d_in;
+    float* dxr = dx + n * d_in;
+    const float g = dy[idx];
+    const int act = m.z & 0xff, gact = (m.z >> 8) & 0xff;
+    if (m.y < 0) {
+        const float v = xr[m.x];
+        dxr[m.x] = act ? g * act_df(act, v) * act_cst[act] : g;  // one output per scalar input: plain store
+    } else {
+        const float v = xr[m.x], gt = xr[m.y];
+        const float a = gact ? act_f(gact, gt) * act_cst[gact] : gt;
+        const float da = gact ? act_df(gact, gt) * act_cst[gact] : 1.0f;
+        dxr[m.x] = g * a;
+        atomicAdd(dxr + m.y, g * v * da);  // 2l+1 components share one gate
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// e3nn BatchNorm, training mode (reference nn/utils.py:418 -> e3nn BatchNorm.forward with self.training).
+// Channel c = one multiplicity index of one irrep block (d components, offset off[c]); 0e channels are
+// centred.  stats: mean[c] (0 for non-scalars), nu[c] = mean_n mean_k (x - mean)^2.
+// chan[C] int4 {offset, d, is_scalar, mean_idx(-1)}
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_stats_kernel(const float* __restrict__ x, int dim, int64_t n_rows, const int4* __restrict__ chan,
+                                float* __restrict__ mean, float* __restrict__ nu) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    const int4 ch = chan[c];
+    const int d = ch.y;
+    float s = 0.0f;
+    if (ch.z) {
+        for (int64_t n = threadIdx.x; n < n_rows; n += blockDim.x) s += x[n * dim + ch.x];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        s = red[0] / (float)n_rows;
+        __syncthreads();
+    }
+    const float mu = ch.z ? s : 0.0f;
+    float q = 0.0f;
+    for (int64_t n = threadIdx.x; n < n_rows; n += blockDim.x)
+        for (int k = 0; k < d; ++k) {
+            float v = x[n * dim + ch.x + k] - mu;
+            q = fmaf(v, v, q);
+        }
+    red[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        mean[c] = mu;
+        nu[c] = red[0] / ((float)n_rows * (float)d);
+    }
+}
+
+// y = (x - mean) * rsqrt(nu + eps) * weight + bias(0e only)
+__global__ void bn_apply_kernel(const float* __restrict__ x, int dim, int64_t n_rows, const int32_t* __restrict__ col2chan,
+                                const int4* __restrict__ chan, const float* __restrict__ mean,
+                                const float* __restrict__ nu, const float* __restrict__ weight,
+                                const float* __restrict__ bias, float eps, float* __restrict__ y) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * dim) return;
+    const int col = (int)(idx % dim);
+    const int c = col2chan[col];
+    const int4 ch = chan[c];
+    float v = (x[idx] - mean[c]) * rsqrtf(nu[c] + eps) * weight[c];
+    if (ch.z) v += bias[ch.w];
+    y[idx] = v;
+}
+
+// reductions of the adjoint: A[c] = sum dy (x - mean), B[c] = sum dy   (over rows and components)
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, int dim, int64_t n_rows,
+                                     const int4* __restrict__ chan, const float* __restrict__ mean,
+                                     float* __restrict__ A, float* __restrict__ B) {
+    __shared__ float ra[256], rb[256];
+    const int c = blockIdx.x;
+    const int4 ch = chan[c];
+    const float mu = mean[c];
+    float a = 0.0f, b = 0.0f;
+    for (int64_t n = threadIdx.x; n < n_rows; n += blockDim.x)
+        for (int k = 0; k < ch.y; ++k) {
+            const float g = dy[n * dim + ch.x + k];
+            a = fmaf(g, x[n * dim + ch.x + k] - mu, a);
+            b += g;
+        }
+    ra[threadIdx.x] = a;
+    rb[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            ra[threadIdx.x] += ra[threadIdx.x + o];
+            rb[threadIdx.x] += rb[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        A[c] = ra[0];
+        B[c] = rb[0];
+    }
+}
+
+// dx = weight * s * [ dy - (x-mean) * s^2 * A/(N d) - (0e ? B/N : 0) ],  s = rsqrt(nu+eps)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, int dim, int64_t n_rows,
+                                    const int32_t* __restrict__ col2chan, const int4* __restrict__ chan,
+                                    const float* __restrict__ mean, const float* __restrict__ nu,
+                                    const float* __restrict__ weight, const float* __restrict__ A,
+                                    const float* __restrict__ B, float eps, float* __restrict__ dx) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * dim) return;
+    const int col = (int)(idx % dim);
+    const int c = col2chan[col];
+    const int4 ch = chan[c];
+    const float s = rsqrtf(nu[c] + eps);
+    const float nd = (float)n_rows * (float)ch.y;
+    float v = dy[idx] - (x[idx] - mean[c]) * s * s * A[c] / nd;
+    if (ch.z) v -= B[c] / (float)n_rows;
+    dx[idx] = weight[c] * s * v;
+}
+
+// NodewiseReduce adjoint: dx[n,:] = dy[batch(n),:] / (mean ? max(count,1) : 1)
+__global__ void segment_reduce_bwd_kernel(const float* __restrict__ dy, int dim, const int64_t* __restrict__ ptr,
+                                          int64_t n_seg, int mean, float* __restrict__ dx) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_seg * dim) return;
+    const int64_t b = idx / dim;
+    const int c = (int)(idx - b * dim);
+    const int64_t beg = ptr[b], end = ptr[b + 1];
+    float g = dy[idx];
+    if (mean) {
+        float cnt = (float)(end - beg);
+        g /= (cnt < 1.0f ? 1.0f : cnt);
+    }
+    for (int64_t n = beg; n < end; ++n) dx[n * dim + c] = g;
+}
+
+}  // namespace
+
+extern "C" int matten_tp_backward(const float* x, int64_t d_in, const float* w_edge, int64_t w_ld, const float* sh_sorted,
+                                  int64_t sh_stride, const int32_t* src_sorted, const int32_t* dst_sorted,
+                                  const int32_t* col_meta, int64_t n_cols, const uint8_t* nnz_ijk, const float* nnz_c,
+                                  const float* g_agg, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
+                                  int64_t n_edges, float* dx /*zero-initialised [N,d_in]*/, float* dw, int64_t dw_ld,
+                                  matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_edges < 0 || d_in <= 0 || n_cols <= 0 || d_mid <= 0 || w_ld < n_cols || dw_ld < n_cols) return MATTEN_EINVAL;
+    if (n_edges == 0) return MATTEN_OK;
+    if (!x || !w_edge || !sh_sorted || !src_sorted || !dst_sorted || !col_meta || !nnz_ijk || !nnz_c || !g_agg || !dx || !dw)
+        return MATTEN_EINVAL;
+    if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
+    const int T = 256;
+    tp_backward_kernel<<<(unsigned)matten_cdiv(n_edges * n_cols, T), T, 0, stream>>>(
+        x, (int)d_in, w_edge, (int)w_ld, sh_sorted, (int)sh_stride, src_sorted, dst_sorted, (const int4*)col_meta,
+        (int)n_cols, (const uchar4*)nnz_ijk, nnz_c, g_agg, (int)d_mid, avg_num_neighbors, num_neigh, n_edges, dx, dw,
+        (int)dw_ld);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_species_linear_wgrad(const float* x, int64_t d_in, const float* dy, int64_t d_out,
+                                           const int32_t* order, const int32_t* seg, int64_t n_species, int64_t n_rows,
+                                           const int32_t* segs, int64_t n_segs, int64_t w_stride, float* dwp,
+                                           matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows < 0 || d_in <= 0 || d_out <= 0 || n_species <= 0 || n_segs < 0 || w_stride < 0) return MATTEN_EINVAL;
+    if (n_segs == 0 || w_stride == 0) return MATTEN_OK;
+    if (!x || !dy || !segs || !dwp) return MATTEN_EINVAL;
+    if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
+    if (!order && n_species != 1) return MATTEN_EINVAL;
+    dim3 grid((unsigned)n_species, (unsigned)n_segs);
+    species_linear_wgrad_kernel<<<grid, 256, 0, stream>>>(x, (int)d_in, dy, (int)d_out, order, seg, (int)n_rows,
+                                                          (const LinSeg*)segs, (int)w_stride, dwp);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_gate_bwd(const float* x, int64_t d_in, const int32_t* meta, int64_t d_out, const float* act_cst,
+                               const float* dy, int64_t n_rows, float* dx /*zero-initialised*/, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows < 0 || d_in <= 0 || d_out <= 0) return MATTEN_EINVAL;
+    if (n_rows == 0) return MATTEN_OK;
+    if (!x || !meta || !act_cst || !dy || !dx) return MATTEN_EINVAL;
+    const int T = 256;
+    gate_bwd_kernel<<<(unsigned)matten_cdiv(n_rows * d_out, T), T, 0, stream>>>(x, (int)d_in, (const int4*)meta,
+                                                                                (int)d_out, act_cst, dy, n_rows, dx);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_bn_train_fwd(const float* x, int64_t dim, int64_t n_rows, const int32_t* col2chan,
+                                   const int32_t* chan, int64_t n_chan, const float* weight, const float* bias,
+                                   float eps, float* mean, float* nu, float* y, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows <= 0 || dim <= 0 || n_chan <= 0) return MATTEN_EINVAL;
+    if (!x || !col2chan || !chan || !weight || !bias || !mean || !nu || !y) return MATTEN_EINVAL;
+    bn_stats_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, (int)dim, n_rows, (const int4*)chan, mean, nu);
+    MATTEN_LAUNCH_CHECK();
+    const int T = 256;
+    bn_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(x, (int)dim, n_rows, col2chan,
+                                                                              (const int4*)chan, mean, nu, weight, bias,
+                                                                              eps, y);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows,
+                                   const int32_t* col2chan, const int32_t* chan, int64_t n_chan, const float* mean,
+                                   const float* nu, const float* weight, float eps, float* A, float* B, float* dx,
+                                   matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows <= 0 || dim <= 0 || n_chan <= 0) return MATTEN_EINVAL;
+    if (!x || !dy || !col2chan || !chan || !mean || !nu || !weight || !A || !B || !dx) return MATTEN_EINVAL;
+    bn_bwd_reduce_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, dy, (int)dim, n_rows, (const int4*)chan, mean, A, B);
+    MATTEN_LAUNCH_CHECK();
+    const int T = 256;
+    bn_bwd_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(
+        x, dy, (int)dim, n_rows, col2chan, (const int4*)chan, mean, nu, weight, A, B, eps, dx);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_segment_reduce_bwd(const float* dy, int64_t dim, const int64_t* ptr, int64_t n_segments, int mean,
+                                         float* dx, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_segments < 0 || dim <= 0) return MATTEN_EINVAL;
+    if (n_segments == 0) return MATTEN_OK;
+    if (!dy || !ptr || !dx) return MATTEN_EINVAL;
+    const int T = 256;
+    segment_reduce_bwd_kernel<<<(unsigned)matten_cdiv(n_segments * dim, T), T, 0, stream>>>(dy, (int)dim, ptr,
+                                                                                            n_segments, mean, dx);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}

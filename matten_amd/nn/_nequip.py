@@ -68,6 +68,17 @@ def ensure_edge_geometry(data: DataKey.Type, lmax: int = None, want_vectors=Fals
     return data
 
 
+def ensure_training_edge_tensors(data: DataKey.Type) -> DataKey.Type:
+    """Extra per-edge tensors the adjoint kernels / the library-GEMM radial MLP need (built once per batch):
+    Bessel embedding and destination ids in destination-sorted order."""
+    if "_amd_emb_sorted" not in data:
+        ensure_edge_geometry(data, want_embedding=True)
+        perm = data[DataKey.AMD_PERM].long()
+        data["_amd_emb_sorted"] = data[DataKey.EDGE_EMBEDDING][perm].contiguous()
+        data["_amd_dst_sorted"] = data[DataKey.EDGE_INDEX][1][perm].to(torch.int32).contiguous()
+    return data
+
+
 def with_edge_vectors(data: DataKey.Type, with_lengths: bool = True) -> DataKey.Type:
     return ensure_edge_geometry(data, want_vectors=True, want_lengths=with_lengths)
 

@@ -125,6 +125,9 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
         data[DataKey.AMD_SPECIES] = (order, seg)
         if attrs is not None:
             data[DataKey.NODE_ATTRS] = attrs
+        if torch.is_grad_enabled() and self.linear.weight.requires_grad:
+            # training path: Linear(one_hot) == column lookup + bias (library indexing, differentiable)
+            feats = self.linear.weight.t()[sidx.clamp(min=0)] + self.linear.bias
         data[DataKey.NODE_FEATURES] = feats
         return data
 

@@ -48,5 +48,11 @@ class NodewiseReduce(ModuleIrreps, torch.nn.Module):
             counts = torch.bincount(batch)
             ptr = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=batch.device)
             ptr[1:] = torch.cumsum(counts, 0)
-        data[self.out_field] = ops.segment_reduce(data[self.field], ptr, self.reduce == "mean")
+        x = data[self.field]
+        if torch.is_grad_enabled() and x.requires_grad:
+            from ..autograd import SegmentReduceFn
+
+            data[self.out_field] = SegmentReduceFn.apply(x, ptr, self.reduce == "mean")
+        else:
+            data[self.out_field] = ops.segment_reduce(x, ptr, self.reduce == "mean")
         return data

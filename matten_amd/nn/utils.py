@@ -14,9 +14,11 @@ Parameters keep the reference's names, shapes and flat layouts (SURVEY.md App. C
 import os
 from typing import Callable, Dict, List, Optional
 
+import numpy as np
 import torch
 from torch import Tensor
 
+from .. import autograd as _ag
 from .. import ops, plan as _plan
 from ..data.irreps import DataKey
 from ..o3 import Irrep, Irreps
@@ -42,7 +44,9 @@ class SpeciesLinear(torch.nn.Module):
         self.n_species = n_species
         self.weight = torch.nn.Parameter(torch.randn(self.plan.weight_numel))
         self._tables = DeviceTables(
-            gather=self.plan.gather, scale=self.plan.scale, **{f"meta{i}": m for i, m in enumerate(self.plan.passes)}
+            gather=self.plan.gather, scale=self.plan.scale, perm_t=self.plan.perm_t,
+            **{f"meta{i}": m for i, m in enumerate(self.plan.passes)},
+            **{f"meta_t{i}": m for i, m in enumerate(self.plan.passes_t)},
         )
         self._packed = DerivedWeight(self._pack)
 
@@ -54,6 +58,11 @@ class SpeciesLinear(torch.nn.Module):
         """species_order = (order, seg): node ids sorted by species + per-species offsets (DataKey.AMD_SPECIES)."""
         if self.n_species is not None and species_order is None:
             raise ValueError("species order required")
+        order = species_order if self.n_species is not None else None
+        if _ag.needs_grad(x, self.weight, add):
+            # training path: the re-packing (index + scale) is differentiable, the linear is the HIP Function
+            wp = self._pack(self.weight)
+            return _ag.SpeciesLinearFn.apply(x, wp, add, self, order)
         wp = self._packed.get(self.weight)
         metas = [self._tables.get(f"meta{i}", x.device) for i in range(len(self.plan.passes))]
         return ops.species_linear(x, species_order if self.n_species is not None else None, wp, self.plan.w_stride,
@@ -107,6 +116,16 @@ class RadialMLP(torch.nn.Module):
         w0p, w1p, w2p = self._packed.get(self.layer0.weight, self.layer1.weight, self.layer2.weight)
         return ops.radial_mlp(geom_sorted, n_basis, r_start, r_end, w0p, w1p, w2p)
 
+    def forward_train(self, emb_sorted: Tensor) -> Tensor:
+        """w[E, W] in the reference column order through library GEMMs (rocBLAS), differentiable.
+        Same arithmetic as e3nn FullyConnectedNet: x <- c*silu(x @ W/sqrt(h_in)); last layer linear."""
+        x = emb_sorted
+        for i, layer in enumerate((self.layer0, self.layer1, self.layer2)):
+            x = x @ (layer.weight / self.hs[i] ** 0.5)
+            if i < 2:
+                x = torch.nn.functional.silu(x) * self.act_cst
+        return x.contiguous()
+
     def hidden(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float):
         """(h2p[E,32], w2p): the two hidden layers evaluated, the last layer left to the fused TP kernel."""
         if n_basis != self.hs[0]:
@@ -150,6 +169,7 @@ class UVUTensorProduct(torch.nn.Module):
             m_idx=self.plan.m_terms_idx, m_coef=self.plan.m_terms_coef, out_meta=self.plan.out_meta,
             entries=self.plan.path_entries, unit_start=self.plan.unit_start,
             gentries=self.plan.group_entries, gstart=self.plan.group_unit_start,
+            bw_col_meta=self.plan.bw_col_meta, bw_nnz_ijk=self.plan.bw_nnz_ijk, bw_nnz_c=self.plan.bw_nnz_c,
         )
 
     @property
@@ -162,6 +182,14 @@ class UVUTensorProduct(torch.nn.Module):
         dev = node_feats.device
         avg = avg_num_neighbors if avg_num_neighbors is not None else 0.0
         num_neigh = None if avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
+        if _ag.needs_grad(node_feats, *self.weight_nn.parameters()):
+            # training path: radial weights materialised in the reference layout (library GEMMs), the
+            # tensor product + neighbour sum and its adjoint are the HIP kernels
+            from ._nequip import ensure_training_edge_tensors
+
+            ensure_training_edge_tensors(data)
+            w_edge = self.weight_nn.forward_train(data["_amd_emb_sorted"])
+            return _ag.TensorProductScatterFn.apply(node_feats, w_edge, self, data, avg, num_neigh)
         if self.impl == "fused":
             h2p, w2p = self.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1)
             return ops.tp_fused(
@@ -229,7 +257,14 @@ class ActivationLayer(torch.nn.Module):
         dev = x.device
         bn = norm.n if (norm is not None and norm.n is not None) else None
         if bn is not None and bn.training:
-            raise NotImplementedError("BatchNorm in training mode: call model.eval() (inference path)")
+            # training: Gate, then BatchNorm with batch statistics (and the running-average update)
+            y = _ag.GateFn.apply(x, self) if x.requires_grad else ops.gate_bn(
+                x, self._tables.get("meta", dev), self._tables.get("act_cst", dev))
+            return bn.forward_train(y)
+        if _ag.needs_grad(x):
+            if bn is not None:
+                raise NotImplementedError("gradients through eval-mode BatchNorm: call model.train()")
+            return _ag.GateFn.apply(x, self)
         return ops.gate_bn(
             x, self._tables.get("meta", dev), self._tables.get("act_cst", dev),
             *((bn.running_mean, bn.running_var, bn.weight, bn.bias) if bn is not None else (None, None, None, None)),
@@ -250,6 +285,17 @@ class _IrrepBatchNorm(torch.nn.Module):
         self.register_buffer("running_var", torch.ones(n_feat))
         self.weight = torch.nn.Parameter(torch.ones(n_feat))
         self.bias = torch.nn.Parameter(torch.zeros(n_scalar))
+        chan, col2chan = _plan.plan_batchnorm(self.irreps)
+        self._tables = DeviceTables(chan=chan, col2chan=col2chan,
+                                    scalar_chan=np.nonzero(chan[:, 2])[0].astype(np.int64))
+
+    def forward_train(self, x: Tensor) -> Tensor:
+        y, mean, nu = _ag.BatchNormTrainFn.apply(x, self.weight, self.bias, self)
+        with torch.no_grad():  # e3nn: running = (1 - momentum) * running + momentum * batch
+            sc = self._tables.get("scalar_chan", x.device)
+            self.running_mean.mul_(1 - self.momentum).add_(self.momentum * mean[sc])
+            self.running_var.mul_(1 - self.momentum).add_(self.momentum * nu)
+        return y
 
 
 class NormalizationLayer(torch.nn.Module):

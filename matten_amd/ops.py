@@ -329,3 +329,91 @@ def dense_rows(x, q) -> torch.Tensor:
     _lib.check(lib.matten_dense_rows(_ptr(x), x.shape[1], _ptr(q), q.shape[1], x.shape[0], _ptr(out), _stream()),
                "matten_dense_rows")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# adjoint operators (training step)
+# ---------------------------------------------------------------------------------------------------
+def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk, nnz_c, g_agg,
+                avg_num_neighbors: float, num_neigh=None):
+    """-> (dx [N,d_in], dw [E,W]) for agg = tp(x, w_edge) with w_edge in the reference column order."""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    w_edge = _need(w_edge, torch.float32, "w_edge")
+    g_agg = _need(g_agg, torch.float32, "grad agg")
+    N, d_in = x.shape
+    E = w_edge.shape[0]
+    W = col_meta.shape[0]
+    dx = torch.zeros(N, d_in, dtype=torch.float32, device=x.device)
+    dw = torch.empty(E, W, dtype=torch.float32, device=x.device)
+    if num_neigh is not None:
+        num_neigh = _need(num_neigh, torch.float32, "num_neigh")
+    _lib.check(
+        lib.matten_tp_backward(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
+                               _ptr(src_sorted), _ptr(dst_sorted), _ptr(col_meta), W, _ptr(nnz_ijk), _ptr(nnz_c),
+                               _ptr(g_agg), g_agg.shape[1], float(avg_num_neighbors or 0.0), _ptr(num_neigh), E,
+                               _ptr(dx), _ptr(dw), W, _stream()),
+        "matten_tp_backward",
+    )
+    return dx, dw
+
+
+def species_linear_wgrad(x, dy, species_order, n_species: int, seg_tables, w_stride: int) -> torch.Tensor:
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    dy = _need(dy, torch.float32, "dy")
+    order, seg = species_order if species_order is not None else (None, None)
+    dwp = torch.zeros(n_species, w_stride, dtype=torch.float32, device=x.device)
+    for segs in seg_tables:
+        _lib.check(
+            lib.matten_species_linear_wgrad(_ptr(x), x.shape[1], _ptr(dy), dy.shape[1], _ptr(order), _ptr(seg),
+                                            n_species, x.shape[0], _ptr(segs), segs.shape[0], w_stride, _ptr(dwp),
+                                            _stream()),
+            "matten_species_linear_wgrad",
+        )
+    return dwp
+
+
+def gate_bwd(x, meta, act_cst, dy) -> torch.Tensor:
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    dy = _need(dy, torch.float32, "dy")
+    dx = torch.zeros_like(x)
+    _lib.check(lib.matten_gate_bwd(_ptr(x), x.shape[1], _ptr(meta), meta.shape[0], _ptr(act_cst), _ptr(dy), x.shape[0],
+                                   _ptr(dx), _stream()), "matten_gate_bwd")
+    return dx
+
+
+def bn_train_fwd(x, col2chan, chan, weight, bias, eps: float):
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    C = chan.shape[0]
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    nu = torch.empty(C, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    _lib.check(lib.matten_bn_train_fwd(_ptr(x), x.shape[1], x.shape[0], _ptr(col2chan), _ptr(chan), C, _ptr(weight),
+                                       _ptr(bias), eps, _ptr(mean), _ptr(nu), _ptr(y), _stream()), "matten_bn_train_fwd")
+    return y, mean, nu
+
+
+def bn_train_bwd(x, dy, col2chan, chan, mean, nu, weight, eps: float):
+    lib = _lib.load()
+    dy = _need(dy, torch.float32, "dy")
+    C = chan.shape[0]
+    A = torch.empty(C, dtype=torch.float32, device=x.device)
+    B = torch.empty(C, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    _lib.check(lib.matten_bn_train_bwd(_ptr(x), _ptr(dy), x.shape[1], x.shape[0], _ptr(col2chan), _ptr(chan), C,
+                                       _ptr(mean), _ptr(nu), _ptr(weight), eps, _ptr(A), _ptr(B), _ptr(dx), _stream()),
+               "matten_bn_train_bwd")
+    return dx, A, B
+
+
+def segment_reduce_bwd(dy, ptr, n_rows: int, mean: bool) -> torch.Tensor:
+    lib = _lib.load()
+    dy = _need(dy, torch.float32, "dy")
+    ptr = _need(ptr, torch.int64, "ptr")
+    dx = torch.zeros(n_rows, dy.shape[1], dtype=torch.float32, device=dy.device)
+    _lib.check(lib.matten_segment_reduce_bwd(_ptr(dy), dy.shape[1], _ptr(ptr), dy.shape[0], int(mean), _ptr(dx),
+                                             _stream()), "matten_segment_reduce_bwd")
+    return dx

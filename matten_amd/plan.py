@@ -93,6 +93,10 @@ class UVUPlan:
     group_units_per_tile: int = 0
     fused_cols: np.ndarray = None     # int64 [W_fused]: fused weight column -> reference weight column, -1 = zero
     fused_lds_floats_per_wave: int = 0  # LDS tile of matten_tp_fused
+    # adjoint tables (matten_tp_backward)
+    bw_col_meta: np.ndarray = None    # int32 [W, 4] {x_base, out_base, nnz_begin, nnz_count | y_off << 16}
+    bw_nnz_ijk: np.ndarray = None     # uint8 [nnz, 4]
+    bw_nnz_c: np.ndarray = None       # f32 [nnz]
 
 
 def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
@@ -222,7 +226,26 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                         fused_cols.append(present[key].w_off + u0 + uu if key in present else -1)
                 gentries.append(row)
                 gstart.append(gstart[-1] + -(-TP_TILE_NODES // nodes_per_wave))
+    # ---- adjoint tables: per weight column its path geometry and the non-zeros of its coupling tensor ----
+    nnz_begin: Dict[Tuple[int, int, int], Tuple[int, int]] = {}
+    nnz_ijk, nnz_c = [], []
+    col_meta = np.zeros((w_off, 4), dtype=np.int64)
+    for p in paths:
+        key = (p.l1, p.l2, p.l3)
+        if key not in nnz_begin:
+            C = wigner_3j(*key) * math.sqrt(2 * p.l3 + 1)
+            b0 = len(nnz_c)
+            for i, j, k in zip(*np.nonzero(np.abs(C) > 1e-12)):
+                nnz_ijk.append((i, j, k, 0))
+                nnz_c.append(C[i, j, k])
+            nnz_begin[key] = (b0, len(nnz_c) - b0)
+        b0, cnt = nnz_begin[key]
+        d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
+        for u in range(p.mul):
+            col_meta[p.w_off + u] = (p.x_off + u * d1, p.out_off + u * d3, b0, cnt | (sh_offs[p.l2] << 16))
     return UVUPlan(
+        bw_col_meta=col_meta.astype(np.int32), bw_nnz_ijk=np.array(nnz_ijk, dtype=np.uint8).reshape(-1, 4),
+        bw_nnz_c=np.array(nnz_c, dtype=np.float32),
         irreps_in1=irreps_in1, irreps_sh=irreps_sh, irreps_mid=irreps_mid, irreps_out=irreps_mid.simplify(),
         paths=paths, weight_numel=w_off, d_in=irreps_in1.dim, d_mid=d_mid, sh_dim=irreps_sh.dim,
         m_total=m_total, m_nterms=m_nterms, m_terms_idx=idx, m_terms_coef=coef, out_meta=meta, cg_nnz=cg_nnz,
@@ -248,6 +271,9 @@ class LinearPlan:
     scale: np.ndarray             # f32 [w_stride]: path normalisation
     passes: List[np.ndarray]      # each int32 [n_segs, 8] segment table (matten_species_linear); pass p>0 accumulates
     fully_covered: bool = True    # False: some output irreps have no input path and must be zero-filled
+    passes_t: List[np.ndarray] = None   # adjoint w.r.t. x: segment tables with input/output swapped
+    perm_t: np.ndarray = None           # int64 [w_stride]: packed^T index j -> packed index (W^T per path)
+    input_covered: bool = True          # False: some input irreps feed no output (their gradient is zero)
     d_in: int = 0
     d_out: int = 0
     flops_per_row: int = 0
@@ -291,10 +317,33 @@ def _plan_linear_like(irreps_in: Irreps, irreps_out: Irreps, n_species: int, pat
             segs.append((x_offs[i_in], d, mi, pk, mo, o_offs[i_out], 0, 0))
         passes.append(np.array(segs, dtype=np.int32).reshape(-1, 8))
     fully_covered = all(i in per_out for i in range(len(irreps_out)) if irreps_out[i].dim > 0)
+    # adjoint w.r.t. x: dX[x_off + u*d + k] = sum_w W[u,w] dY[o_off + w*d + k]  ==  the same operator with
+    # (x_off, mul_in) <-> (o_off, mo) and each path's weight block transposed
+    perm_t = np.zeros(packed, dtype=np.int64)
+    segs_t_by_pass: List[List[Tuple[int, ...]]] = []
+    used_inputs = set()
+    for i_out, lst in per_out.items():
+        for ps, (i_in, pk) in enumerate(lst):
+            mi, mo = irreps_in[i_in].mul, irreps_out[i_out].mul
+            d = irreps_out[i_out].ir.dim
+            uu, ww = np.meshgrid(np.arange(mi), np.arange(mo), indexing="ij")
+            perm_t[pk + ww * mi + uu] = pk + uu * mo + ww
+            # several outputs may read one input block: spread them over passes so every pass writes each x once
+            slot = 0
+            while True:
+                if slot == len(segs_t_by_pass):
+                    segs_t_by_pass.append([])
+                if all(sg[5] != x_offs[i_in] for sg in segs_t_by_pass[slot]):
+                    break
+                slot += 1
+            segs_t_by_pass[slot].append((o_offs[i_out], d, mo, pk, mi, x_offs[i_in], 0, 0))
+            used_inputs.add(i_in)
+    passes_t = [np.array(sg, dtype=np.int32).reshape(-1, 8) for sg in segs_t_by_pass]
+    input_covered = all(i in used_inputs for i in range(len(irreps_in)) if irreps_in[i].dim > 0)
     gather = np.concatenate(gather_cols, axis=1) if gather_cols else np.zeros((n_species, 0), dtype=np.int64)
     scale = np.concatenate(scale_cols) if scale_cols else np.zeros(0, dtype=np.float32)
     return LinearPlan(irreps_in, irreps_out, n_species, flat, packed, gather.astype(np.int64), scale, passes,
-                      fully_covered, irreps_in.dim, irreps_out.dim, flops)
+                      fully_covered, passes_t, perm_t, input_covered, irreps_in.dim, irreps_out.dim, flops)
 
 
 def plan_fctp(irreps_in1, n_species: int, irreps_out) -> LinearPlan:
@@ -419,3 +468,19 @@ def _scalar_out_parity(act_name: str, p_in: int) -> int:
     if pa == 0:
         raise ValueError(f"activation {act_name} on an odd scalar violates parity")
     return pa
+
+
+def plan_batchnorm(irreps) -> Tuple[np.ndarray, np.ndarray]:
+    """(chan[C,4] int32 {column offset, 2l+1, is_0e, bias/mean index or -1}, col2chan[dim] int32) of e3nn BatchNorm."""
+    irreps = Irreps(irreps)
+    chan, col2chan = [], []
+    off = 0
+    mi = 0
+    for mul, ir in irreps:
+        for _ in range(mul):
+            is0 = 1 if ir.is_scalar() else 0
+            chan.append((off, ir.dim, is0, mi if is0 else -1))
+            col2chan += [len(chan) - 1] * ir.dim
+            off += ir.dim
+            mi += is0
+    return np.array(chan, dtype=np.int32).reshape(-1, 4), np.array(col2chan, dtype=np.int32)

@@ -1,0 +1,104 @@
+"""
+Training step on the GPU (BASELINE.json configs[3] / SURVEY.md 8d config 4: lmax=2, 3 gated blocks,
+BatchNorm in training mode, MSE in irreps space, Adam) against the CPU oracle's autograd on identical
+crystals and weights: forward values, every parameter gradient, BatchNorm running statistics and the
+parameters after one Adam step.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import LMAX2, PAPER, build_pair
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(got, want, rtol, what):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(1e-12, want.abs().max().item())
+    err = (got - want).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def _graphs(golden_dir, n=10):
+    from matten_amd.data.graph import average_num_neighbors, crystal_graph
+    from oracle.matten_ref.data import structures_from_json
+
+    structs = structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))[:n]
+    graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
+    species = sorted({int(z) for s in structs for z in s["atomic_numbers"]})
+    return graphs, {"allowed_species": species, "average_num_neighbors": average_num_neighbors(graphs)}
+
+
+@pytest.mark.parametrize("hp_name", ["lmax2", "paper"])
+def test_training_step_matches_oracle_autograd(golden_dir, hp_name):
+    from matten_amd.data.graph import collate
+
+    hp = {"lmax2": LMAX2, "paper": PAPER}[hp_name]
+    graphs, ds = _graphs(golden_dir, 10 if hp_name == "lmax2" else 6)
+    ref, model = build_pair(hp, ds, randomize_bn=True)
+    ref.train()
+    model.train()
+    B = len(graphs)
+    target = torch.randn(B, 21, generator=torch.Generator().manual_seed(7))
+
+    # ---- oracle: forward, MSE, backward, Adam ----
+    opt_r = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=1e-5)
+    out_r = ref.decode(collate(graphs))
+    loss_r = torch.nn.functional.mse_loss(out_r, target)
+    opt_r.zero_grad()
+    loss_r.backward()
+    grads_r = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+
+    # ---- HIP path ----
+    opt_m = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=1e-5)
+    preds, _ = model(collate(graphs, device=DEV))
+    out_m = preds["elastic_tensor_full"]
+    loss_m = torch.nn.functional.mse_loss(out_m, target.to(DEV))
+    opt_m.zero_grad()
+    loss_m.backward()
+
+    _close(out_m, out_r, 5e-4, "train-mode forward [B,21]")
+    _close(loss_m, loss_r, 1e-4, "loss")
+    if hp_name == "lmax2":  # config 4: the 4e block of the head is unreachable and stays exactly zero
+        assert torch.all(out_m[:, 12:] == 0)
+    named = dict(model.named_parameters())
+    assert set(grads_r) <= set(named)
+    for k, g in grads_r.items():
+        assert named[k].grad is not None, k
+        _close(named[k].grad, g, 3e-3, f"grad {k}")
+    # BatchNorm running statistics after the forward
+    bufs_m = dict(model.named_buffers())
+    for k, b in ref.named_buffers():
+        if k.endswith(("running_mean", "running_var")):
+            _close(bufs_m[k], b, 1e-4, k)
+
+    opt_r.step()
+    opt_m.step()
+    for k, p in ref.named_parameters():
+        if p.grad is not None:
+            _close(named[k], p, 2e-3, f"param after Adam {k}")
+
+
+def test_eval_after_training_uses_running_stats(golden_dir):
+    """model.eval() after a training forward: the fused inference path agrees with the oracle again."""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _graphs(golden_dir, 6)
+    ref, model = build_pair(LMAX2, ds, randomize_bn=True)
+    ref.train()
+    model.train()
+    with torch.no_grad():
+        ref.decode(collate(graphs))
+        model(collate(graphs, device=DEV))
+    ref.eval()
+    model.eval()
+    with torch.no_grad():
+        want = ref.decode(collate(graphs))
+        got = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+    _close(got, want, 5e-4, "eval after train")
