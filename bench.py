@@ -68,7 +68,9 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    distributed = world > 1
+    # one process per GPU under torch.distributed.run; MATTEN_FORCE_DIST=1 exercises the RCCL path with a
+    # single rank too (init, barrier, all_gather) so it can be smoke-tested on a 1-GPU box
+    distributed = world > 1 or (os.environ.get("MATTEN_FORCE_DIST") == "1" and "RANK" in os.environ)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
