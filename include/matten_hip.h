@@ -254,6 +254,24 @@ int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim, int64_t n_
 int matten_segment_reduce_bwd(const float* dy, int64_t dim, const int64_t* ptr, int64_t n_segments, int mean, float* dx,
                               matten_stream_t stream);
 
+
+/* ==========================================================================================
+ * Graph construction on the GPU (replaces neighbor_list_and_relative_vec,
+ * data/data.py:285-413, i.e. ase.neighborlist.primitive_neighbor_list("ijS") + the self-edge filter).
+ *   edges = all (i, j, S): | pos[j] + S.cell - pos[i] | < r_cut (strict, fp64), (i==j, S==0) excluded,
+ *   emitted in lexicographic order (i, j, Sx, Sy, Sz); i, j are GLOBAL node ids (ptr-offset applied).
+ *   pos[N,3] fp64; cell[B,9] fp64 (rows = lattice vectors); ptr[B+1], batch[N] int64;
+ *   reach[B,3] int32 = number of periodic images to scan along each lattice direction.
+ * Two passes: matten_neighbor_count -> counts[N]; the caller scans them into offsets[N] (exclusive) and
+ * n_edges; matten_neighbor_fill writes edge_index[2,n_edges] (int64) and edge_cell_shift[n_edges,3] (fp32).
+ * ========================================================================================== */
+int matten_neighbor_count(const double* pos, const double* cell, const int64_t* ptr, const int32_t* reach,
+                          const int64_t* batch, double r_cut, int64_t n_nodes, int32_t* counts,
+                          matten_stream_t stream);
+int matten_neighbor_fill(const double* pos, const double* cell, const int64_t* ptr, const int32_t* reach,
+                         const int64_t* batch, double r_cut, int64_t n_nodes, const int64_t* offsets, int64_t n_edges,
+                         int64_t* edge_index, float* edge_cell_shift, matten_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

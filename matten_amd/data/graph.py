@@ -19,18 +19,24 @@ import torch
 from scipy.spatial import cKDTree
 
 
+def image_reach(pos: np.ndarray, cell: np.ndarray, r_cut: float) -> np.ndarray:
+    """Number of periodic images to scan along each lattice direction so that no pair within r_cut is missed:
+    cutoff over the lattice-plane spacing, plus the fractional extent of the atoms (they need not be wrapped)."""
+    recip = np.linalg.inv(cell).T  # rows: reciprocal vectors (without 2 pi)
+    plane_dist = 1.0 / np.linalg.norm(recip, axis=1)
+    frac = pos @ np.linalg.inv(cell)
+    span = frac.max(0) - frac.min(0) if len(pos) else np.zeros(3)
+    return np.ceil(float(r_cut) / plane_dist + span).astype(int)
+
+
 def neighbor_list(pos: np.ndarray, cell: np.ndarray, r_cut: float):
-    """-> edge_index [2,E] int64, shifts [E,3] int64 (canonical order)."""
+    """-> edge_index [2,E] int64, shifts [E,3] int64 (canonical order).  Host builder (scipy KD-tree); the
+    production path for batches is ``batch_graphs_gpu`` below, which emits the identical list on the device."""
     pos = np.asarray(pos, dtype=np.float64).reshape(-1, 3)
     cell = np.asarray(cell, dtype=np.float64).reshape(3, 3)
     n = pos.shape[0]
     rc = float(r_cut)
-    # number of periodic images needed along each lattice direction: distance between lattice planes
-    recip = np.linalg.inv(cell).T  # rows: reciprocal vectors (without 2 pi)
-    plane_dist = 1.0 / np.linalg.norm(recip, axis=1)
-    frac = pos @ np.linalg.inv(cell)
-    span = frac.max(0) - frac.min(0) if n else np.zeros(3)
-    reach = np.ceil(rc / plane_dist + span).astype(int)
+    reach = image_reach(pos, cell, rc)
 
     # candidate images: every lattice shift in the reach box; a KD-tree over the image atoms prunes
     # the pair search, the strict fp64 test below decides (same expression as the brute-force form)
@@ -96,3 +102,61 @@ def collate(graphs: Sequence[Dict[str, torch.Tensor]], device=None, pin: bool = 
 def average_num_neighbors(graphs: Sequence[Dict[str, torch.Tensor]]) -> float:
     """dataset statistic the reference derives in get_to_model_info (dataset/structure_scalar_tensor.py:640-666)."""
     return float(torch.cat([g["num_neigh"] for g in graphs]).mean())
+
+
+class EdgelessStructures(ValueError):
+    """Some crystals of a batch have no edge inside the cutoff; ``indices`` are their positions in the batch."""
+
+    def __init__(self, indices):
+        super().__init__(f"After eliminating self edges, no edges remain in this system (structures {list(indices)}).")
+        self.indices = list(indices)
+
+
+def batch_graphs_gpu(structures: Sequence, r_cut: float, device="cuda", y: Optional[Dict[str, torch.Tensor]] = None,
+                     ) -> Dict[str, torch.Tensor]:
+    """Crystals -> collated batch, with the neighbour search on the GPU (matten_neighbor_count/_fill).
+
+    ``structures`` is a sequence of (pos [n,3], cell [3,3], atomic_numbers [n]) triples.  The result has exactly
+    the keys, dtypes and edge order of ``collate([crystal_graph(...) ...], device)``; only the positions, cells
+    and species cross PCIe (fp64 for the distance test, as in the host builder).  A crystal without any edge
+    raises ValueError, like the reference (data/data.py:398-402)."""
+    from .. import ops
+
+    sizes = np.array([len(s[0]) for s in structures], dtype=np.int64)
+    ptr = np.zeros(len(structures) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=ptr[1:])
+    pos = np.concatenate([np.asarray(s[0], dtype=np.float64).reshape(-1, 3) for s in structures])
+    cell = np.stack([np.asarray(s[1], dtype=np.float64).reshape(3, 3) for s in structures])
+    Z = np.concatenate([np.asarray(s[2], dtype=np.int64).reshape(-1) for s in structures])
+    batch = np.repeat(np.arange(len(structures), dtype=np.int64), sizes)
+    # image_reach for all crystals at once
+    inv = np.linalg.inv(cell)
+    ib = inv[batch]
+    frac = pos[:, 0:1] * ib[:, 0] + pos[:, 1:2] * ib[:, 1] + pos[:, 2:3] * ib[:, 2]
+    span = np.maximum.reduceat(frac, ptr[:-1]) - np.minimum.reduceat(frac, ptr[:-1])
+    reach = np.ceil(float(r_cut) * np.linalg.norm(inv, axis=1) + span).astype(np.int32)
+
+    dev = torch.device(device)
+    pos_d = torch.from_numpy(pos).to(dev)
+    cell_d = torch.from_numpy(cell.reshape(-1, 9)).to(dev)
+    ptr_d = torch.from_numpy(ptr).to(dev)
+    batch_d = torch.from_numpy(batch).to(dev)
+    edge_index, shifts, counts = ops.neighbor_list(pos_d, cell_d, ptr_d, torch.from_numpy(reach).to(dev), batch_d,
+                                                   r_cut)
+    per_crystal = torch.zeros(len(structures), dtype=torch.int64, device=dev).index_add_(0, batch_d, counts.long())
+    empty = torch.nonzero(per_crystal == 0).flatten().tolist()
+    if empty:
+        raise EdgelessStructures(empty)
+    out = {
+        "pos": pos_d.float(),
+        "edge_index": edge_index,
+        "edge_cell_shift": shifts,
+        "cell": cell_d.float().reshape(-1, 3),
+        "num_neigh": counts.float(),
+        "atomic_numbers": torch.from_numpy(Z).to(dev),
+    }
+    for k, v in (y or {}).items():
+        out[k] = torch.as_tensor(v).to(dev)
+    out["batch"] = batch_d
+    out["ptr"] = ptr_d
+    return out

@@ -17,7 +17,7 @@ from typing import Any, Dict, List, Sequence, Union
 import numpy as np
 import torch
 
-from .data.graph import collate, crystal_graph
+from .data.graph import EdgelessStructures, batch_graphs_gpu, collate, crystal_graph, image_reach
 from .model_factory.tfn_scalar_tensor import ScalarTensorModel
 from .parallel import sharded_apply
 from .utils import CartesianTensorWrapper, yaml_load
@@ -76,13 +76,25 @@ def check_species(model, structures: Sequence):
             )
 
 
-def build_graphs(structures: Sequence, r_cut: float):
+def build_graphs(structures: Sequence, r_cut: float, on_gpu: bool = False):
     """-> (graphs, failed indices): per-structure try/except like the reference dataset
-    (dataset/structure_scalar_tensor.py:296-362)."""
+    (dataset/structure_scalar_tensor.py:296-362).
+
+    ``on_gpu``: only validate on the host and return (pos, cell, Z) triples; the neighbour search then runs on
+    the device, batch by batch, inside ``evaluate`` (crystals that turn out to have no edge come back as NaN
+    rows and are reported as failed by ``predict``)."""
     graphs, failed = [], []
     for i, s in enumerate(structures):
         try:
             f = _fields(s)
+            if on_gpu:
+                pos = np.asarray(f["cart_coords"], dtype=np.float64).reshape(-1, 3)
+                cell = np.asarray(f["lattice"], dtype=np.float64).reshape(3, 3)
+                Z = np.asarray(f["atomic_numbers"], dtype=np.int64).reshape(-1)
+                if len(pos) == 0 or len(pos) != len(Z) or not np.all(np.isfinite(image_reach(pos, cell, r_cut))):
+                    raise ValueError("malformed structure")
+                graphs.append((pos, cell, Z))
+                continue
             graphs.append(crystal_graph(f["cart_coords"], f["lattice"], f["atomic_numbers"], r_cut))
         except Exception as e:  # noqa: BLE001
             warnings.warn(f"Failed converting structure {i}, Skip it. {e}")
@@ -92,11 +104,15 @@ def build_graphs(structures: Sequence, r_cut: float):
     return graphs, failed
 
 
-def evaluate(model, graphs: List[Dict[str, torch.Tensor]], batch_size: int = 200,
+def evaluate(model, graphs: List, batch_size: int = 200,
              tensor_target_name: str = "elastic_tensor_full", tensor_target_formula: str = "ijkl=jikl=klij",
-             distributed: bool = False) -> List[torch.Tensor]:
+             distributed: bool = False, r_cut: float = None) -> List[torch.Tensor]:
     """Batched forward; returns one Cartesian tensor per graph (on the host).  With ``distributed`` the
-    graphs are sharded by index over the ranks and gathered with one collective per call."""
+    graphs are sharded by index over the ranks and gathered with one collective per call.
+
+    ``graphs`` holds either host graph dicts (``crystal_graph``) or raw (pos, cell, Z) triples; triples are
+    turned into a batch on the device (``batch_graphs_gpu``, needs ``r_cut``).  A triple without any edge
+    yields a NaN tensor."""
     converter = CartesianTensorWrapper(tensor_target_formula)
     device = model.device
     rank_dims = (3,) * len(tensor_target_formula.split("=")[0].replace("-", ""))
@@ -105,12 +121,24 @@ def evaluate(model, graphs: List[Dict[str, torch.Tensor]], batch_size: int = 200
         outs = []
         with torch.no_grad():
             for lo in range(0, len(shard), batch_size):
-                batch = collate(shard[lo : lo + batch_size], device=device)
-                preds, _ = model(batch, task_name=tensor_target_name)
-                p = preds[tensor_target_name]
-                if p.dim() == 2:  # irreps -> Cartesian on the GPU
-                    p = converter.to_cartesian(p)
-                outs.append(p)
+                items = shard[lo : lo + batch_size]
+                keep = list(range(len(items)))
+                if isinstance(items[0], dict):
+                    batch = collate(items, device=device)
+                else:
+                    try:
+                        batch = batch_graphs_gpu(items, r_cut, device)
+                    except EdgelessStructures as e:
+                        keep = [i for i in keep if i not in set(e.indices)]
+                        batch = batch_graphs_gpu([items[i] for i in keep], r_cut, device) if keep else None
+                full = torch.full((len(items),) + rank_dims, float("nan"), device=device)
+                if batch is not None:
+                    preds, _ = model(batch, task_name=tensor_target_name)
+                    p = preds[tensor_target_name]
+                    if p.dim() == 2:  # irreps -> Cartesian on the GPU
+                        p = converter.to_cartesian(p)
+                    full[torch.as_tensor(keep, device=device)] = p
+                outs.append(full)
         return torch.cat(outs, dim=0)
 
     model.eval()
@@ -143,13 +171,26 @@ def predict(
     if config is None:
         config = get_pretrained_config(model_identifier)
     check_species(model, structures)
-    graphs, failed = build_graphs(structures, r_cut=config["data"]["r_cut"])
+    r_cut = config["data"]["r_cut"]
+    graphs, failed = build_graphs(structures, r_cut=r_cut, on_gpu=True)
     predictions = evaluate(
         model, graphs, batch_size=batch_size,
         tensor_target_name=config["data"]["tensor_target_name"],
         tensor_target_formula=config["data"]["tensor_target_formula"],
+        r_cut=r_cut,
     )
     predictions = [t.numpy() for t in predictions]
+    # crystals whose neighbour search found no edge come back as NaN tensors
+    ok_idx = [i for i in range(len(structures)) if i not in set(failed)]
+    edgeless = [ok_idx[k] for k, t in enumerate(predictions) if np.isnan(t).all()]
+    if edgeless:
+        for i in edgeless:
+            warnings.warn(f"Failed converting structure {i}, Skip it. After eliminating self edges, no edges remain "
+                          "in this system.")
+        predictions = [t for t in predictions if not np.isnan(t).all()]
+        failed = sorted(set(failed) | set(edgeless))
+        if not predictions:
+            raise RuntimeError("Cannot successfully convert any structures.")
     if is_elasticity_tensor:
         try:
             from pymatgen.analysis.elasticity import ElasticTensor
