@@ -10,7 +10,8 @@ N, S = 64000, 10
 irr = "32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e"
 u = mplan.plan_uvu(irr, Irreps.spherical_harmonics(4), irr)
 lp = mplan.plan_fctp(u.irreps_out, S, irr)
-x = torch.randn(N, lp.d_in, device=dev)
+PAD = int(os.environ.get("SL_PAD", "0"))
+x = torch.randn(N, lp.d_in + PAD, device=dev)
 wp = torch.randn(S, lp.w_stride, device=dev)
 items = [torch.from_numpy(np.ascontiguousarray(m)).to(dev) for m in lp.passes]
 def bench(order, seg, label):
