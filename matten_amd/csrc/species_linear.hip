@@ -4,19 +4,30 @@
 //
 // For one irrep block (mul_in -> mo channels, d = 2l+1 components) the op is, per node n of species s,
 //      out[n, o_off + v*d + m] = sum_u W_s[u, v] x[n, x_off + u*d + m].
-// The operator is HBM-bound (each input row, up to 16.7 KB, is read once; ~5 MAC per input float), so the
-// kernel is built around the input stream:
-//   * a wave owns 16 rows of ONE species (rows are visited in species-sorted order) and walks the irrep blocks;
-//   * rows are the N dimension of v_mfma_f32_16x16x4_f32, output channels v the M dimension, input channels u
-//     the contraction.  Lane (g = lane>>4, c = lane&15) loads, per step of 16 input channels, the 4d CONTIGUOUS
-//     floats x[row_c, x_off + (16 st + 4g)*d .. +4d) straight from global memory with 16-byte loads -- the four
-//     lanes of a row cover 16d contiguous floats, so every fetched line is used in full -- and feeds them to the
-//     matrix core as B[k = g][n = c] with the contraction index enumerated as u = 16 st + 4g + j for the j-th
-//     MFMA of the step (A uses the same enumeration, so no shuffle and no LDS is needed);
-//   * the weights (<= 89 KB per species, L2-resident) are read as A[m = c][k = g] = W_s[u, 16 vt + c];
+// The operator is HBM-bound (each input row, up to 16.7 KB, is read once; ~5 MAC per input float) and, on
+// MI355X, latency-bound unless ~30 MB of loads are in flight.  The kernel is therefore built around the input
+// stream:
+//   * a workgroup = 4 waves = 64 rows of ONE species (rows are visited in species-sorted order); the species'
+//     packed weight table (<= 128 KB, typically 32 KB) is copied to LDS once;
+//   * a wave owns 16 rows.  Rows are the N dimension of v_mfma_f32_16x16x4_f32, output channels v the M
+//     dimension, input channels u the contraction: B[k = g][n = c] = x[row_c, x_off + u*d + m] with the
+//     contraction index enumerated as u = 16 st + 4g + j for the j-th MFMA of step st (g = lane>>4, c = lane&15),
+//     A[m = c][k = g] = W_s[u, 16 vt + c] from LDS with the same enumeration;
+//   * the row is cut into CHUNKS: windows of 16*d*KS contiguous floats per row (KS = 10/3/2/1/1 steps for
+//     d = 1/3/5/7/9, <= 640 B), fetched by exactly NB = 10 16-byte buffer loads per lane -- load t takes the t-th
+//     64-byte piece of each of the 16 rows, so every instruction touches 16 full lines (a lane-contiguous layout,
+//     4d floats per lane, touches 64 lines per instruction and streams at 2.5 TB/s for d = 9 instead of 5.8,
+//     tools/ubench/rowstream.hip); unused slots are dummy loads of a resident line.  The landed registers are
+//     transposed through a wave-private LDS tile (ds_write_b128 in load order, ds_read_b128 of the 4d contiguous
+//     floats lane (g, c) needs), no barrier involved;
+//   * two scalar cursors walk the chunks: the load cursor runs two chunks ahead of the MFMA cursor ACROSS
+//     irrep-block boundaries (three register buffers).  Because every chunk issues the same number of loads the
+//     compiler's s_waitcnt vmcnt() counts are exact and a wave keeps 20 KB in flight while it multiplies;
+//   * buffer (SRD) loads give hardware bounds checking: reads past the tensor return 0, tails past a block's last
+//     channel are masked, so no NaN can leak between rows;
+//   * the optional addend (self-connection + message: out = add + W x) is streamed the same way, as one more chunk
+//     per output tile multiplied by an identity A operand, so the epilogue issues no loads;
 //   * D[row = 4g + r][col = c] is channel v = 16 vt + 4g + r of row c: each lane stores 4d contiguous floats.
-// The next step's operands are loaded before the current step's MFMAs (two register buffers), there are no
-// barriers, and the only LDS use is none at all.
 #include "common.h"
 
 namespace {
@@ -26,177 +37,358 @@ struct LinSeg {  // 8 x int32: one irrep block of one pass (matten_amd/plan.py:_
 };
 constexpr int SL_ROWS = 16;
 constexpr int SL_WAVES = 4;
-#ifndef SL_MIN_BLOCKS
-#define SL_MIN_BLOCKS 3
+#ifndef SL_NB
+#define SL_NB 10
 #endif
+constexpr int NB = SL_NB;     // 16-byte loads per lane and chunk
+constexpr int NACC = 9;       // accumulator tiles: max(NVT * d)
+constexpr int XS_RS = 16 * NB + 4;  // LDS row stride of the transpose tile (== 4 mod 32: conflict-free b128)
+constexpr uint32_t SRD_WORD3 = 0x00020000u;
+constexpr int64_t SRD_SPAN = ((int64_t)1 << 32) - (1 << 20);  // addressable bytes per descriptor, with slack
 typedef float sl_f32x4 __attribute__((ext_vector_type(4)));
+typedef int sl_i32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) sl_f4u {
     float v[4];
 };
+}  // namespace
+// 16-byte buffer load (bounds-checked against the descriptor: out-of-range lanes read 0)
+__device__ sl_f32x4 sl_buffer_load_x4(sl_i32x4 srsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.v4f32");
+namespace {
 
-template <int D, int NVT>
-struct Operands {
-    float x[4 * D];
-    float a[NVT][4];
+// v_mfma_f32_16x16x4_f32 accumulating in place (vDst tied to SrcC), issued through inline asm.
+// Why not the builtin: with __builtin_amdgcn_mfma_f32_16x16x4f32 clang moves the accumulators between register
+// tuples inside this (17 k instruction, 256 VGPR) kernel, and two builds of that form produced accumulators whose
+// upper half was stale for a few shapes (d = 1 blocks with an addend; tools/sl_check.py finds them).  The hardware
+// was ruled out -- overlapping vDst/SrcA/SrcB/SrcC, dependent chains and MFMA -> VALU reads are all interlocked
+// on gfx950, only MFMA -> VMEM-store needs 8 wait states and clang leaves 10 (tools/ubench/mfma_overlap.hip,
+// mfma_latency.hip) -- and the miscompile was not root-caused.  The tied form below leaves the register allocator
+// nothing to move; it passes the full sweep (tests/test_gpu_parity.py::test_species_linear_shape_sweep).
+// The hazard recogniser does not look inside inline asm, hence the explicit wait states: s_nop 1 in front (VALU
+// write of an operand -> MFMA read) and mfma_drain() after the last MFMA of every straight-line group, before
+// anything else may read, copy or store an accumulator.
+__device__ __forceinline__ void mfma_16x16x4(sl_f32x4& acc, float a, float b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15" ::: "memory"); }
+
+__device__ __forceinline__ constexpr int steps_per_chunk(int d) { return NB / d > 0 ? NB / d : 1; }
+
+struct Cursor {  // position of a chunk in the walk over (irrep block, channel-tile group, step); wave-uniform
+    int sg, vt0, st;
 };
 
-template <int D, int NVT>
-__device__ __forceinline__ void load_operands(Operands<D, NVT>& o, const float* __restrict__ xp,
-                                              const float* __restrict__ wl, int u0, int mul_in, int mo, int v0) {
-    // xp -> x[row, x_off + u0*D], wl -> W_s[u0, v0]  (u0 = 16 st + 4g, v0 = 16 vt0 + c)
-    if (u0 + 4 <= mul_in) {
-#pragma unroll
-        for (int q = 0; q < D; ++q) {
-#ifdef SL_ABLATE_COALESCED
-            const sl_f4u t = *reinterpret_cast<const sl_f4u*>(xp - (u0 & 15) * (D - 1) + 16 * q);
-#else
-            const sl_f4u t = *reinterpret_cast<const sl_f4u*>(xp + 4 * q);
-#endif
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o.x[4 * q + e] = t.v[e];
-        }
-#pragma unroll
-        for (int vt = 0; vt < NVT; ++vt) {
-            const bool v_ok = v0 + 16 * vt < mo;
-#pragma unroll
-#ifdef SL_ABLATE_NO_W
-            for (int j = 0; j < 4; ++j) o.a[vt][j] = v_ok ? 1.0f : 0.0f;
-#else
-            for (int j = 0; j < 4; ++j) o.a[vt][j] = v_ok ? wl[j * mo + 16 * vt] : 0.0f;
-#endif
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool u_ok = u0 + j < mul_in;
-#pragma unroll
-            for (int m = 0; m < D; ++m) o.x[j * D + m] = u_ok ? xp[j * D + m] : 0.0f;
-#pragma unroll
-            for (int vt = 0; vt < NVT; ++vt)
-                o.a[vt][j] = (u_ok && v0 + 16 * vt < mo) ? wl[j * mo + 16 * vt] : 0.0f;
+// st == -1 is the addend chunk that opens an output tile group when add != NULL
+__device__ __forceinline__ void advance(Cursor& cu, const LinSeg& L, int st_first) {
+    const int n_st = (L.mul_in + 15) >> 4, n_vt = (L.mo + 15) >> 4;
+    cu.st = cu.st < 0 ? 0 : cu.st + steps_per_chunk(L.d);
+    if (cu.st >= n_st) {
+        cu.st = st_first;
+        cu.vt0 += L.d <= 3 ? 2 : 1;
+        if (cu.vt0 >= n_vt) {
+            cu.vt0 = 0;
+            ++cu.sg;
         }
     }
 }
 
-template <int D, int NVT>
-__device__ __forceinline__ void mfma_step(const Operands<D, NVT>& o, sl_f32x4 (&acc)[NVT][D]) {
+struct Stream {  // descriptor + per-lane row offset of the two streamed operands
+    sl_i32x4 x_rsrc, a_rsrc;
+    int x_voff, a_voff;
+};
+
+// NB loads, always: load t fetches floats [16 t + 4g, +4) of the chunk's window in row c.
+__device__ __forceinline__ void load_chunk(float (&buf)[4 * NB], const Stream& sm, int g, const LinSeg& L,
+                                           const Cursor& cu, bool live) {
+    const bool is_add = cu.st < 0;
+    const int n_st = (L.mul_in + 15) >> 4, n_vt = (L.mo + 15) >> 4;
+    // window: steps of the input row, or (addend chunk) the output tiles of the group
+    const int n_run = is_add ? ((L.d <= 3 && cu.vt0 + 1 < n_vt) ? 2 : 1) : min(steps_per_chunk(L.d), n_st - cu.st);
+    const int n_real = live ? n_run * L.d : 0;
+    const int base = is_add ? L.o_off + 16 * cu.vt0 * L.d : L.x_off + 16 * cu.st * L.d;
+    const sl_i32x4 rsrc = is_add ? sm.a_rsrc : sm.x_rsrc;
+    const int voff = (is_add ? sm.a_voff : sm.x_voff) + 16 * g;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int t = 0; t < NB; ++t) {
+        const int soff = t < n_real ? 4 * (base + 16 * t) : 0;
+        const sl_f32x4 v = sl_buffer_load_x4(rsrc, voff, soff, 0);
+        buf[4 * t + 0] = v[0];
+        buf[4 * t + 1] = v[1];
+        buf[4 * t + 2] = v[2];
+        buf[4 * t + 3] = v[3];
+    }
+}
+
+// registers (load order) -> wave-private LDS tile [16 rows][XS_RS]
+__device__ __forceinline__ void stage_chunk(const float (&buf)[4 * NB], float* xs, int g, int c) {
+    float* p = xs + c * XS_RS + 4 * g;
 #pragma unroll
-        for (int vt = 0; vt < NVT; ++vt)
-#pragma unroll
-            for (int m = 0; m < D; ++m)
-#ifdef SL_ABLATE_NO_MFMA
-                acc[vt][m][0] += o.a[vt][j] * o.x[j * D + m];
-#else
-                acc[vt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[vt][j], o.x[j * D + m], acc[vt][m], 0, 0, 0);
-#endif
+    for (int t = 0; t < NB; ++t)
+        *reinterpret_cast<sl_f32x4*>(p + 16 * t) = sl_f32x4{buf[4 * t], buf[4 * t + 1], buf[4 * t + 2], buf[4 * t + 3]};
 }
 
 template <int D, int NVT>
-__device__ __forceinline__ void run_block(const float* __restrict__ xrow, const float* __restrict__ wsp,
-                                          const LinSeg& L, int g, int c, int vt0, bool row_ok,
-                                          float* __restrict__ orow, const float* __restrict__ arow) {
-    sl_f32x4 acc[NVT][D];
-#pragma unroll
-    for (int vt = 0; vt < NVT; ++vt)
-#pragma unroll
-        for (int m = 0; m < D; ++m) acc[vt][m] = sl_f32x4{0.f, 0.f, 0.f, 0.f};
-    const int v0 = 16 * vt0 + c;
-    const float* xp = xrow + L.x_off + 4 * g * D;
-    const float* wl = wsp + L.w_off + 4 * g * L.mo + v0;
+__device__ __forceinline__ void mfma_chunk(const float* xs, sl_f32x4 (&acc)[NACC],
+                                           const float* __restrict__ ws, const LinSeg& L, int vt0, int st, int g,
+                                           int c) {
+    constexpr int KS = steps_per_chunk(D);
     const int n_st = (L.mul_in + 15) >> 4;
-    Operands<D, NVT> A, B;
-    load_operands<D, NVT>(A, xp, wl, 4 * g, L.mul_in, L.mo, v0);
-    for (int st = 0; st < n_st; st += 2) {
-        if (st + 1 < n_st)
-            load_operands<D, NVT>(B, xp + 16 * (st + 1) * D, wl + 16 * (st + 1) * L.mo, 16 * (st + 1) + 4 * g,
-                                  L.mul_in, L.mo, v0);
-        mfma_step<D, NVT>(A, acc);
-        if (st + 1 < n_st) {
-            if (st + 2 < n_st)
-                load_operands<D, NVT>(A, xp + 16 * (st + 2) * D, wl + 16 * (st + 2) * L.mo, 16 * (st + 2) + 4 * g,
-                                      L.mul_in, L.mo, v0);
-            mfma_step<D, NVT>(B, acc);
-        }
-    }
-    if (!row_ok) return;
+    const float* xl = xs + c * XS_RS + 4 * g * D;  // lane (g, c): floats [16 D r + 4 g D, + 4 D) of row c's window
 #pragma unroll
-    for (int vt = 0; vt < NVT; ++vt)
+    for (int r = 0; r < KS; ++r) {
+        if (st + r < n_st) {
+            float xr[4 * D];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int v = 16 * (vt0 + vt) + 4 * g + r;
-            if (v < L.mo) {
+            for (int q = 0; q < D; ++q) {
+                const sl_f32x4 t = *reinterpret_cast<const sl_f32x4*>(xl + 16 * D * r + 4 * q);
+                xr[4 * q] = t[0];
+                xr[4 * q + 1] = t[1];
+                xr[4 * q + 2] = t[2];
+                xr[4 * q + 3] = t[3];
+            }
+            const int ub = 16 * (st + r) + 4 * g;
+            float a[NVT][4];
 #pragma unroll
-                for (int m = 0; m < D; ++m) {
-                    const int oi = L.o_off + v * D + m;
-                    orow[oi] = (arow ? arow[oi] : 0.0f) + acc[vt][m][r];
+            for (int vt = 0; vt < NVT; ++vt) {
+                const int v = 16 * (vt0 + vt) + c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = ub + j < L.mul_in && v < L.mo;
+                    const float wv = ws[ok ? L.w_off + (ub + j) * L.mo + v : 0];
+                    a[vt][j] = ok ? wv : 0.0f;
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool u_ok = ub + j < L.mul_in;
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    const float xv = u_ok ? xr[j * D + m] : 0.0f;
+#pragma unroll
+                    for (int vt = 0; vt < NVT; ++vt) mfma_16x16x4(acc[vt * D + m], a[vt][j], xv);
+                }
+            }
+            mfma_drain();
         }
+    }
+}
+
+// addend chunk: run vt holds add[row c, o_off + (16 (vt0+vt) + 4g + j)*D + m]; multiply by A = identity
+template <int D, int NVT>
+__device__ __forceinline__ void mfma_addend(const float* xs, sl_f32x4 (&acc)[NACC], const LinSeg& L,
+                                            int vt0, int g, int c) {
+    const float* xl = xs + c * XS_RS + 4 * g * D;
+#pragma unroll
+    for (int vt = 0; vt < NVT; ++vt) {
+        float xr[4 * D];
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+            const sl_f32x4 t = *reinterpret_cast<const sl_f32x4*>(xl + 16 * D * vt + 4 * q);
+            xr[4 * q] = t[0];
+            xr[4 * q + 1] = t[1];
+            xr[4 * q + 2] = t[2];
+            xr[4 * q + 3] = t[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = (c == 4 * g + j) ? 1.0f : 0.0f;
+            const bool v_ok = 16 * (vt0 + vt) + 4 * g + j < L.mo;
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                const float xv = v_ok ? xr[j * D + m] : 0.0f;
+                mfma_16x16x4(acc[vt * D + m], a, xv);
+            }
+        }
+        mfma_drain();
+    }
+}
+
+template <int D, int NVT>
+__device__ __forceinline__ void store_tiles(sl_f32x4 (&acc)[NACC], const LinSeg& L, int vt0, int g, bool row_ok,
+                                            float* __restrict__ orow) {
+#pragma unroll
+    for (int vt = 0; vt < NVT; ++vt) {
+        const int vb = 16 * (vt0 + vt) + 4 * g;
+        float* op = orow + L.o_off + vb * D;
+        if (row_ok && vb + 4 <= L.mo) {
+            float o[4 * D];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < D; ++m) o[r * D + m] = acc[vt * D + m][r];
+#pragma unroll
+            for (int q = 0; q < D; ++q) {
+                sl_f4u t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t.v[e] = o[4 * q + e];
+                *reinterpret_cast<sl_f4u*>(op + 4 * q) = t;
+            }
+        } else if (row_ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (vb + r < L.mo) {
+#pragma unroll
+                    for (int m = 0; m < D; ++m) op[r * D + m] = acc[vt * D + m][r];
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NVT * D; ++i) acc[i] = sl_f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int D, int NVT>
+__device__ __forceinline__ void consume_dn(const float* buf, sl_f32x4 (&acc)[NACC],
+                                           const float* __restrict__ ws, const LinSeg& L, const Cursor& cu, int g,
+                                           int c, bool row_ok, float* __restrict__ orow) {
+    const int n_st = (L.mul_in + 15) >> 4;
+    if (cu.st < 0) {
+        mfma_addend<D, NVT>(buf, acc, L, cu.vt0, g, c);
+    } else {
+        mfma_chunk<D, NVT>(buf, acc, ws, L, cu.vt0, cu.st, g, c);
+        if (cu.st + steps_per_chunk(D) >= n_st) store_tiles<D, NVT>(acc, L, cu.vt0, g, row_ok, orow);
+    }
 }
 
 template <int D>
-__device__ __forceinline__ void run_segment(const float* __restrict__ xrow, const float* __restrict__ wsp,
-                                            const LinSeg& L, int g, int c, bool row_ok, float* __restrict__ orow,
-                                            const float* __restrict__ arow) {
+__device__ __forceinline__ void consume_d(const float* buf, sl_f32x4 (&acc)[NACC],
+                                          const float* __restrict__ ws, const LinSeg& L, const Cursor& cu, int g, int c,
+                                          bool row_ok, float* __restrict__ orow) {
     const int n_vt = (L.mo + 15) >> 4;
-    if constexpr (D <= 3) {
-        for (int vt0 = 0; vt0 < n_vt; vt0 += 2) {
-            if (vt0 + 1 < n_vt) run_block<D, 2>(xrow, wsp, L, g, c, vt0, row_ok, orow, arow);
-            else run_block<D, 1>(xrow, wsp, L, g, c, vt0, row_ok, orow, arow);
-        }
-    } else {
-        for (int vt0 = 0; vt0 < n_vt; ++vt0) run_block<D, 1>(xrow, wsp, L, g, c, vt0, row_ok, orow, arow);
+    if (D <= 3 && cu.vt0 + 1 < n_vt) consume_dn<D, (D <= 3 ? 2 : 1)>(buf, acc, ws, L, cu, g, c, row_ok, orow);
+    else consume_dn<D, 1>(buf, acc, ws, L, cu, g, c, row_ok, orow);
+}
+
+__device__ __forceinline__ void consume(const float (&regs)[4 * NB], float* buf, sl_f32x4 (&acc)[NACC],
+                                        const float* __restrict__ ws, const LinSeg& L, const Cursor& cu, int g, int c,
+                                        bool row_ok, float* __restrict__ orow) {
+    stage_chunk(regs, buf, g, c);
+    switch (L.d) {
+        case 1: consume_d<1>(buf, acc, ws, L, cu, g, c, row_ok, orow); break;
+        case 3: consume_d<3>(buf, acc, ws, L, cu, g, c, row_ok, orow); break;
+        case 5: consume_d<5>(buf, acc, ws, L, cu, g, c, row_ok, orow); break;
+        case 7: consume_d<7>(buf, acc, ws, L, cu, g, c, row_ok, orow); break;
+        case 9: consume_d<9>(buf, acc, ws, L, cu, g, c, row_ok, orow); break;
+        default: break;  // 2l+1 > 9: rejected by the host plan
     }
 }
+
+#ifndef SL_MIN_BLOCKS
+#define SL_MIN_BLOCKS 2
+#endif
 
 __global__ __launch_bounds__(SL_WAVES * 64, SL_MIN_BLOCKS) void species_linear_kernel(
     const float* __restrict__ x, int d_in, const int32_t* __restrict__ order, const int32_t* __restrict__ seg,
     int n_species, const float* __restrict__ wp, int w_stride, const LinSeg* __restrict__ segs, int n_segs,
     int segs_per_block, int d_out, const float* __restrict__ add, int n_rows, float* __restrict__ out) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    int t = blockIdx.x * SL_WAVES + wave, s = 0, lo = 0, hi = 0;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ws = lds + SL_WAVES * SL_ROWS * XS_RS;  // [w_stride] packed table of this block's species
+    // ---- block -> (species, 64 rows) ----
+    int b = blockIdx.x, s = 0, blo = 0, bhi = 0;
+    constexpr int BR = SL_ROWS * SL_WAVES;
     if (seg) {
         bool found = false;
         for (s = 0; s < n_species; ++s) {
             const int beg = seg[s], end = seg[s + 1];
-            const int nt = (end - beg + SL_ROWS - 1) / SL_ROWS;
-            if (t < nt) {
-                lo = beg + t * SL_ROWS;
-                hi = min(end, lo + SL_ROWS);
+            const int nb = (end - beg + BR - 1) / BR;
+            if (b < nb) {
+                blo = beg + b * BR;
+                bhi = min(end, blo + BR);
                 found = true;
                 break;
             }
-            t -= nt;
+            b -= nb;
         }
         if (!found) return;
     } else {
-        lo = t * SL_ROWS;
-        hi = min(n_rows, lo + SL_ROWS);
-        if (lo >= hi) return;
+        blo = b * BR;
+        bhi = min(n_rows, blo + BR);
+        if (blo >= bhi) return;
     }
-    const float* wsp = wp + (int64_t)s * w_stride;
-    const int g = lane >> 4, c = lane & 15;
-    const bool row_ok = lo + c < hi;
-    const int row = row_ok ? lo + c : lo;
-    const int node = order ? order[row] : row;
-    const float* xrow = x + (int64_t)node * d_in;
-    float* orow = out + (int64_t)node * d_out;
-    const float* arow = add ? add + (int64_t)node * d_out : nullptr;
-
     const int sg0 = blockIdx.y * segs_per_block, sg1 = min(n_segs, sg0 + segs_per_block);
-    for (int sg = sg0; sg < sg1; ++sg) {
-        const LinSeg L = segs[sg];
-        switch (L.d) {
-            case 1: run_segment<1>(xrow, wsp, L, g, c, row_ok, orow, arow); break;
-            case 3: run_segment<3>(xrow, wsp, L, g, c, row_ok, orow, arow); break;
-            case 5: run_segment<5>(xrow, wsp, L, g, c, row_ok, orow, arow); break;
-            case 7: run_segment<7>(xrow, wsp, L, g, c, row_ok, orow, arow); break;
-            case 9: run_segment<9>(xrow, wsp, L, g, c, row_ok, orow, arow); break;
-            default: break;  // rejected on the host
+    {   // the slice of the weight table this block's irrep blocks touch
+        int w_lo = w_stride, w_hi = 0;
+        for (int sg = sg0; sg < sg1; ++sg) {
+            w_lo = min(w_lo, segs[sg].w_off);
+            w_hi = max(w_hi, segs[sg].w_off + segs[sg].mul_in * segs[sg].mo);
         }
+        const float* wsp = wp + (int64_t)s * w_stride;
+        for (int i = w_lo + threadIdx.x; i < w_hi; i += blockDim.x) ws[i] = wsp[i];
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, c = lane & 15;
+    float* xs = lds + wave * SL_ROWS * XS_RS;  // this wave's transpose tile
+    const int lo = blo + wave * SL_ROWS;
+    if (lo >= bhi) return;
+    const int hi = min(bhi, lo + SL_ROWS);
+    const bool row_in = lo + c < hi;
+    const int row = row_in ? lo + c : lo;
+    const int node = order ? order[row] : row;
+    float* orow = out + (int64_t)node * d_out;
+    const int64_t x_bytes = (int64_t)n_rows * d_in * 4, a_bytes = (int64_t)n_rows * d_out * 4;
+    const int st_first = add ? -1 : 0;
+
+    // Rows of a tile ascend in memory; a descriptor addresses 4 GB from its base.  Tiles whose rows are further
+    // apart than that (only possible for > 4 GB inputs and very rare species) take several passes.
+    bool pending = row_in;
+    while (true) {
+        int nmin = pending ? node : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nmin = min(nmin, __shfl_xor(nmin, off));
+        if (nmin == 0x7fffffff) break;
+        nmin = __builtin_amdgcn_readfirstlane(nmin);
+        const int64_t rel = (int64_t)node - nmin;
+        const bool row_ok = pending && rel >= 0 && rel * max(d_in, d_out) * 4 < SRD_SPAN;
+        Stream sm;
+        {
+            const int64_t xb = (int64_t)nmin * d_in * 4, ab = (int64_t)nmin * d_out * 4;
+            const uint64_t xp = (uint64_t)(reinterpret_cast<const char*>(x) + xb);
+            const uint64_t ap = (uint64_t)(reinterpret_cast<const char*>(add ? add : x) + (add ? ab : 0));
+            const int64_t xl = x_bytes - xb, al = add ? a_bytes - ab : 0;
+            sm.x_rsrc = sl_i32x4{(int)(uint32_t)xp, (int)((uint32_t)(xp >> 32) & 0xffffu),
+                                 (int)(uint32_t)(xl > 0xffffffffll ? 0xffffffffll : xl), (int)SRD_WORD3};
+            sm.a_rsrc = sl_i32x4{(int)(uint32_t)ap, (int)((uint32_t)(ap >> 32) & 0xffffu),
+                                 (int)(uint32_t)(al > 0xffffffffll ? 0xffffffffll : al), (int)SRD_WORD3};
+            sm.x_voff = row_ok ? (int)(rel * d_in * 4) : 0;
+            sm.a_voff = row_ok ? (int)(rel * d_out * 4) : 0;
+        }
+
+        sl_f32x4 acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = sl_f32x4{0.f, 0.f, 0.f, 0.f};
+        float bufA[4 * NB], bufB[4 * NB], bufC[4 * NB];
+        Cursor lc{sg0, 0, st_first}, cc{sg0, 0, st_first};
+        LinSeg Ll = segs[sg0], Lc = Ll;
+#define SL_STEP_LOAD(buf)                                             \
+        load_chunk(buf, sm, g, Ll, lc, lc.sg < sg1);                  \
+        if (lc.sg < sg1) {                                            \
+            const int sgp = lc.sg;                                    \
+            advance(lc, Ll, st_first);                                \
+            if (lc.sg != sgp && lc.sg < sg1) Ll = segs[lc.sg];        \
+        }
+#define SL_STEP_MFMA(buf)                                             \
+        consume(buf, xs, acc, ws, Lc, cc, g, c, row_ok, orow);            \
+        {                                                             \
+            const int sgp = cc.sg;                                    \
+            advance(cc, Lc, st_first);                                \
+            if (cc.sg >= sg1) break;                                  \
+            if (cc.sg != sgp) Lc = segs[cc.sg];                       \
+        }
+        SL_STEP_LOAD(bufA)
+        SL_STEP_LOAD(bufB)
+        while (true) {  // two chunks (20 KB per wave) in flight while the third is multiplied
+            SL_STEP_LOAD(bufC)
+            SL_STEP_MFMA(bufA)
+            SL_STEP_LOAD(bufA)
+            SL_STEP_MFMA(bufB)
+            SL_STEP_LOAD(bufB)
+            SL_STEP_MFMA(bufC)
+        }
+#undef SL_STEP_LOAD
+#undef SL_STEP_MFMA
+        pending = pending && !row_ok;
     }
 }
 
@@ -214,13 +406,23 @@ extern "C" int matten_species_linear(const float* x, int64_t d_in, const int32_t
     if (!x || !wp || !out || !segs) return MATTEN_EINVAL;
     if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
     if (!order && n_species != 1) return MATTEN_EINVAL;
-    const int64_t tiles = matten_cdiv(n_rows, SL_ROWS) + (order ? n_species : 0);
+    const size_t lds = sizeof(float) * ((size_t)((w_stride + 3) & ~3) + SL_WAVES * SL_ROWS * XS_RS);
+    if (lds > 160 * 1024) return MATTEN_EINVAL;  // one species' packed table must fit in LDS (<= ~118 KB)
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)species_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return MATTEN_ELAUNCH;
+        attr_set = true;
+    }
+    constexpr int BR = SL_ROWS * SL_WAVES;
+    const int64_t blocks = matten_cdiv(n_rows, BR) + (order ? n_species : 0);
     // few rows: spread the irrep blocks over blockIdx.y so the chip still sees enough waves
-    const int segs_per_block = tiles >= 2048 ? (int)n_segs : 1;
-    dim3 grid((unsigned)matten_cdiv(tiles, SL_WAVES), (unsigned)matten_cdiv(n_segs, segs_per_block));
-    species_linear_kernel<<<grid, SL_WAVES * 64, 0, stream>>>(x, (int)d_in, order, seg, (int)n_species, wp,
-                                                            (int)w_stride, (const LinSeg*)segs, (int)n_segs,
-                                                            segs_per_block, (int)d_out, add, (int)n_rows, out);
+    const int segs_per_block = blocks >= 512 ? (int)n_segs : 1;
+    dim3 grid((unsigned)blocks, (unsigned)matten_cdiv(n_segs, segs_per_block));
+    species_linear_kernel<<<grid, SL_WAVES * 64, lds, stream>>>(x, (int)d_in, order, seg, (int)n_species, wp,
+                                                              (int)w_stride, (const LinSeg*)segs, (int)n_segs,
+                                                              segs_per_block, (int)d_out, add, (int)n_rows, out);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

@@ -396,3 +396,54 @@ def test_gpu_neighbor_list_is_identical_to_oracle_builder(golden_dir):
     with pytest.raises(EdgelessStructures) as ei:
         batch_graphs_gpu([triples[0], (np.zeros((1, 3)), 50.0 * np.eye(3), [14]), triples[1]], 5.0, DEV)
     assert ei.value.indices == [1]
+
+
+def _species_linear_case(irreps_in, irreps_out, S, N, with_add, gen):
+    """matten_species_linear against a dense fp64 evaluation of the same segment tables."""
+    from matten_amd import ops, plan as mplan
+
+    lp = mplan.plan_fctp(irreps_in, S, irreps_out)
+    x = torch.randn(N, lp.d_in, device=DEV, generator=gen)
+    wp = torch.randn(S, lp.w_stride, device=DEV, generator=gen)
+    add = torch.randn(N, lp.d_out, device=DEV, generator=gen) if with_add else None
+    species = torch.randint(0, S, (N,), device=DEV, generator=gen)
+    order, seg, _, _ = ops.csr_build(torch.stack([torch.arange(N, device=DEV), species]), S)
+    items = [torch.from_numpy(np.ascontiguousarray(m)).to(DEV) for m in lp.passes]
+    got = ops.species_linear(x, (order, seg), wp, lp.w_stride, items, lp.d_out, add, lp.fully_covered)
+    want = add.double().clone() if with_add else torch.zeros(N, lp.d_out, dtype=torch.float64, device=DEV)
+    for p in lp.passes:
+        for (xo, d, mi, wo, mo, oo, _, _) in p.tolist():
+            W = wp.double()[species][:, wo:wo + mi * mo].reshape(N, mi, mo)
+            X = x.double()[:, xo:xo + mi * d].reshape(N, mi, d)
+            want[:, oo:oo + mo * d] += torch.einsum("nuv,num->nvm", W, X).reshape(N, mo * d)
+    return (got.double() - want).abs().max().item() / max(1e-6, want.abs().max().item())
+
+
+def test_species_linear_shape_sweep():
+    """Row-streaming MFMA kernel over the shapes that stress its chunking: every conv-layer shape of the paper
+    model, output multiplicities across the 16/32-channel tile boundaries (with and without the streamed addend),
+    input multiplicities across the 16-channel step and 160-float window boundaries, all l <= 4, ragged species
+    groups.  Reference: dense fp64 contraction of the same segment tables (oracle semantics of
+    FullyConnectedTensorProduct(x, one_hot), e3nn_lite/o3.py)."""
+    from matten_amd.model_factory.tfn_scalar_tensor import create_model
+    from matten_amd.data import synthetic
+
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    worst = {}
+    m = create_model(dict(PAPER), {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0})
+    for name, mod in m.named_modules():
+        if type(mod).__name__ == "SpeciesLinear" and mod.n_species is not None:
+            for N in (1, 200):
+                for add in (False, True):
+                    worst[(name, N, add)] = _species_linear_case(str(mod.irreps_in), str(mod.irreps_out), mod.n_species,
+                                                                 N, add, gen)
+    for mo in list(range(1, 40)) + [63, 64, 65, 70, 78, 79, 80, 81, 96, 97, 127, 128, 129, 161]:
+        for l, mi in ((0, 8), (1, 5), (2, 3)):
+            ir = f"{l}{'e' if l % 2 == 0 else 'o'}"
+            worst[("mo", mo, l)] = _species_linear_case(f"{mi}x{ir}", f"{mo}x{ir}", 2, 37, True, gen)
+    for mi in list(range(1, 36, 2)) + [159, 160, 161, 170, 321]:
+        for l in range(5):
+            ir = f"{l}{'e' if l % 2 == 0 else 'o'}"
+            worst[("mi", mi, l)] = _species_linear_case(f"{mi}x{ir}+3x0e", f"5x{ir}+2x0e", 3, 50, bool(mi % 2), gen)
+    bad = {k: v for k, v in worst.items() if not v < 2e-6}
+    assert not bad, f"{len(bad)} of {len(worst)} shapes off: {sorted(bad.items(), key=lambda kv: -kv[1])[:8]}"
