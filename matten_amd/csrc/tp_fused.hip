@@ -100,6 +100,19 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
         }
     }
 
+    // Software pipeline of the neighbour gather: the source index runs two edges ahead and the feature row
+    // x[src] one edge ahead of the contraction, across chunk boundaries (the loads are unconditional on a clamped
+    // edge index, so nothing but the data dependence orders them against the MFMA phase).
+    const int e_last = deg > 0 ? beg + deg - 1 : 0;
+    float xn[G::D1];
+    int src_nn;
+    {
+        const int src0 = a.src_sorted[min(beg, e_last)];
+        src_nn = a.src_sorted[min(beg + 1, e_last)];
+        const float* xp0 = a.x + (int64_t)src0 * a.d_in + xcol;
+#pragma unroll
+        for (int i = 0; i < G::D1; ++i) xn[i] = xp0[i];
+    }
     for (int s0 = 0; s0 < maxdeg; s0 += CH) {
         // ---- MFMA: w[edge n, col] = h2[edge n, :] . W2p[:, col] into the wave's LDS tile (edge n = jn*CH + so) ----
 #pragma unroll
@@ -146,15 +159,19 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
 #ifndef MATTEN_ABLATE_NO_VALU
         for (int so = 0; so < CH; ++so) {
             const int s = s0 + so;
+            float x[G::D1];
+#pragma unroll
+            for (int i = 0; i < G::D1; ++i) x[i] = xn[i];
+            {   // issue edge s+1's row and edge s+2's index
+                const float* xp = a.x + (int64_t)src_nn * a.d_in + xcol;
+#pragma unroll
+                for (int i = 0; i < G::D1; ++i) xn[i] = xp[i];
+                src_nn = a.src_sorted[min(beg + s + 2, e_last)];
+            }
             if (s < deg) {
-                const int e = beg + s;
-                const int src = a.src_sorted[e];
-                const float* xp = a.x + (int64_t)src * a.d_in + xcol;
                 const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
                 const float* yp = tile + ((j << ch_log2) + so) * stride + ycol + G::Y0;
-                float x[G::D1], y[G::NY], w[NC];
-#pragma unroll
-                for (int i = 0; i < G::D1; ++i) x[i] = xp[i];
+                float y[G::NY], w[NC];
 #pragma unroll
                 for (int jj = 0; jj < G::NY; ++jj) y[jj] = yp[jj];
 #pragma unroll
@@ -185,7 +202,10 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
 #define MATTEN_GROUP_CASE(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, node, lane, valid, beg, deg, maxdeg); break;
 
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 3) void tp_fused_kernel(Args a, const GroupEntry* __restrict__ entries,
+#ifndef TPF_MIN_BLOCKS
+#define TPF_MIN_BLOCKS 3
+#endif
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused_kernel(Args a, const GroupEntry* __restrict__ entries,
                                                                         const int* __restrict__ ustart,
                                                                         int n_entries, int units_per_tile,
                                                                         int blocks_per_tile, int n_tiles) {
