@@ -159,6 +159,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
 #ifndef MATTEN_ABLATE_NO_VALU
         for (int so = 0; so < CH; ++so) {
             const int s = s0 + so;
+            if (s >= maxdeg) break;  // wave-uniform: no lane has an edge in the remaining slots
             float x[G::D1];
 #pragma unroll
             for (int i = 0; i < G::D1; ++i) x[i] = xn[i];
@@ -252,7 +253,11 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
 
 // Hidden layers of the radial MLP: rbf(|v|) -> 32 -> 32, written as h2p [E,32] (see header comment).
 constexpr int NT = 4;
-__device__ __forceinline__ float silu(float z) { return z / (1.0f + expf(-z)); }
+// silu on the hardware transcendental units: v_exp_f32 (2^x) + v_rcp_f32, ~1 ulp each, against the ~25-instruction
+// expf + IEEE division; the hidden kernel is bound by exactly this arithmetic (64 silu per edge and layer)
+__device__ __forceinline__ float silu(float z) {
+    return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
 
 template <int KS0>
 __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __restrict__ geom, int64_t E, int n_basis,
