@@ -123,7 +123,13 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
                 const int begn = __shfl(beg, jn << cu_log2);
                 const int degn = __shfl(deg_node, jn << cu_log2);
                 f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+#ifdef MATTEN_ABLATE_NO_H2LOAD
+                b0 = f32x4{1.f, 2.f, 3.f, 4.f};
+                b1 = b0;
+                if (false) {
+#else
                 if (s0 + so < degn) {
+#endif
                     const int64_t en = begn + s0 + so;
                     const f32x4* hp = reinterpret_cast<const f32x4*>(a.h2p + en * HID + g * 8);
                     b0 = hp[0];
