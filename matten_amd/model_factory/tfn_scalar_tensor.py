@@ -24,7 +24,7 @@ from .utils import create_sequential_module
 OUT_FIELD_NAME = "my_model_output"
 
 
-def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any]):
+def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any], pooling: bool = True):
     use_atom_feats = hparams.get("use_atom_feats", False)
     atom_feats_dim = dataset_hparams.get("atom_feats_size", None)
     materialize = bool(hparams.get("materialize_intermediates", False))
@@ -75,10 +75,11 @@ def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any]):
         NodewiseLinear,
         {"irreps_out": hparams["conv_to_output_hidden_irreps_out"], "out_field": OUT_FIELD_NAME},
     )
-    layers["output_pooling"] = (
-        NodewiseReduce,
-        {"field": OUT_FIELD_NAME, "out_field": OUT_FIELD_NAME, "reduce": hparams["reduce"]},
-    )
+    if pooling:  # the per-atom model (tfn_atomic_tensor) stops at the node head
+        layers["output_pooling"] = (
+            NodewiseReduce,
+            {"field": OUT_FIELD_NAME, "out_field": OUT_FIELD_NAME, "reduce": hparams["reduce"]},
+        )
     return create_sequential_module(modules=layers)
 
 

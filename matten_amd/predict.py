@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from .data.graph import EdgelessStructures, batch_graphs_gpu, collate, crystal_graph, image_reach
+from .model_factory.tfn_atomic_tensor import AtomicTensorModel
 from .model_factory.tfn_scalar_tensor import ScalarTensorModel
 from .parallel import sharded_apply
 from .utils import CartesianTensorWrapper, yaml_load
@@ -149,6 +150,26 @@ def evaluate(model, graphs: List, batch_size: int = 200,
     return list(preds.cpu())
 
 
+def evaluate_atomic(model, graphs: List, batch_size: int = 200, tensor_target_name: str = "nmr_tensor",
+                    tensor_target_formula: str = "ij=ji", r_cut: float = None) -> List[torch.Tensor]:
+    """Per-atom tensors of all atoms of all structures, in input order, as ONE flat list -- what the reference's
+    ``evaluate`` produces for an ``AtomicTensorModel`` (predict.py:117-148: ``predictions.extend(p)``)."""
+    converter = CartesianTensorWrapper(tensor_target_formula)
+    device = model.device
+    outs = []
+    model.eval()
+    with torch.no_grad():
+        for lo in range(0, len(graphs), batch_size):
+            items = graphs[lo : lo + batch_size]
+            batch = collate(items, device=device) if isinstance(items[0], dict) else batch_graphs_gpu(items, r_cut, device)
+            preds, _ = model(batch, task_name=tensor_target_name)
+            p = preds[tensor_target_name]
+            if p.dim() == 2:
+                p = converter.to_cartesian(p)
+            outs.append(p)
+    return list(torch.cat(outs, dim=0).cpu())
+
+
 def predict(
     structure,
     model_identifier="20230627",
@@ -161,17 +182,29 @@ def predict(
     config: Dict[str, Any] = None,
 ):
     """See the module docstring.  ``model`` / ``config`` let a caller reuse an already loaded model."""
-    if is_atomic_tensor:
-        raise NotImplementedError("the atomic (NMR) tensor model is outside the accelerated path")
+    if is_atomic_tensor:  # reference predict.py:196-199
+        is_elasticity_tensor = False
     single = not isinstance(structure, (list, tuple))
     structures = [structure] if single else list(structure)
 
     if model is None:
-        model = get_pretrained_model(model_identifier, checkpoint)
+        model = get_pretrained_model(model_identifier, checkpoint,
+                                     model_class=AtomicTensorModel if is_atomic_tensor else ScalarTensorModel)
     if config is None:
         config = get_pretrained_config(model_identifier)
     check_species(model, structures)
     r_cut = config["data"]["r_cut"]
+    if is_atomic_tensor:
+        # one tensor per atom; the reference returns them as one flat list over all structures and never unwraps a
+        # single structure (predict.py:210-242).  A structure whose graph cannot be built fails the whole call
+        # here: with per-atom outputs the reference's "None at the failed index" bookkeeping has no meaning.
+        graphs, failed = build_graphs(structures, r_cut=r_cut, on_gpu=True)
+        if failed:
+            raise RuntimeError(f"Cannot build the graph of structures {failed}.")
+        preds = evaluate_atomic(model, graphs, batch_size=batch_size,
+                                tensor_target_name=config["data"]["tensor_target_name"],
+                                tensor_target_formula=config["data"]["tensor_target_formula"], r_cut=r_cut)
+        return [t.numpy() for t in preds]
     graphs, failed = build_graphs(structures, r_cut=r_cut, on_gpu=True)
     predictions = evaluate(
         model, graphs, batch_size=batch_size,

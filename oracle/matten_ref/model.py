@@ -38,7 +38,9 @@ def create_sequential_module(modules: "OrderedDict[str, tuple]", irreps_in=None)
     return rnn.Sequential(OrderedDict(zip(names, instances)))
 
 
-def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any]) -> rnn.Sequential:
+def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any], atomic: bool = False) -> rnn.Sequential:
+    """atomic=False: model_factory/tfn_scalar_tensor.py:103-195; atomic=True: tfn_atomic_tensor.py:103-199 (the node
+    head maps straight to the Cartesian-tensor irreps, no pooling)."""
     layers = {
         "one_hot": (
             rnn.SpeciesEmbedding,
@@ -79,6 +81,12 @@ def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any]) -> rn
             "avg_num_neighbors": num_neigh,
         },
     )
+    if atomic:
+        layers["conv_to_output_hidden"] = (
+            rnn.NodewiseLinear,
+            {"irreps_out": CartesianTensor(formula=hparams["output_formula"].lower()), "out_field": OUT_FIELD_NAME},
+        )
+        return create_sequential_module(OrderedDict(layers))
     layers["conv_to_output_hidden"] = (
         rnn.NodewiseLinear,
         {"irreps_out": hparams["conv_to_output_hidden_irreps_out"], "out_field": OUT_FIELD_NAME},
@@ -117,6 +125,27 @@ class ScalarTensorOracle(torch.nn.Module):
     def decode(self, model_input: Dict[str, torch.Tensor]) -> torch.Tensor:
         out = self.backbone(model_input)[OUT_FIELD_NAME]
         out = self.extra_layers_dict["out_layer"](out)
+        if self.to_cartesian is not None:
+            out = self.to_cartesian(out)
+        return out
+
+    forward = decode
+
+
+class AtomicTensorOracle(torch.nn.Module):
+    """AtomicTensorModel (model_factory/tfn_atomic_tensor.py:31-77): one tensor per atom, no out_layer."""
+
+    def __init__(self, backbone_hparams: Dict[str, Any], dataset_hparams: Dict[str, Any]):
+        super().__init__()
+        self.backbone = create_model(backbone_hparams, dataset_hparams, atomic=True)
+        formula = backbone_hparams["output_formula"].lower()
+        if backbone_hparams["output_format"] == "cartesian" and formula != "scalar":
+            self.to_cartesian = ToCartesian(formula)
+        else:
+            self.to_cartesian = None
+
+    def decode(self, model_input: Dict[str, torch.Tensor]) -> torch.Tensor:
+        out = self.backbone(model_input)[OUT_FIELD_NAME]
         if self.to_cartesian is not None:
             out = self.to_cartesian(out)
         return out

@@ -447,3 +447,44 @@ def test_species_linear_shape_sweep():
             worst[("mi", mi, l)] = _species_linear_case(f"{mi}x{ir}+3x0e", f"5x{ir}+2x0e", 3, 50, bool(mi % 2), gen)
     bad = {k: v for k, v in worst.items() if not v < 2e-6}
     assert not bad, f"{len(bad)} of {len(worst)} shapes off: {sorted(bad.items(), key=lambda kv: -kv[1])[:8]}"
+
+
+def test_atomic_tensor_model_vs_oracle_and_predict(tmp_path, golden_dir):
+    """AtomicTensorModel (model_factory/tfn_atomic_tensor.py) -- per-atom ij=ji tensors against
+    the oracle on the n=100 sample, the atom_selector step of the reference's shared_step, and
+    predict(is_atomic_tensor=True) returning one flat list of per-atom tensors (predict.py:196-242)."""
+    import yaml
+
+    from common import ATOMIC
+    from matten_amd import predict as P
+    from matten_amd.data.graph import average_num_neighbors, collate, crystal_graph
+    from oracle.matten_ref import data as rdata
+    from oracle.matten_ref.model import ToCartesian
+
+    structs = rdata.structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))[:12]
+    graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
+    ds = {"allowed_species": sorted({int(z) for s in structs for z in s["atomic_numbers"]}),
+          "average_num_neighbors": average_num_neighbors(graphs)}
+    ref, model = build_pair(dict(ATOMIC), ds, randomize_bn=True, atomic=True)
+    cpu = collate(graphs)
+    with torch.no_grad():
+        want = ref.decode(cpu)
+        preds, labels = model(dict(collate(graphs, device=DEV), atom_selector=(cpu["atomic_numbers"] % 2 == 0).to(DEV)),
+                              task_name="nmr_tensor")
+    got = preds["nmr_tensor"]
+    assert got.shape == (cpu["pos"].shape[0], 6)
+    close(got, want, RTOL, "per-atom irreps")
+    sel = model.select_atoms(preds, labels)["nmr_tensor"]
+    assert sel.shape[0] == int((cpu["atomic_numbers"] % 2 == 0).sum()) and "atom_selector" in labels
+    close(sel, want[cpu["atomic_numbers"] % 2 == 0], RTOL, "selected atoms")
+
+    torch.save({"state_dict": model.state_dict(),
+                "hyper_parameters": {"backbone_hparams": dict(ATOMIC), "dataset_hparams": ds, "tasks": "nmr_tensor"}},
+               tmp_path / "model_final.ckpt")
+    cfg = {"data": {"r_cut": 5.0, "tensor_target_name": "nmr_tensor", "tensor_target_formula": "ij=ji"}}
+    (tmp_path / "config_final.yaml").write_text(yaml.safe_dump(cfg))
+    out = P.predict(structs, model_identifier=str(tmp_path), is_atomic_tensor=True, batch_size=5)
+    assert len(out) == cpu["pos"].shape[0] and out[0].shape == (3, 3)
+    close(torch.as_tensor(np.stack(out)), ToCartesian("ij=ji")(want), RTOL, "predict() per-atom Cartesian tensors")
+    one = P.predict(structs[0], model_identifier=str(tmp_path), is_atomic_tensor=True)
+    assert isinstance(one, list) and len(one) == len(structs[0]["atomic_numbers"])

@@ -242,3 +242,36 @@ def test_lmax2_head_zero_fills_unreachable_4e():
     with torch.no_grad():
         y = m.decode(rdata.collate(graphs))
     assert y.shape == (1, 21) and torch.all(y[:, 12:] == 0) and y[:, :12].abs().max() > 0
+
+
+def test_atomic_tensor_oracle_is_equivariant_per_atom(golden_dir):
+    """AtomicTensorModel (reference model_factory/tfn_atomic_tensor.py, config scripts/configs/atomic_tensor.yaml):
+    one symmetric 2-tensor per atom, irreps 0e+2e; rotating the crystal rotates every atom's tensor
+    (the property the reference checks for the crystal-level model, tests/model/test_tfn_tensor.py:98-139)."""
+    from common import ATOMIC
+    from oracle.e3nn_lite import o3
+    from oracle.matten_ref.model import AtomicTensorOracle, ToCartesian
+
+    s = rdata.structures_from_json(os.path.join(golden_dir, "elastic_tensor_one.json"))[0]
+    torch.manual_seed(35)
+    Q = o3.rand_matrix()
+    hp = dict(ATOMIC, normalization=None, output_format="cartesian")
+    ds = {"allowed_species": sorted(set(int(z) for z in s["atomic_numbers"])), "average_num_neighbors": 30.0}
+    m = AtomicTensorOracle(hp, ds).eval()
+    g1 = rdata.crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0)
+    g2 = rdata.crystal_graph(s["cart_coords"] @ Q.numpy().T, s["lattice"] @ Q.numpy().T, s["atomic_numbers"], 5.0)
+    with torch.no_grad():
+        t1 = m(rdata.collate([g1]))
+        t2 = m(rdata.collate([g2]))
+    n = len(s["atomic_numbers"])
+    assert t1.shape == (n, 3, 3) and t1.abs().max() > 1e-3
+    assert torch.allclose(t1, t1.transpose(1, 2), atol=1e-6)
+    want = torch.einsum("ia,jb,nab->nij", Q.to(t1.dtype), Q.to(t1.dtype), t1)
+    assert torch.allclose(t2, want, atol=1e-4), (t2 - want).abs().max()
+    # irreps output: 0e + 2e = 6 numbers per atom, and ToCartesian maps them onto the same tensors
+    m_ir = AtomicTensorOracle(dict(hp, output_format="irreps"), ds).eval()
+    m_ir.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        ir = m_ir(rdata.collate([g1]))
+    assert ir.shape == (n, 6)
+    assert torch.allclose(ToCartesian("ij=ji")(ir), t1, atol=1e-6)
