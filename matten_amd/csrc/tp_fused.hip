@@ -90,9 +90,12 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
     const int xcol = ge.x_off + u * G::D1;
     // A operand (the entry's weight columns, <= 64 by construction of the plan) stays in registers for the
     // whole CSR walk: av[mt][kk] = W2p[pi(kk,g)][w_base + 16*mt + c]
-    float av[4][8];
+    // MTMAX: the plan caps an entry at the largest power-of-two channel count whose [u][c] block fits 64 columns
+    constexpr int CAPC = NC > 32 ? 1 : NC > 16 ? 2 : NC > 8 ? 4 : NC > 4 ? 8 : NC > 2 ? 16 : NC > 1 ? 32 : 64;
+    constexpr int MTMAX = (CAPC * NC + 15) / 16;
+    float av[MTMAX][8];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MTMAX; ++mt) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
@@ -142,7 +145,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
                 }
 #ifndef MATTEN_ABLATE_NO_MFMA
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MTMAX; ++mt) {
                     if (mt < MT) {
                         f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
