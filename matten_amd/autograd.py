@@ -15,6 +15,22 @@ import torch
 from . import ops
 
 
+class PackWeightsFn(torch.autograd.Function):
+    """packed[s, j] = weight[gather[s, j]] * scale[j] with ``gather`` a bijection between the flat e3nn parameter and
+    the packed per-species table.  The generic index backward sorts the indices (nine small rocPRIM launches per
+    module and step); a bijection needs only the inverse permutation."""
+
+    @staticmethod
+    def forward(ctx, weight, gather, scale, inverse):
+        ctx.save_for_backward(scale, inverse)
+        return (weight[gather] * scale).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, inverse = ctx.saved_tensors
+        return (g * scale).reshape(-1)[inverse], None, None, None
+
+
 class SpeciesLinearFn(torch.autograd.Function):
     """out = add + x W_species  (matten_species_linear); adjoints: same kernel with W^T, and the weight-gradient kernel."""
 

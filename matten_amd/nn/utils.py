@@ -31,6 +31,17 @@ ACTIVATION = {"e": {"ssp": "ssp", "silu": "silu", "sigmoid": "sigmoid"}, "o": {"
 tp_path_exists = _plan.tp_path_exists
 
 
+def _inverse_permutation(gather):
+    """flat parameter index -> position in the packed [S, w_stride] table (gather is a bijection, see plan.py)"""
+    import numpy as np
+
+    g = np.asarray(gather).reshape(-1)
+    assert g.size == 0 or (np.sort(g) == np.arange(g.size)).all(), "packed weight table is not a permutation"
+    inv = np.empty_like(g)
+    inv[g] = np.arange(g.size, dtype=g.dtype)
+    return inv
+
+
 class SpeciesLinear(torch.nn.Module):
     """out[n] = sum_u W[u, species(n), w] x[n,u] / sqrt(fan_in), per irrep; flat ``weight`` as in e3nn."""
 
@@ -45,6 +56,7 @@ class SpeciesLinear(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.randn(self.plan.weight_numel))
         self._tables = DeviceTables(
             gather=self.plan.gather, scale=self.plan.scale, perm_t=self.plan.perm_t,
+            gather_inv=_inverse_permutation(self.plan.gather),
             **{f"meta{i}": m for i, m in enumerate(self.plan.passes)},
             **{f"meta_t{i}": m for i, m in enumerate(self.plan.passes_t)},
         )
@@ -61,7 +73,8 @@ class SpeciesLinear(torch.nn.Module):
         order = species_order if self.n_species is not None else None
         if _ag.needs_grad(x, self.weight, add):
             # training path: the re-packing (index + scale) is differentiable, the linear is the HIP Function
-            wp = self._pack(self.weight)
+            wp = _ag.PackWeightsFn.apply(self.weight, self._tables.get("gather", x.device),
+                                         self._tables.get("scale", x.device), self._tables.get("gather_inv", x.device))
             return _ag.SpeciesLinearFn.apply(x, wp, add, self, order)
         wp = self._packed.get(self.weight)
         metas = [self._tables.get(f"meta{i}", x.device) for i in range(len(self.plan.passes))]

@@ -17,9 +17,12 @@ species = sorted({int(z) for s in structs for z in s["atomic_numbers"]})
 ds = {"allowed_species": species, "average_num_neighbors": average_num_neighbors(graphs)}
 torch.manual_seed(3)
 model = ScalarTensorModel(backbone_hparams=dict(LMAX2), dataset_hparams=ds).to("cuda:0").train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=1e-5)
-batches = [collate(graphs[i:i + 32], device="cuda:0") for i in range(0, 96, 32)]
-targets = [torch.randn(32, 21, device="cuda:0") for _ in batches]
+FUSED = os.environ.get("ADAM", "fused") == "fused"   # one multi-tensor kernel for all 60-odd parameters
+opt = torch.optim.Adam(model.parameters(), lr=1e-2, weight_decay=1e-5, fused=FUSED)
+BS = int(os.environ.get("BATCH", "32"))
+pool = [graphs[i % len(graphs)] for i in range(3 * BS)]
+batches = [collate(pool[i:i + BS], device="cuda:0") for i in range(0, 3 * BS, BS)]
+targets = [torch.randn(BS, 21, device="cuda:0") for _ in batches]
 def step(b, t):
     preds, _ = model(dict(b))
     loss = torch.nn.functional.mse_loss(preds["elastic_tensor_full"], t)
@@ -32,4 +35,5 @@ for _ in range(10):
     for b, t in zip(batches, targets): loss = step(b, t); n += 1
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 nodes = sum(int(b["pos"].shape[0]) for b in batches) / len(batches); edges = sum(int(b["edge_index"].shape[1]) for b in batches) / len(batches)
-print(f"training step (batch 32 crystals, {nodes:.0f} nodes, {edges:.0f} edges avg): {dt*1e3:.2f} ms/step, {32/dt:.0f} crystals/s, final loss {loss.item():.4f}")
+print(f"training step (batch {BS} crystals, {nodes:.0f} nodes, {edges:.0f} edges avg, Adam {'fused' if FUSED else 'per-tensor'}): "
+      f"{dt*1e3:.2f} ms/step, {BS/dt:.0f} crystals/s, final loss {loss.item():.4f}")
