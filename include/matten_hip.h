@@ -260,17 +260,21 @@ int matten_segment_reduce_bwd(const float* dy, int64_t dim, const int64_t* ptr, 
  * data/data.py:285-413, i.e. ase.neighborlist.primitive_neighbor_list("ijS") + the self-edge filter).
  *   edges = all (i, j, S): | pos[j] + S.cell - pos[i] | < r_cut (strict, fp64), (i==j, S==0) excluded,
  *   emitted in lexicographic order (i, j, Sx, Sy, Sz); i, j are GLOBAL node ids (ptr-offset applied).
- *   pos[N,3] fp64; cell[B,9] fp64 (rows = lattice vectors); ptr[B+1], batch[N] int64;
+ *   pos[N,3] fp64; cell[B,9] fp64 (rows = lattice vectors); ptr[B+1] int64;
  *   reach[B,3] int32 = number of periodic images to scan along each lattice direction.
- * Two passes: matten_neighbor_count -> counts[N]; the caller scans them into offsets[N] (exclusive) and
- * n_edges; matten_neighbor_fill writes edge_index[2,n_edges] (int64) and edge_cell_shift[n_edges,3] (fp32).
+ *   pair_ptr[B+1] int64 = running sum of n_b^2: ordered atom pairs are numbered crystal by crystal, i-major.
+ * Two passes: matten_neighbor_count -> counts[pair_ptr[B]] (edges of each ordered pair (i, j)); the caller scans
+ * them into offsets (exclusive) and n_edges; matten_neighbor_fill writes edge_index[2,n_edges] (int64) and
+ * edge_cell_shift[n_edges,3] (fp32).  num_neigh[i] = sum of the counts of atom i's n_b pairs.
+ * max_atoms = largest n_b; at most 65535 crystals per call.
  * ========================================================================================== */
 int matten_neighbor_count(const double* pos, const double* cell, const int64_t* ptr, const int32_t* reach,
-                          const int64_t* batch, double r_cut, int64_t n_nodes, int32_t* counts,
+                          const int64_t* pair_ptr, double r_cut, int64_t n_crystals, int64_t max_atoms, int32_t* counts,
                           matten_stream_t stream);
 int matten_neighbor_fill(const double* pos, const double* cell, const int64_t* ptr, const int32_t* reach,
-                         const int64_t* batch, double r_cut, int64_t n_nodes, const int64_t* offsets, int64_t n_edges,
-                         int64_t* edge_index, float* edge_cell_shift, matten_stream_t stream);
+                         const int64_t* pair_ptr, double r_cut, int64_t n_crystals, int64_t max_atoms,
+                         const int64_t* offsets, int64_t n_edges, int64_t* edge_index, float* edge_cell_shift,
+                         matten_stream_t stream);
 
 #ifdef __cplusplus
 }

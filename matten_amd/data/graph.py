@@ -116,34 +116,59 @@ def batch_graphs_gpu(structures: Sequence, r_cut: float, device="cuda", y: Optio
                      ) -> Dict[str, torch.Tensor]:
     """Crystals -> collated batch, with the neighbour search on the GPU (matten_neighbor_count/_fill).
 
-    ``structures`` is a sequence of (pos [n,3], cell [3,3], atomic_numbers [n]) triples.  The result has exactly
-    the keys, dtypes and edge order of ``collate([crystal_graph(...) ...], device)``; only the positions, cells
-    and species cross PCIe (fp64 for the distance test, as in the host builder).  A crystal without any edge
-    raises ValueError, like the reference (data/data.py:398-402)."""
-    from .. import ops
-
+    ``structures`` is a sequence of (pos [n,3], cell [3,3], atomic_numbers [n]) triples; they are packed into the
+    flat struct-of-arrays form of ``batch_graphs_gpu_soa``, which callers that already hold their crystals as
+    arrays should use directly (no per-structure Python work)."""
     sizes = np.array([len(s[0]) for s in structures], dtype=np.int64)
     ptr = np.zeros(len(structures) + 1, dtype=np.int64)
     np.cumsum(sizes, out=ptr[1:])
     pos = np.concatenate([np.asarray(s[0], dtype=np.float64).reshape(-1, 3) for s in structures])
     cell = np.stack([np.asarray(s[1], dtype=np.float64).reshape(3, 3) for s in structures])
     Z = np.concatenate([np.asarray(s[2], dtype=np.int64).reshape(-1) for s in structures])
-    batch = np.repeat(np.arange(len(structures), dtype=np.int64), sizes)
+    return batch_graphs_gpu_soa(pos, cell, Z, ptr, r_cut, device, y)
+
+
+def batch_graphs_gpu_soa(pos: np.ndarray, cell: np.ndarray, Z: np.ndarray, ptr: np.ndarray, r_cut: float,
+                         device="cuda", y: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """Flat batch (pos [N,3] fp64, cell [B,3,3] fp64, Z [N] int64, ptr [B+1] int64) ->
+    collated graph batch on the device.
+
+    The result has exactly the keys, dtypes and edge order of ``collate([crystal_graph(...) ...], device)``; only
+    positions, cells and species cross PCIe (fp64 for the distance test, as in the host builder).  A crystal without
+    any edge raises ``EdgelessStructures`` (a ValueError, like the reference data/data.py:398-402)."""
+    from .. import ops
+
+    pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+    cell = np.ascontiguousarray(cell, dtype=np.float64).reshape(-1, 3, 3)
+    Z = np.ascontiguousarray(Z, dtype=np.int64).reshape(-1)
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    sizes = np.diff(ptr)
+    n_crystals = len(sizes)
+    if n_crystals > 65535:  # blockIdx.y of the neighbour kernels
+        raise ValueError("at most 65535 crystals per batch_graphs_gpu call")
+    batch = np.repeat(np.arange(n_crystals, dtype=np.int64), sizes)
     # image_reach for all crystals at once
     inv = np.linalg.inv(cell)
     ib = inv[batch]
     frac = pos[:, 0:1] * ib[:, 0] + pos[:, 1:2] * ib[:, 1] + pos[:, 2:3] * ib[:, 2]
     span = np.maximum.reduceat(frac, ptr[:-1]) - np.minimum.reduceat(frac, ptr[:-1])
     reach = np.ceil(float(r_cut) * np.linalg.norm(inv, axis=1) + span).astype(np.int32)
+    pair_ptr = np.zeros(n_crystals + 1, dtype=np.int64)
+    np.cumsum(sizes * sizes, out=pair_ptr[1:])
+    # first ordered pair of every atom (pairs of a crystal are numbered i-major): its edges are contiguous
+    atom_pair0 = pair_ptr[:-1][batch] + (np.arange(len(batch)) - ptr[:-1][batch]) * sizes[batch]
 
     dev = torch.device(device)
     pos_d = torch.from_numpy(pos).to(dev)
     cell_d = torch.from_numpy(cell.reshape(-1, 9)).to(dev)
     ptr_d = torch.from_numpy(ptr).to(dev)
     batch_d = torch.from_numpy(batch).to(dev)
-    edge_index, shifts, counts = ops.neighbor_list(pos_d, cell_d, ptr_d, torch.from_numpy(reach).to(dev), batch_d,
-                                                   r_cut)
-    per_crystal = torch.zeros(len(structures), dtype=torch.int64, device=dev).index_add_(0, batch_d, counts.long())
+    edge_index, shifts, pair_off = ops.neighbor_list(pos_d, cell_d, ptr_d, torch.from_numpy(reach).to(dev),
+                                                     torch.from_numpy(pair_ptr).to(dev), r_cut, int(sizes.max()),
+                                                     int(pair_ptr[-1]))
+    first = pair_off[torch.from_numpy(np.append(atom_pair0, pair_ptr[-1])).to(dev)]
+    counts = first[1:] - first[:-1]                       # edges per centre atom
+    per_crystal = first[ptr_d[1:]] - first[ptr_d[:-1]]
     empty = torch.nonzero(per_crystal == 0).flatten().tolist()
     if empty:
         raise EdgelessStructures(empty)

@@ -419,33 +419,34 @@ def segment_reduce_bwd(dy, ptr, n_rows: int, mean: bool) -> torch.Tensor:
     return dx
 
 
-def neighbor_list(pos64, cell64, ptr, reach, batch, r_cut: float):
+def neighbor_list(pos64, cell64, ptr, reach, pair_ptr, r_cut: float, max_atoms: int, n_pairs: int):
     """Periodic neighbour list of a batch of crystals, canonical (i, j, Sx, Sy, Sz) order.
-    -> (edge_index [2,E] i64 (global ids), edge_cell_shift [E,3] f32, counts [N] i32)"""
+    pair_ptr[B+1] = running sum of n_b^2 (ordered pairs numbered crystal by crystal, i-major), n_pairs = pair_ptr[B].
+    -> (edge_index [2,E] i64 (global ids), edge_cell_shift [E,3] f32, pair_offsets [n_pairs+1] i64)"""
     lib = _lib.load()
     pos64 = _need(pos64, torch.float64, "pos")
     cell64 = _need(cell64, torch.float64, "cell")
     ptr = _need(ptr, torch.int64, "ptr")
     reach = _need(reach, torch.int32, "reach")
-    batch = _need(batch, torch.int64, "batch")
-    N = pos64.shape[0]
+    pair_ptr = _need(pair_ptr, torch.int64, "pair_ptr")
+    B = ptr.shape[0] - 1
     dev = pos64.device
-    counts = torch.empty(N, dtype=torch.int32, device=dev)
+    counts = torch.empty(n_pairs, dtype=torch.int32, device=dev)
     with _timed("neighbor_count"):
         _lib.check(
-            lib.matten_neighbor_count(_ptr(pos64), _ptr(cell64), _ptr(ptr), _ptr(reach), _ptr(batch), float(r_cut), N,
-                                      _ptr(counts), _stream()),
+            lib.matten_neighbor_count(_ptr(pos64), _ptr(cell64), _ptr(ptr), _ptr(reach), _ptr(pair_ptr), float(r_cut), B,
+                                      int(max_atoms), _ptr(counts), _stream()),
             "matten_neighbor_count",
         )
-    incl = torch.cumsum(counts, 0, dtype=torch.int64)
-    E = int(incl[-1]) if N else 0  # the one host sync of graph construction: the edge count sizes the outputs
-    offsets = incl - counts
+    offsets = torch.zeros(n_pairs + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, dtype=torch.int64, out=offsets[1:])
+    E = int(offsets[-1]) if n_pairs else 0  # the one host sync of graph construction: the edge count sizes the outputs
     edge_index = torch.empty(2, E, dtype=torch.int64, device=dev)
     shifts = torch.empty(E, 3, dtype=torch.float32, device=dev)
     with _timed("neighbor_fill"):
         _lib.check(
-            lib.matten_neighbor_fill(_ptr(pos64), _ptr(cell64), _ptr(ptr), _ptr(reach), _ptr(batch), float(r_cut), N,
-                                     _ptr(offsets), E, _ptr(edge_index), _ptr(shifts), _stream()),
+            lib.matten_neighbor_fill(_ptr(pos64), _ptr(cell64), _ptr(ptr), _ptr(reach), _ptr(pair_ptr), float(r_cut), B,
+                                     int(max_atoms), _ptr(offsets), E, _ptr(edge_index), _ptr(shifts), _stream()),
             "matten_neighbor_fill",
         )
-    return edge_index, shifts, counts
+    return edge_index, shifts, offsets
