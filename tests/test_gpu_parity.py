@@ -488,3 +488,52 @@ def test_atomic_tensor_model_vs_oracle_and_predict(tmp_path, golden_dir):
     close(torch.as_tensor(np.stack(out)), ToCartesian("ij=ji")(want), RTOL, "predict() per-atom Cartesian tensors")
     one = P.predict(structs[0], model_identifier=str(tmp_path), is_atomic_tensor=True)
     assert isinstance(one, list) and len(one) == len(structs[0]["atomic_numbers"])
+
+
+def test_config3_full_size_batch_properties():
+    """BASELINE configs[2] at its full size (1000 fcc-64 crystals, 64 000 atoms, 1 152 000 edges -- the bench workload),
+    checked through size-independent properties: (a) a crystal's prediction does not depend on what else is in the
+    batch (bitwise: the per-node summation order is fixed), which ties the full-size run to the 8-crystal batches the
+    oracle can afford; (b) the oracle itself on 6 crystals picked from the big batch; (c) permuting the crystals
+    permutes the rows; (d) rotating every crystal rotates every elasticity tensor; (e) bitwise determinism."""
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import batch_graphs_gpu, collate, crystal_graph
+    from oracle.e3nn_lite import o3
+    from oracle.matten_ref.model import ToCartesian
+
+    n = 1000
+    structs = synthetic.fcc64_structures(n)
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    ref, model = build_pair(PAPER, ds, randomize_bn=True)
+    triples = [(s["cart_coords"], s["lattice"], s["atomic_numbers"]) for s in structs]
+    big = batch_graphs_gpu(triples, 5.0, DEV)
+    assert big["pos"].shape[0] == 64 * n and big["edge_index"].shape[1] == 1152 * n
+    with torch.no_grad():
+        y = model.decode(dict(big))["elastic_tensor_full"]
+        y_again = model.decode(dict(big))["elastic_tensor_full"]
+    assert y.shape == (n, 21) and torch.isfinite(y).all()
+    assert torch.equal(y, y_again)                                                   # (e)
+
+    pick = [0, 1, 137, 500, 998, 999]
+    small = batch_graphs_gpu([triples[i] for i in pick], 5.0, DEV)
+    with torch.no_grad():
+        y_small = model.decode(dict(small))["elastic_tensor_full"]
+        want = ref.decode(collate([crystal_graph(*triples[i], 5.0) for i in pick]))
+    assert torch.equal(y[pick], y_small)                                             # (a)
+    close(y[pick], want, RTOL, "full-size batch vs oracle on 6 crystals")            # (b)
+
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).tolist()
+    with torch.no_grad():
+        y_perm = model.decode(dict(batch_graphs_gpu([triples[i] for i in perm], 5.0, DEV)))["elastic_tensor_full"]
+    assert torch.equal(y_perm, y[perm])                                              # (c)
+
+    torch.manual_seed(35)
+    Q = o3.rand_matrix().double().numpy()
+    rotated = [(p @ Q.T, c @ Q.T, z) for (p, c, z) in triples]
+    with torch.no_grad():
+        y_rot = model.decode(dict(batch_graphs_gpu(rotated, 5.0, DEV)))["elastic_tensor_full"]
+    to_cart = ToCartesian("ijkl=jikl=klij")
+    t, t_rot = to_cart(y.cpu()), to_cart(y_rot.cpu())
+    Qt = torch.as_tensor(Q, dtype=t.dtype)
+    want_rot = torch.einsum("ia,jb,kc,ld,nabcd->nijkl", Qt, Qt, Qt, Qt, t)
+    close(t_rot, want_rot, 5e-4, "rotation equivariance of 1000 crystals")           # (d)
