@@ -13,7 +13,7 @@ all_gather_into_tensor of the [B,21] predictions (configs[4]).  value = edge ten
 all ranks: one edge-TP = one (edge, conv layer) evaluation, 4 conv layers => 4 per edge per forward.
 
 Printed by rank 0: one JSON line with the driver contract fields plus
-  "roofline"     -- the dominant kernel (last conv layer's TP+scatter) against the HBM roofline
+  "roofline"     -- the dominant kernel (tp_fused_kernel, mean over its launches) against the HBM roofline
   "cpu_baseline" -- the CPU oracle (a restatement of the reference's e3nn path, NOT e3nn itself;
                     e3nn cannot be installed on either box) timed on a bounded sample, rank 0, N=1
 """
@@ -44,12 +44,13 @@ def parse():
     return ap.parse_args()
 
 
-def _pmc_traffic(kernel: str):
+def _pmc_traffic(kernel: str, field: str = "hbm_bytes_mean_launch"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC run (profiles/hbm_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes, gfx950 x2 correction on FETCH_SIZE), or None."""
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, gfx950 x2 correction on FETCH_SIZE), or None.
+    'hbm_bytes_mean_launch' averages over the kernel's launches of a forward, 'hbm_bytes_per_launch' is the largest."""
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            return float(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"])
+            return float(json.load(f)["kernels"][kernel][field])
     except Exception:
         return None
 
@@ -160,17 +161,21 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: TP + scatter of the last conv layer ----
-        last = model.backbone.conv_layer_last.tp.plan
+        # ---- roofline of the dominant kernel, tp_fused_kernel, averaged over its launches of the timed region (one per
+        # conv layer and step) -- the same average rocprofv3 --stats reports for the kernel ----
         deg = n_edges / n_nodes
-        key = f"tp_scatter/d_mid={last.d_mid}"
         per_kernel = {k: sum(v) / len(v) for k, v in kernel_ms.items()}
-        if key in per_kernel:
-            dur_s = per_kernel[key] * 1e-3
-            bytes_per_launch = algorithmic_bytes_tp_kernel(last, deg) * n_edges
-            achieved = bytes_per_launch / dur_s / 1e9
+        tp_plans = [m.tp.plan for m in model.backbone.modules() if hasattr(m, "tp") and hasattr(m.tp, "plan")]
+        tp_keys = [f"tp_scatter/d_mid={p.d_mid}" for p in tp_plans]
+        if tp_plans and all(k in per_kernel for k in tp_keys):
+            layer_bytes = [algorithmic_bytes_tp_kernel(p, deg) * n_edges for p in tp_plans]
+            layer_ms = [per_kernel[k] for k in tp_keys]
+            bytes_per_launch = sum(layer_bytes) / len(layer_bytes)
+            avg_ms = sum(layer_ms) / len(layer_ms)
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             result["roofline"] = {
-                "kernel": "tp_fused_kernel (conv_layer_last: radial GEMM + 103 CG paths + neighbour sum, d_mid 4170)",
+                "kernel": f"tp_fused_kernel (radial GEMM + CG paths + neighbour sum; mean over its {len(tp_plans)} launches "
+                          "per forward, one per conv layer)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK / 1e9,
@@ -178,7 +183,13 @@ def main():
                 "frac": achieved / (HBM_PEAK / 1e9),
                 "traffic": _pmc_traffic("tp_fused_kernel"),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "avg_launch_ms": per_kernel[key],
+                "avg_launch_ms": avg_ms,
+                "per_layer": [
+                    {"d_mid": p.d_mid, "weight_numel": p.weight_numel, "ms": ms, "algorithmic_bytes": by,
+                     "achieved_GBps": by / (ms * 1e-3) / 1e9}
+                    for p, ms, by in zip(tp_plans, layer_ms, layer_bytes)
+                ],
+                "last_layer_traffic": _pmc_traffic("tp_fused_kernel", "hbm_bytes_per_launch"),
             }
         result["kernel_ms_per_launch"] = per_kernel
         result["path_roofline"] = {

@@ -27,6 +27,8 @@ for k, d in res.items():
         # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2 (guide, section HBM)
         out[k] = {"fetch_kb_raw_max": d["FETCH_SIZE"]["max_kb"], "write_kb_max": d["WRITE_SIZE"]["max_kb"],
                   "hbm_bytes_max_launch": 2 * 1024 * d["FETCH_SIZE"]["max_kb"] + 1024 * d["WRITE_SIZE"]["max_kb"],
+                  "fetch_kb_raw_mean": d["FETCH_SIZE"]["mean_kb"], "write_kb_mean": d["WRITE_SIZE"]["mean_kb"],
+                  "hbm_bytes_mean_launch": 2 * 1024 * d["FETCH_SIZE"]["mean_kb"] + 1024 * d["WRITE_SIZE"]["mean_kb"],
                   "launches": d["FETCH_SIZE"]["launches"]}
 json.dump(out, open(f"{R}/gpurun_out/traffic_{TAG}.json", "w"), indent=1)
 for k, v in out.items():
