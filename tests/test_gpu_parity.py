@@ -537,3 +537,25 @@ def test_config3_full_size_batch_properties():
     Qt = torch.as_tensor(Q, dtype=t.dtype)
     want_rot = torch.einsum("ia,jb,kc,ld,nabcd->nijkl", Qt, Qt, Qt, Qt, t)
     close(t_rot, want_rot, 5e-4, "rotation equivariance of 1000 crystals")           # (d)
+
+
+def test_operands_beyond_4GB():
+    """Maximum sizes: with 4200 fcc-64 crystals the neighbour-sum output of the last conv layer is 4.5 GB, past the
+    4 GB a buffer descriptor / 32-bit byte offset can address (species_linear re-bases its descriptors per wave,
+    the TP kernels use 64-bit row offsets).  Property: predictions are bitwise those of a 4-crystal batch."""
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import batch_graphs_gpu
+
+    n = 4200
+    uniq = synthetic.fcc64_structures(100)
+    triples = [(uniq[i % 100]["cart_coords"], uniq[i % 100]["lattice"], uniq[i % 100]["atomic_numbers"]) for i in range(n)]
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    _, model = build_pair(PAPER, ds, randomize_bn=True)
+    assert 64 * n * model.backbone.conv_layer_last.tp.plan.d_mid * 4 > 2**32
+    with torch.no_grad():
+        y = model.decode(dict(batch_graphs_gpu(triples, 5.0, DEV)))["elastic_tensor_full"]
+        pick = [0, 1, n // 2, n - 1]
+        ys = model.decode(dict(batch_graphs_gpu([triples[i] for i in pick], 5.0, DEV)))["elastic_tensor_full"]
+    assert torch.isfinite(y).all() and torch.equal(y[pick], ys)
+    # copies of one crystal give identical rows wherever they sit in the batch
+    assert torch.equal(y[0], y[100]) and torch.equal(y[7], y[4107])
