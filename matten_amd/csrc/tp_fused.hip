@@ -30,7 +30,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TILE_NODES = 32;
+constexpr int TILE_NODES = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int N_XCD = 8;
 constexpr int MAXC = matten::GROUP_MAX_COMBOS;

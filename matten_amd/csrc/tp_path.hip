@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int TILE_NODES = 32;
+constexpr int TILE_NODES = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int N_XCD = 8;
 

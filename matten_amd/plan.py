@@ -21,7 +21,7 @@ import numpy as np
 
 from .o3 import Irrep, Irreps, wigner_3j
 
-TP_TILE_NODES = 32  # must equal matten_tp_tile_nodes() of the library (checked at first use)
+TP_TILE_NODES = 64  # must equal matten_tp_tile_nodes() of the library (checked at first use)
 
 # l2 ranges fused per input-block degree l1; must match GROUPS in matten_amd/csrc/gen_cg.py
 _GROUP_SCHEMES = {
