@@ -1,4 +1,4 @@
-"""Node-wise output head on MI355X (mirrors reference nn/nodewise.py:89-148)."""
+"""Node-wise output head on MI355X (mirrors reference nn/nodewise.py:18-148)."""
 from typing import Dict, Optional
 
 import torch
@@ -8,6 +8,31 @@ from ..data.irreps import DataKey, ModuleIrreps
 from ..o3 import Irreps
 from ._nequip import with_batch
 from .utils import SpeciesLinear
+
+
+class NodewiseSelect(ModuleIrreps, torch.nn.Module):
+    """Select node features by a boolean mask (reference nn/nodewise.py:18-86): ``data[out_field] =
+    data[field][data[mask_field]]``; without a mask field the features are passed through.  Pure row indexing --
+    torch's device indexing is the plumbing here, no arithmetic."""
+
+    def __init__(self, irreps_in: Dict[str, Irreps], field: str = DataKey.NODE_FEATURES,
+                 out_field: Optional[str] = None, mask_field: Optional[str] = None):
+        super().__init__()
+        self.field = field
+        self.out_field = out_field if out_field is not None else field
+        self.mask_field = mask_field
+        self.init_irreps(irreps_in=irreps_in, irreps_out={self.out_field: irreps_in[self.field]},
+                         required_keys_irreps_in=[self.field])
+
+    def forward(self, data: DataKey.Type) -> DataKey.Type:
+        data = data.copy()  # shallow copy so the input dict is not modified (reference nodewise.py:64-65)
+        value = data[self.field]
+        data[self.out_field] = value if self.mask_field is None else value[data[self.mask_field]]
+        return data
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(\n  field: {self.field}, out_field: {self.out_field}, out field irreps: "
+                f"{self.irreps_out[self.out_field]}\n)")
 
 
 class NodewiseLinear(ModuleIrreps, torch.nn.Module):

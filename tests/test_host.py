@@ -235,3 +235,20 @@ def test_predict_api_surface():
         [{"lattice": 3.0 * np.eye(3), "cart_coords": np.zeros((1, 3)), "atomic_numbers": [14]},
          {"lattice": 50.0 * np.eye(3), "cart_coords": np.zeros((1, 3)), "atomic_numbers": [14]}], 5.0)
     assert len(graphs) == 1 and failed == [1]
+
+
+def test_nodewise_select_known_answer():
+    """reference tests/nn/test_nodewise.py:7-30, verbatim scenario"""
+    from matten_amd.data.irreps import DataKey
+    from matten_amd.nn.nodewise import NodewiseSelect
+
+    node_feats, mask_field, out_field = DataKey.NODE_FEATURES, "node_masks", "selected_node_features"
+    aws = NodewiseSelect(irreps_in={node_feats: None, mask_field: None}, field=node_feats, out_field=out_field,
+                         mask_field=mask_field)
+    n_atoms = 5
+    data = {node_feats: torch.arange(n_atoms * 2).reshape(n_atoms, 2),
+            mask_field: torch.tensor([True, False, True, True, False])}
+    out = aws(data)
+    assert torch.allclose(out[out_field], data[node_feats][data[mask_field]])
+    assert out_field not in data  # the input dict is left alone
+    assert torch.equal(NodewiseSelect(irreps_in={node_feats: None}, field=node_feats)(data)[node_feats], data[node_feats])
