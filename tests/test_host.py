@@ -252,3 +252,46 @@ def test_nodewise_select_known_answer():
     assert torch.allclose(out[out_field], data[node_feats][data[mask_field]])
     assert out_field not in data  # the input dict is left alone
     assert torch.equal(NodewiseSelect(irreps_in={node_feats: None}, field=node_feats)(data)[node_feats], data[node_feats])
+
+
+def test_target_normalizers_reference_scenarios():
+    """reference tests/data/test_transform.py:7-72 (MeanNormNormalize on 0e+2x1e+2e, ScalarNormalize), same checks;
+    and the model-side use: ScalarTensorModel.transform_prediction applies task.normalizer.inverse."""
+    from matten_amd.data.transform import MeanNormNormalize, ScalarNormalize
+
+    N, dim = 3, 1 + 2 * 3 + 5
+    data = torch.arange(N * dim).reshape(N, dim).to(torch.float)
+    mnn = MeanNormNormalize("0e+2x1e+2e", eps=0.0)
+    with pytest.raises(RuntimeError, match="not initialized"):
+        mnn(data)
+    mean1, norm1 = mnn.compute_statistics(data)
+    sd = mnn.state_dict()
+    mean, norm = sd["mean"], sd["norm"]
+    assert torch.allclose(mean1, mean) and torch.allclose(norm1, norm)
+    assert mean.shape == torch.Size((dim,)) and norm.shape == torch.Size((dim,))
+    scalars = data[:, 0]
+    assert mean[0] == scalars.mean() and norm[0] == torch.std(scalars, unbiased=False)
+    n = data[:, 4:7].square().mean(dim=1).mean(dim=0).sqrt()  # the second 1e lives in columns 4..6
+    assert torch.allclose(norm[4], n) and torch.allclose(norm[5], n) and torch.allclose(norm[6], n)
+    assert mean[1:].abs().max() == 0  # only scalars are centred
+    assert torch.allclose(data, mnn.inverse(mnn(data)))
+
+    data = torch.arange(3 * 4).reshape(3, 4).to(torch.float)
+    sn = ScalarNormalize(num_features=4)
+    mean1, norm1 = sn.compute_statistics(data)
+    sd = sn.state_dict()
+    assert torch.allclose(mean1, sd["mean"]) and torch.allclose(norm1, sd["norm"])
+    assert torch.allclose(sd["mean"], torch.mean(data, dim=0))
+    assert torch.allclose(sd["norm"], torch.std(data, dim=0, unbiased=False))
+    assert torch.allclose(data, sn.inverse(sn(data)))
+
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+
+    class Task:
+        name = "elastic_tensor_full"
+        normalizer = mnn
+
+    x = torch.randn(2, dim)
+    out = ScalarTensorModel.transform_prediction(type("M", (), {"tasks": {"elastic_tensor_full": Task()}})(),
+                                                 {"elastic_tensor_full": x})
+    assert torch.allclose(out["elastic_tensor_full"], mnn.inverse(x))
