@@ -65,9 +65,19 @@ def _fields(s) -> Dict[str, np.ndarray]:
             "atomic_numbers": np.asarray(s.atomic_numbers)}
 
 
-def check_species(model, structures: Sequence):
+def check_species(model, structures: Sequence, Z=None, ptr=None, index=None):
+    """Raise like the reference (predict.py:96-114) if a structure holds a species the model was not trained on.
+    With the packed arrays of ``pack_structures`` the common all-supported case is one vectorised membership test."""
     supported = set(int(z) for z in model.hparams["dataset_hparams"]["allowed_species"])
-    for i, s in enumerate(structures):
+    if Z is not None:
+        bad = ~np.isin(Z, np.fromiter(supported, dtype=np.int64))
+        if not bad.any():
+            return
+        k = int(np.searchsorted(ptr, np.nonzero(bad)[0][0], side="right") - 1)
+        structures, first = [structures[index[k]]], index[k]
+    else:
+        first = 0
+    for i, s in enumerate(structures, start=first):
         numbers = set(int(z) for z in _fields(s)["atomic_numbers"])
         if not numbers.issubset(supported):
             not_supported = ", ".join(str(z) for z in sorted(numbers - supported))
@@ -75,6 +85,90 @@ def check_species(model, structures: Sequence):
                 f"Cannot make predictions for structure {i}. It contains species {not_supported} not supported by "
                 f"the model. The model were trained with species {supported}."
             )
+
+
+def pack_structures(structures: Sequence):
+    """One pass over the structures -> flat struct-of-arrays batch (pos [N,3] f64, cell [B,3,3] f64, Z [N] i64,
+    ptr [B+1]) of the usable ones, plus the indices that cannot be used (same role as the per-structure try/except of
+    the reference dataset, dataset/structure_scalar_tensor.py:296-362): malformed arrays, no atoms, non-finite
+    numbers, singular cell.  Everything after the attribute access is vectorised."""
+    pos_l, cell_l, z_l, keep, failed = [], [], [], [], []
+    for i, s in enumerate(structures):
+        try:
+            f = _fields(s)
+            p = np.asarray(f["cart_coords"], dtype=np.float64).reshape(-1, 3)
+            c = np.asarray(f["lattice"], dtype=np.float64).reshape(3, 3)
+            z = np.asarray(f["atomic_numbers"], dtype=np.int64).reshape(-1)
+            if len(p) == 0 or len(p) != len(z):
+                raise ValueError("malformed structure")
+        except Exception as e:  # noqa: BLE001
+            warnings.warn(f"Failed converting structure {i}, Skip it. {e}")
+            failed.append(i)
+            continue
+        pos_l.append(p); cell_l.append(c); z_l.append(z); keep.append(i)
+    if keep:
+        sizes = np.array([len(p) for p in pos_l], dtype=np.int64)
+        cell = np.stack(cell_l)
+        pos = np.concatenate(pos_l)
+        ptr = np.zeros(len(keep) + 1, dtype=np.int64)
+        np.cumsum(sizes, out=ptr[1:])
+        with np.errstate(all="ignore"):
+            ok = np.isfinite(cell).all(axis=(1, 2)) & (np.abs(np.linalg.det(cell)) > 1e-12)
+            ok &= np.logical_and.reduceat(np.isfinite(pos).all(axis=1), ptr[:-1])
+        if not ok.all():
+            for k in np.nonzero(~ok)[0]:
+                warnings.warn(f"Failed converting structure {keep[k]}, Skip it. singular cell or non-finite coordinates")
+                failed.append(keep[k])
+            sel = np.nonzero(ok)[0]
+            pos_l, cell_l, z_l = [pos_l[k] for k in sel], [cell_l[k] for k in sel], [z_l[k] for k in sel]
+            keep = [keep[k] for k in sel]
+    if not keep:
+        raise RuntimeError("Cannot successfully convert any structures.")
+    sizes = np.array([len(p) for p in pos_l], dtype=np.int64)
+    ptr = np.zeros(len(keep) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=ptr[1:])
+    return np.concatenate(pos_l), np.stack(cell_l), np.concatenate(z_l), ptr, keep, sorted(failed)
+
+
+def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
+                 tensor_target_name: str = "elastic_tensor_full", tensor_target_formula: str = "ijkl=jikl=klij"):
+    """Batched forward straight from the flat arrays of ``pack_structures`` (graphs are built on the device, batch by
+    batch).  -> (Cartesian tensors [B, 3, ...] on the host as one array, indices of crystals without any edge)."""
+    from .data.graph import batch_graphs_gpu_soa
+
+    converter = CartesianTensorWrapper(tensor_target_formula)
+    device = model.device
+    rank_dims = (3,) * len(tensor_target_formula.split("=")[0].replace("-", ""))
+    B = len(ptr) - 1
+    out = torch.full((B,) + rank_dims, float("nan"), device=device)
+    edgeless = []
+    model.eval()
+    with torch.no_grad():
+        for lo in range(0, B, batch_size):
+            hi = min(B, lo + batch_size)
+            ids = np.arange(lo, hi)
+            while len(ids):
+                a, b = ptr[ids[0]], ptr[ids[-1] + 1]
+                if len(ids) == hi - lo or np.all(np.diff(ids) == 1):
+                    sub = (pos[a:b], cell[ids], Z[a:b], ptr[ids[0] : ids[-1] + 2] - a)
+                else:  # crystals were dropped from the batch: regather
+                    rows = np.concatenate([np.arange(ptr[i], ptr[i + 1]) for i in ids])
+                    sp = np.zeros(len(ids) + 1, dtype=np.int64)
+                    np.cumsum(ptr[ids + 1] - ptr[ids], out=sp[1:])
+                    sub = (pos[rows], cell[ids], Z[rows], sp)
+                try:
+                    batch = batch_graphs_gpu_soa(*sub, r_cut, device)
+                except EdgelessStructures as e:
+                    edgeless += [int(ids[k]) for k in e.indices]
+                    ids = np.delete(ids, e.indices)
+                    continue
+                preds, _ = model(batch, task_name=tensor_target_name)
+                p = preds[tensor_target_name]
+                if p.dim() == 2:  # irreps -> Cartesian on the GPU
+                    p = converter.to_cartesian(p)
+                out[torch.as_tensor(ids, device=device)] = p
+                break
+    return out.cpu().numpy(), sorted(edgeless)
 
 
 def build_graphs(structures: Sequence, r_cut: float, on_gpu: bool = False):
@@ -192,9 +286,9 @@ def predict(
                                      model_class=AtomicTensorModel if is_atomic_tensor else ScalarTensorModel)
     if config is None:
         config = get_pretrained_config(model_identifier)
-    check_species(model, structures)
     r_cut = config["data"]["r_cut"]
     if is_atomic_tensor:
+        check_species(model, structures)
         # one tensor per atom; the reference returns them as one flat list over all structures and never unwraps a
         # single structure (predict.py:210-242).  A structure whose graph cannot be built fails the whole call
         # here: with per-atom outputs the reference's "None at the failed index" bookkeeping has no meaning.
@@ -205,25 +299,20 @@ def predict(
                                 tensor_target_name=config["data"]["tensor_target_name"],
                                 tensor_target_formula=config["data"]["tensor_target_formula"], r_cut=r_cut)
         return [t.numpy() for t in preds]
-    graphs, failed = build_graphs(structures, r_cut=r_cut, on_gpu=True)
-    predictions = evaluate(
-        model, graphs, batch_size=batch_size,
-        tensor_target_name=config["data"]["tensor_target_name"],
-        tensor_target_formula=config["data"]["tensor_target_formula"],
-        r_cut=r_cut,
-    )
-    predictions = [t.numpy() for t in predictions]
-    # crystals whose neighbour search found no edge come back as NaN tensors
-    ok_idx = [i for i in range(len(structures)) if i not in set(failed)]
-    edgeless = [ok_idx[k] for k, t in enumerate(predictions) if np.isnan(t).all()]
-    if edgeless:
-        for i in edgeless:
-            warnings.warn(f"Failed converting structure {i}, Skip it. After eliminating self edges, no edges remain "
-                          "in this system.")
-        predictions = [t for t in predictions if not np.isnan(t).all()]
-        failed = sorted(set(failed) | set(edgeless))
-        if not predictions:
-            raise RuntimeError("Cannot successfully convert any structures.")
+    # fast path: one pass over the structures, then flat arrays all the way to the device
+    pos, cell, Z, ptr, keep, failed = pack_structures(structures)
+    check_species(model, structures, Z, ptr, keep)
+    tensors, edgeless = evaluate_soa(model, pos, cell, Z, ptr, r_cut, batch_size=batch_size,
+                                     tensor_target_name=config["data"]["tensor_target_name"],
+                                     tensor_target_formula=config["data"]["tensor_target_formula"])
+    for k in edgeless:
+        warnings.warn(f"Failed converting structure {keep[k]}, Skip it. After eliminating self edges, no edges remain "
+                      "in this system.")
+    failed = sorted(set(failed) | {keep[k] for k in edgeless})
+    dropped = set(edgeless)
+    predictions = [tensors[k] for k in range(len(keep)) if k not in dropped]
+    if not predictions:
+        raise RuntimeError("Cannot successfully convert any structures.")
     if is_elasticity_tensor:
         try:
             from pymatgen.analysis.elasticity import ElasticTensor
