@@ -130,10 +130,24 @@ def pack_structures(structures: Sequence):
     return np.concatenate(pos_l), np.stack(cell_l), np.concatenate(z_l), ptr, keep, sorted(failed)
 
 
+_SIDE_STREAMS: Dict[Any, Any] = {}
+
+
+def _side_stream(device):
+    """one persistent graph-construction stream per device (a fresh stream per call would also mean a fresh, empty
+    allocator pool per call)"""
+    key = torch.device(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(key)
+    return _SIDE_STREAMS[key]
+
+
 def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
                  tensor_target_name: str = "elastic_tensor_full", tensor_target_formula: str = "ijkl=jikl=klij"):
-    """Batched forward straight from the flat arrays of ``pack_structures`` (graphs are built on the device, batch by
-    batch).  -> (Cartesian tensors [B, 3, ...] on the host as one array, indices of crystals without any edge)."""
+    """Batched forward straight from the flat arrays of ``pack_structures``.  Graphs are built on the device batch
+    by batch on a SECOND stream: the neighbour search of batch k+1 (and its one host sync, the edge count) overlaps
+    the forward of batch k, which runs on the caller's stream.
+    -> (Cartesian tensors [B, 3, ...] on the host as one array, indices of crystals without any edge)."""
     from .data.graph import batch_graphs_gpu_soa
 
     converter = CartesianTensorWrapper(tensor_target_formula)
@@ -142,32 +156,45 @@ def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
     B = len(ptr) - 1
     out = torch.full((B,) + rank_dims, float("nan"), device=device)
     edgeless = []
+    main = torch.cuda.current_stream(device)
+    side = _side_stream(device)
+
+    def slice_of(ids):
+        a, b = ptr[ids[0]], ptr[ids[-1] + 1]
+        if np.all(np.diff(ids) == 1):
+            return pos[a:b], cell[ids], Z[a:b], ptr[ids[0] : ids[-1] + 2] - a
+        rows = np.concatenate([np.arange(ptr[i], ptr[i + 1]) for i in ids])  # crystals were dropped: regather
+        sp = np.zeros(len(ids) + 1, dtype=np.int64)
+        np.cumsum(ptr[ids + 1] - ptr[ids], out=sp[1:])
+        return pos[rows], cell[ids], Z[rows], sp
+
+    def build(ids):
+        """graph batch of crystals `ids` on the side stream; crystals without edges are dropped and recorded"""
+        with torch.cuda.stream(side):
+            while len(ids):
+                try:
+                    return ids, batch_graphs_gpu_soa(*slice_of(ids), r_cut, device)
+                except EdgelessStructures as e:
+                    edgeless.extend(int(ids[k]) for k in e.indices)
+                    ids = np.delete(ids, e.indices)
+        return ids, None
+
+    chunks = [np.arange(lo, min(B, lo + batch_size)) for lo in range(0, B, batch_size)]
     model.eval()
     with torch.no_grad():
-        for lo in range(0, B, batch_size):
-            hi = min(B, lo + batch_size)
-            ids = np.arange(lo, hi)
-            while len(ids):
-                a, b = ptr[ids[0]], ptr[ids[-1] + 1]
-                if len(ids) == hi - lo or np.all(np.diff(ids) == 1):
-                    sub = (pos[a:b], cell[ids], Z[a:b], ptr[ids[0] : ids[-1] + 2] - a)
-                else:  # crystals were dropped from the batch: regather
-                    rows = np.concatenate([np.arange(ptr[i], ptr[i + 1]) for i in ids])
-                    sp = np.zeros(len(ids) + 1, dtype=np.int64)
-                    np.cumsum(ptr[ids + 1] - ptr[ids], out=sp[1:])
-                    sub = (pos[rows], cell[ids], Z[rows], sp)
-                try:
-                    batch = batch_graphs_gpu_soa(*sub, r_cut, device)
-                except EdgelessStructures as e:
-                    edgeless += [int(ids[k]) for k in e.indices]
-                    ids = np.delete(ids, e.indices)
-                    continue
+        nxt = build(chunks[0]) if chunks else None
+        for k in range(len(chunks)):
+            ids, batch = nxt
+            if batch is not None:
+                main.wait_stream(side)
+                for t in batch.values():
+                    t.record_stream(main)  # allocated on the side stream, consumed on the caller's
                 preds, _ = model(batch, task_name=tensor_target_name)
                 p = preds[tensor_target_name]
                 if p.dim() == 2:  # irreps -> Cartesian on the GPU
                     p = converter.to_cartesian(p)
                 out[torch.as_tensor(ids, device=device)] = p
-                break
+            nxt = build(chunks[k + 1]) if k + 1 < len(chunks) else None  # overlaps the forward just enqueued
     return out.cpu().numpy(), sorted(edgeless)
 
 
