@@ -275,3 +275,53 @@ def test_atomic_tensor_oracle_is_equivariant_per_atom(golden_dir):
         ir = m_ir(rdata.collate([g1]))
     assert ir.shape == (n, 6)
     assert torch.allclose(ToCartesian("ij=ji")(ir), t1, atol=1e-6)
+
+
+def test_su2_clebsch_gordan_matches_sympy():
+    """Independent pin of the published part of the coupling coefficients: the oracle's su(2) Clebsch-Gordan
+    coefficients <l1 m1 l2 m2 | l3 m3> (Racah formula, e3nn_lite/o3.py) against sympy's exact evaluation, every
+    (l1, l2, l3) with l <= 4.  (The real-basis change on top of them is e3nn's convention)"""
+    from sympy import S
+    from sympy.physics.wigner import clebsch_gordan
+
+    n = 0
+    for l1 in range(5):
+        for l2 in range(5):
+            for l3 in range(abs(l1 - l2), min(4, l1 + l2) + 1):
+                C = o3._su2_clebsch_gordan(l1, l2, l3)
+                for m1 in range(-l1, l1 + 1):
+                    for m2 in range(-l2, l2 + 1):
+                        m3 = m1 + m2
+                        if abs(m3) > l3:
+                            continue
+                        want = float(clebsch_gordan(S(l1), S(l2), S(l3), S(m1), S(m2), S(m3)))
+                        assert abs(C[l1 + m1, l2 + m2, l3 + m3].item() - want) < 1e-12, (l1, l2, l3, m1, m2)
+                        n += 1
+    assert n == 1439  # all (m1, m2) with |m1 + m2| <= l3 over the 65 triples
+
+
+def test_real_spherical_harmonics_match_sympy():
+    """The oracle's real harmonics against sympy's complex Ynm: with the polar axis on y, (x_s, y_s, z_s) = (z, x, y),
+    and without the Condon-Shortley sign, norm-normalised:
+        Y_{l,m>0} = sqrt(4 pi/(2l+1)) sqrt2 (-1)^m Re Ynm(l, m),  Y_{l,-m} = ... Im Ynm(l, m),  Y_{l,0} = ... Ynm(l, 0)."""
+    import sympy as sp
+
+    th, ph = sp.symbols("theta phi", real=True)
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(6, 3, dtype=torch.float64, generator=g)
+    n = v / v.norm(dim=1, keepdim=True)
+    x, y, z = n[:, 0].numpy(), n[:, 1].numpy(), n[:, 2].numpy()
+    xs, ys, zs = z, x, y
+    theta, phi = np.arccos(zs), np.arctan2(ys, xs)
+    got = o3.spherical_harmonics([0, 1, 2, 3, 4], v, True, "norm").numpy()
+    for l in range(5):
+        scale = math.sqrt(4 * math.pi / (2 * l + 1))
+        for m in range(0, l + 1):
+            f = sp.lambdify((th, ph), sp.Ynm(l, m, th, ph).expand(func=True), "numpy")
+            val = np.asarray(f(theta, phi), dtype=np.complex128) * np.ones_like(theta)
+            if m == 0:
+                assert np.allclose(got[:, l * l + l], scale * val.real, atol=1e-12), (l, m)
+            else:
+                c = scale * math.sqrt(2) * (-1) ** m
+                assert np.allclose(got[:, l * l + l + m], c * val.real, atol=1e-12), (l, m)
+                assert np.allclose(got[:, l * l + l - m], c * val.imag, atol=1e-12), (l, -m)
