@@ -276,12 +276,15 @@ __device__ __forceinline__ void consume(const float (&regs)[4 * NB], float* buf,
 #define SL_MIN_BLOCKS 2
 #endif
 
+// W_LDS = false: the species' packed table does not fit next to the transpose tiles (> ~118 KB); the A operand is
+// then read from global memory (L2-resident) -- same arithmetic, slower, no size limit.
+template <bool W_LDS>
 __global__ __launch_bounds__(SL_WAVES * 64, SL_MIN_BLOCKS) void species_linear_kernel(
     const float* __restrict__ x, int d_in, const int32_t* __restrict__ order, const int32_t* __restrict__ seg,
     int n_species, const float* __restrict__ wp, int w_stride, const LinSeg* __restrict__ segs, int n_segs,
     int segs_per_block, int d_out, const float* __restrict__ add, int n_rows, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ws = lds + SL_WAVES * SL_ROWS * XS_RS;  // [w_stride] packed table of this block's species
+    float* ws_lds = lds + SL_WAVES * SL_ROWS * XS_RS;  // [w_stride] packed table of this block's species
     // ---- block -> (species, 64 rows) ----
     int b = blockIdx.x, s = 0, blo = 0, bhi = 0;
     constexpr int BR = SL_ROWS * SL_WAVES;
@@ -305,16 +308,17 @@ __global__ __launch_bounds__(SL_WAVES * 64, SL_MIN_BLOCKS) void species_linear_k
         if (blo >= bhi) return;
     }
     const int sg0 = blockIdx.y * segs_per_block, sg1 = min(n_segs, sg0 + segs_per_block);
-    {   // the slice of the weight table this block's irrep blocks touch
+    const float* wsp = wp + (int64_t)s * w_stride;
+    if (W_LDS) {   // the slice of the weight table this block's irrep blocks touch
         int w_lo = w_stride, w_hi = 0;
         for (int sg = sg0; sg < sg1; ++sg) {
             w_lo = min(w_lo, segs[sg].w_off);
             w_hi = max(w_hi, segs[sg].w_off + segs[sg].mul_in * segs[sg].mo);
         }
-        const float* wsp = wp + (int64_t)s * w_stride;
-        for (int i = w_lo + threadIdx.x; i < w_hi; i += blockDim.x) ws[i] = wsp[i];
+        for (int i = w_lo + threadIdx.x; i < w_hi; i += blockDim.x) ws_lds[i] = wsp[i];
+        __syncthreads();
     }
-    __syncthreads();
+    const float* ws = W_LDS ? ws_lds : wsp;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -406,11 +410,12 @@ extern "C" int matten_species_linear(const float* x, int64_t d_in, const int32_t
     if (!x || !wp || !out || !segs) return MATTEN_EINVAL;
     if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
     if (!order && n_species != 1) return MATTEN_EINVAL;
-    const size_t lds = sizeof(float) * ((size_t)((w_stride + 3) & ~3) + SL_WAVES * SL_ROWS * XS_RS);
-    if (lds > 160 * 1024) return MATTEN_EINVAL;  // one species' packed table must fit in LDS (<= ~118 KB)
+    const size_t lds_tiles = sizeof(float) * SL_WAVES * SL_ROWS * XS_RS;
+    const bool w_lds = lds_tiles + sizeof(float) * (size_t)((w_stride + 3) & ~3) <= 160 * 1024;
+    const size_t lds = lds_tiles + (w_lds ? sizeof(float) * (size_t)((w_stride + 3) & ~3) : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)species_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)species_linear_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return MATTEN_ELAUNCH;
         attr_set = true;
@@ -420,9 +425,14 @@ extern "C" int matten_species_linear(const float* x, int64_t d_in, const int32_t
     // few rows: spread the irrep blocks over blockIdx.y so the chip still sees enough waves
     const int segs_per_block = blocks >= 512 ? (int)n_segs : 1;
     dim3 grid((unsigned)blocks, (unsigned)matten_cdiv(n_segs, segs_per_block));
-    species_linear_kernel<<<grid, SL_WAVES * 64, lds, stream>>>(x, (int)d_in, order, seg, (int)n_species, wp,
-                                                              (int)w_stride, (const LinSeg*)segs, (int)n_segs,
-                                                              segs_per_block, (int)d_out, add, (int)n_rows, out);
+    if (w_lds)
+        species_linear_kernel<true><<<grid, SL_WAVES * 64, lds, stream>>>(
+            x, (int)d_in, order, seg, (int)n_species, wp, (int)w_stride, (const LinSeg*)segs, (int)n_segs,
+            segs_per_block, (int)d_out, add, (int)n_rows, out);
+    else
+        species_linear_kernel<false><<<grid, SL_WAVES * 64, lds, stream>>>(
+            x, (int)d_in, order, seg, (int)n_species, wp, (int)w_stride, (const LinSeg*)segs, (int)n_segs,
+            segs_per_block, (int)d_out, add, (int)n_rows, out);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

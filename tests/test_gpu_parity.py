@@ -445,6 +445,9 @@ def test_species_linear_shape_sweep():
         for l in range(5):
             ir = f"{l}{'e' if l % 2 == 0 else 'o'}"
             worst[("mi", mi, l)] = _species_linear_case(f"{mi}x{ir}+3x0e", f"5x{ir}+2x0e", 3, 50, bool(mi % 2), gen)
+    # a packed table too large for LDS (400 x 90 floats = 144 KB per species): the global-memory A-operand variant
+    worst[("big W", 0)] = _species_linear_case("400x0e+20x1o", "90x0e+7x1o", 3, 130, True, gen)
+    worst[("big W", 1)] = _species_linear_case("330x1o", "100x1o", 2, 70, False, gen)
     bad = {k: v for k, v in worst.items() if not v < 2e-6}
     assert not bad, f"{len(bad)} of {len(worst)} shapes off: {sorted(bad.items(), key=lambda kv: -kv[1])[:8]}"
 
