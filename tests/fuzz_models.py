@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random small models (irreps, multiplicities, lmax, depth, normalisation, neighbour normalisation) on random small
-crystals: product on the GPU against the oracle on the CPU.  Usage: model_fuzz.py [n_cases] [seed]"""
+crystals: product on the GPU against the oracle on the CPU.  Test infrastructure (it drives the oracle): tests/fuzz_models.py [n_cases] [seed]"""
 import copy, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -567,13 +567,13 @@ def test_operands_beyond_4GB():
 def test_random_small_models_vs_oracle():
     """Generality of the plan / kernel tables beyond the shipped configs: six random models (lmax 1-4, odd and unit
     multiplicities, missing parities, 1-3 gated layers, with and without BatchNorm / fixed neighbour normalisation) on
-    random triclinic cells against the oracle (tools/model_fuzz.py runs the same generator for as many cases as wanted;
+    random triclinic cells against the oracle (tests/fuzz_models.py runs the same generator for as many cases as wanted;
     104 cases were clean when this test was written)."""
     import subprocess
     import sys as _sys
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "model_fuzz.py"), "6", "11"], capture_output=True,
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([_sys.executable, os.path.join(here, "fuzz_models.py"), "6", "11"], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "bad 0" in r.stdout

@@ -295,3 +295,17 @@ def test_target_normalizers_reference_scenarios():
     out = ScalarTensorModel.transform_prediction(type("M", (), {"tasks": {"elastic_tensor_full": Task()}})(),
                                                  {"elastic_tensor_full": x})
     assert torch.allclose(out["elastic_tensor_full"], mnn.inverse(x))
+
+
+def test_dataset_json_reader_matches_oracle_reader(golden_dir):
+    """matten_amd.data.io reads the reference's dataset format (dataset/structure_scalar_tensor.py:229-243) like the
+    oracle's reader: 100 rows, 473 atoms, same arrays."""
+    from matten_amd.data.io import structures_from_json
+    from oracle.matten_ref import data as rdata
+
+    path = os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json")
+    got, want = structures_from_json(path), rdata.structures_from_json(path)
+    assert len(got) == len(want) == 100 and sum(len(s["atomic_numbers"]) for s in got) == 473
+    for a, b in zip(got, want):
+        for k in ("lattice", "cart_coords", "atomic_numbers", "elastic_tensor_full"):
+            assert np.array_equal(a[k], b[k]), k

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from common import LMAX2
 from matten_amd.data.graph import average_num_neighbors, collate, crystal_graph
 from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
-from oracle.matten_ref.data import structures_from_json   # JSON reader only (host-side fixture parsing)
+from matten_amd.data.io import structures_from_json
 
 structs = structures_from_json(os.path.join(ROOT, "tests", "golden", "example_crystal_elasticity_tensor_n100.json"))
 graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
