@@ -577,3 +577,20 @@ def test_random_small_models_vs_oracle():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "bad 0" in r.stdout
+
+
+def test_isolated_atom_and_ragged_degrees():
+    """An atom without any neighbour inside the cutoff (degree 0) next to bonded ones, in a batch with a dense crystal:
+    empty CSR segments, ragged degrees (0 / 1 / 18+), fixed neighbour normalisation -- against the oracle."""
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import collate, crystal_graph
+
+    lone = crystal_graph(np.array([[0.0, 0, 0], [1.5, 0, 0], [6.0, 6.0, 6.0]]), 12.0 * np.eye(3), [29, 79, 29], 5.0)
+    assert lone["num_neigh"].tolist() == [1.0, 1.0, 0.0]
+    graphs = [lone] + synthetic.fcc64_graphs(1) + [lone]
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    ref, model = build_pair(PAPER, ds, randomize_bn=True)
+    got, want = _run_pair(ref, model, graphs)
+    assert torch.isfinite(got).all()
+    close(got, want, RTOL, "batch with an isolated atom")
+    assert torch.equal(got[0], got[2])
