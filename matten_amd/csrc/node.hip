@@ -18,11 +18,59 @@ __device__ __forceinline__ float apply_act(int code, float v) {
     }
 }
 
-__global__ void gate_bn_kernel(const float* __restrict__ x, int d_in, const int4* __restrict__ meta, int d_out,
-                               const float* __restrict__ act_cst, const float* __restrict__ running_mean,
-                               const float* __restrict__ running_var, const float* __restrict__ bn_weight,
-                               const float* __restrict__ bn_bias, float eps, int64_t n_rows,
-                               float* __restrict__ out) {
+// Gate + (eval) BatchNorm.  A workgroup owns GB_ROWS rows and first folds the per-column constants into LDS once --
+// source column, gate column, activation codes and the BatchNorm affine as (scale, shift) -- so the per-element work is
+// two loads, the activations and one fma; consecutive lanes write consecutive output columns.
+constexpr int GB_ROWS = 32;
+constexpr int GB_MAXD = 1024;  // output columns held in LDS (wider layers take the plain path below)
+
+__global__ __launch_bounds__(256) void gate_bn_kernel(const float* __restrict__ x, int d_in, const int4* __restrict__ meta,
+                                                      int d_out, const float* __restrict__ act_cst,
+                                                      const float* __restrict__ running_mean,
+                                                      const float* __restrict__ running_var,
+                                                      const float* __restrict__ bn_weight,
+                                                      const float* __restrict__ bn_bias, float eps, int64_t n_rows,
+                                                      float* __restrict__ out) {
+    __shared__ int s_src[GB_MAXD], s_gate[GB_MAXD], s_act[GB_MAXD];
+    __shared__ float s_scale[GB_MAXD], s_shift[GB_MAXD];
+    for (int o = threadIdx.x; o < d_out; o += blockDim.x) {
+        const int4 m = meta[o];
+        s_src[o] = m.x;
+        s_gate[o] = m.y;
+        s_act[o] = m.z;
+        float scale = 1.0f, shift = 0.0f;
+        if (bn_weight) {
+            const int bn_idx = m.w & 0xffff, mean_idx = (m.w >> 16) & 0xffff;
+            scale = bn_weight[bn_idx] / sqrtf(running_var[bn_idx] + eps);
+            if (mean_idx != 0xffff) shift = bn_bias[mean_idx] - running_mean[mean_idx] * scale;  // (v - mu) s + b
+        }
+        s_scale[o] = scale;
+        s_shift[o] = shift;
+    }
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * GB_ROWS;
+    const int rows = (int)min((int64_t)GB_ROWS, n_rows - row0);
+    for (int idx = threadIdx.x; idx < rows * d_out; idx += blockDim.x) {
+        const int r = idx / d_out, o = idx - r * d_out;
+        const float* xr = x + (row0 + r) * d_in;
+        float v = xr[s_src[o]];
+        const int act = s_act[o] & 0xff, gact = (s_act[o] >> 8) & 0xff;
+        if (s_gate[o] < 0) {
+            if (act) v = apply_act(act, v) * act_cst[act];
+        } else {
+            float gte = xr[s_gate[o]];
+            if (gact) gte = apply_act(gact, gte) * act_cst[gact];
+            v = v * gte;
+        }
+        out[(row0 + r) * d_out + o] = bn_weight ? fmaf(v, s_scale[o], s_shift[o]) : v;
+    }
+}
+
+__global__ void gate_bn_wide_kernel(const float* __restrict__ x, int d_in, const int4* __restrict__ meta, int d_out,
+                                    const float* __restrict__ act_cst, const float* __restrict__ running_mean,
+                                    const float* __restrict__ running_var, const float* __restrict__ bn_weight,
+                                    const float* __restrict__ bn_bias, float eps, int64_t n_rows,
+                                    float* __restrict__ out) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_rows * d_out) return;
     int64_t n = idx / d_out;
@@ -85,9 +133,14 @@ extern "C" int matten_gate_bn(const float* x, int64_t d_in, const int32_t* meta,
     if (!x || !meta || !act_cst || !out) return MATTEN_EINVAL;
     if (bn_weight && (!running_var || !running_mean || !bn_bias)) return MATTEN_EINVAL;
     const int T = 256;
-    gate_bn_kernel<<<(unsigned)matten_cdiv(n_rows * d_out, T), T, 0, stream>>>(
-        x, (int)d_in, (const int4*)meta, (int)d_out, act_cst, running_mean, running_var, bn_weight, bn_bias, eps,
-        n_rows, out);
+    if (d_out <= GB_MAXD)
+        gate_bn_kernel<<<(unsigned)matten_cdiv(n_rows, GB_ROWS), T, 0, stream>>>(
+            x, (int)d_in, (const int4*)meta, (int)d_out, act_cst, running_mean, running_var, bn_weight, bn_bias, eps,
+            n_rows, out);
+    else
+        gate_bn_wide_kernel<<<(unsigned)matten_cdiv(n_rows * d_out, T), T, 0, stream>>>(
+            x, (int)d_in, (const int4*)meta, (int)d_out, act_cst, running_mean, running_var, bn_weight, bn_bias, eps,
+            n_rows, out);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }
