@@ -50,19 +50,22 @@ __global__ __launch_bounds__(256) void gate_bn_kernel(const float* __restrict__ 
     __syncthreads();
     const int64_t row0 = (int64_t)blockIdx.x * GB_ROWS;
     const int rows = (int)min((int64_t)GB_ROWS, n_rows - row0);
-    for (int idx = threadIdx.x; idx < rows * d_out; idx += blockDim.x) {
-        const int r = idx / d_out, o = idx - r * d_out;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < rows; r += 4) {  // a wave walks one row: consecutive lanes, consecutive columns, no division
         const float* xr = x + (row0 + r) * d_in;
-        float v = xr[s_src[o]];
-        const int act = s_act[o] & 0xff, gact = (s_act[o] >> 8) & 0xff;
-        if (s_gate[o] < 0) {
-            if (act) v = apply_act(act, v) * act_cst[act];
-        } else {
-            float gte = xr[s_gate[o]];
-            if (gact) gte = apply_act(gact, gte) * act_cst[gact];
-            v = v * gte;
+        float* orow = out + (row0 + r) * d_out;
+        for (int o = lane; o < d_out; o += 64) {
+            float v = xr[s_src[o]];
+            const int act = s_act[o] & 0xff, gact = (s_act[o] >> 8) & 0xff;
+            if (s_gate[o] < 0) {
+                if (act) v = apply_act(act, v) * act_cst[act];
+            } else {
+                float gte = xr[s_gate[o]];
+                if (gact) gte = apply_act(gact, gte) * act_cst[gact];
+                v = v * gte;
+            }
+            orow[o] = bn_weight ? fmaf(v, s_scale[o], s_shift[o]) : v;
         }
-        out[(row0 + r) * d_out + o] = bn_weight ? fmaf(v, s_scale[o], s_shift[o]) : v;
     }
 }
 
