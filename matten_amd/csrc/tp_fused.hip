@@ -278,6 +278,8 @@ __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __rest
     const int g = lane >> 4, c = lane & 15;
     const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * (NT * 16);
     if (e0 >= E) return;
+    const float inv_c = 1.0f / (r_end - r_start);
+    const float bes_pref = sqrtf(2.0f * inv_c) * sqrtf((float)n_basis);  // soft_one_hot_linspace 'bessel' x sqrt(nb)
     float a1[2][8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -289,11 +291,17 @@ __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __rest
     for (int nt = 0; nt < NT; ++nt) {
         const int64_t e = e0 + nt * 16 + c;
         const float len = geom[e < E ? e : E - 1].w;
+        const float xr = len - r_start;
+        const float t01 = xr * inv_c, inv_xr = __builtin_amdgcn_rcpf(xr);
         f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS0; ++kk) {
             int k = 4 * kk + g;
-            float b = (k < n_basis) ? matten::bessel_basis(len, k, n_basis, r_start, r_end) : 0.0f;
+            // Bessel basis on the transcendental units: sin(pi (k+1) t) = v_sin_f32 of (k+1) t / 2 revolutions, 1/r by
+            // v_rcp_f32 (the precise sinf + three IEEE divisions were half of this kernel's instructions)
+            float b = 0.0f;
+            if (k < n_basis && t01 > 0.0f && t01 < 1.0f)
+                b = bes_pref * __builtin_amdgcn_sinf(0.5f * (float)(k + 1) * t01) * inv_xr;
             h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0p[k * HID + c], b, h0, 0, 0, 0);
             h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0p[k * HID + 16 + c], b, h1, 0, 0, 0);
         }
