@@ -80,7 +80,8 @@ struct Cursor {  // position of a chunk in the walk over (irrep block, channel-t
 
 // st == -1 is the addend chunk that opens an output tile group when add != NULL
 __device__ __forceinline__ void advance(Cursor& cu, const LinSeg& L, int st_first) {
-    const int n_st = (L.mul_in + 15) >> 4, n_vt = (L.mo + 15) >> 4;
+    // an empty block (mul_in == 0: output irrep without an input path) still has one, empty, step: it stores zeros / the addend
+    const int n_st = max(1, (L.mul_in + 15) >> 4), n_vt = (L.mo + 15) >> 4;
     cu.st = cu.st < 0 ? 0 : cu.st + steps_per_chunk(L.d);
     if (cu.st >= n_st) {
         cu.st = st_first;

@@ -316,7 +316,16 @@ def _plan_linear_like(irreps_in: Irreps, irreps_out: Irreps, n_species: int, pat
             d = irreps_out[i_out].ir.dim
             segs.append((x_offs[i_in], d, mi, pk, mo, o_offs[i_out], 0, 0))
         passes.append(np.array(segs, dtype=np.int32).reshape(-1, 8))
-    fully_covered = all(i in per_out for i in range(len(irreps_out)) if irreps_out[i].dim > 0)
+    # output irreps without any input path are zero (e3nn output_mask): an empty segment (mul_in = 0) makes the
+    # kernel store zeros (or the addend) there itself, so the caller never has to pre-fill the output
+    uncovered = [i for i in range(len(irreps_out)) if irreps_out[i].dim > 0 and i not in per_out]
+    if uncovered:
+        zero = np.array([(0, irreps_out[i].ir.dim, 0, 0, irreps_out[i].mul, o_offs[i], 0, 0) for i in uncovered],
+                        dtype=np.int32).reshape(-1, 8)
+        passes[0] = np.concatenate([passes[0], zero]) if len(passes) else zero
+        if not len(passes):
+            passes = [zero]
+    fully_covered = True
     # adjoint w.r.t. x: dX[x_off + u*d + k] = sum_w W[u,w] dY[o_off + w*d + k]  ==  the same operator with
     # (x_off, mul_in) <-> (o_off, mo) and each path's weight block transposed
     perm_t = np.zeros(packed, dtype=np.int64)
@@ -339,7 +348,15 @@ def _plan_linear_like(irreps_in: Irreps, irreps_out: Irreps, n_species: int, pat
             segs_t_by_pass[slot].append((o_offs[i_out], d, mo, pk, mi, x_offs[i_in], 0, 0))
             used_inputs.add(i_in)
     passes_t = [np.array(sg, dtype=np.int32).reshape(-1, 8) for sg in segs_t_by_pass]
-    input_covered = all(i in used_inputs for i in range(len(irreps_in)) if irreps_in[i].dim > 0)
+    unused = [i for i in range(len(irreps_in)) if irreps_in[i].dim > 0 and i not in used_inputs]
+    if unused:  # inputs that feed no output: their gradient is zero, written by empty segments of the adjoint table
+        zero_t = np.array([(0, irreps_in[i].ir.dim, 0, 0, irreps_in[i].mul, x_offs[i], 0, 0) for i in unused],
+                          dtype=np.int32).reshape(-1, 8)
+        if passes_t:
+            passes_t[0] = np.concatenate([passes_t[0], zero_t])
+        else:
+            passes_t = [zero_t]
+    input_covered = True
     gather = np.concatenate(gather_cols, axis=1) if gather_cols else np.zeros((n_species, 0), dtype=np.int64)
     scale = np.concatenate(scale_cols) if scale_cols else np.zeros(0, dtype=np.float32)
     return LinearPlan(irreps_in, irreps_out, n_species, flat, packed, gather.astype(np.int64), scale, passes,
