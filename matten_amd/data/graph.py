@@ -104,6 +104,9 @@ def average_num_neighbors(graphs: Sequence[Dict[str, torch.Tensor]]) -> float:
     return float(torch.cat([g["num_neigh"] for g in graphs]).mean())
 
 
+_MAX_CRYSTALS_PER_LAUNCH = 65535
+
+
 class EdgelessStructures(ValueError):
     """Some crystals of a batch have no edge inside the cutoff; ``indices`` are their positions in the batch."""
 
@@ -144,8 +147,30 @@ def batch_graphs_gpu_soa(pos: np.ndarray, cell: np.ndarray, Z: np.ndarray, ptr: 
     ptr = np.ascontiguousarray(ptr, dtype=np.int64)
     sizes = np.diff(ptr)
     n_crystals = len(sizes)
-    if n_crystals > 65535:  # blockIdx.y of the neighbour kernels
-        raise ValueError("at most 65535 crystals per batch_graphs_gpu call")
+    if n_crystals > _MAX_CRYSTALS_PER_LAUNCH:  # blockIdx.y of the neighbour kernels: build in slabs and concatenate
+        parts = []
+        for lo in range(0, n_crystals, _MAX_CRYSTALS_PER_LAUNCH):
+            hi = min(n_crystals, lo + _MAX_CRYSTALS_PER_LAUNCH)
+            a, b = ptr[lo], ptr[hi]
+            try:
+                parts.append(batch_graphs_gpu_soa(pos[a:b], cell[lo:hi], Z[a:b], ptr[lo : hi + 1] - a, r_cut, device))
+            except EdgelessStructures as e:
+                raise EdgelessStructures([lo + k for k in e.indices]) from None
+        out, node_off, cry_off = {}, 0, 0
+        for p in parts:
+            p["edge_index"] = p["edge_index"] + node_off
+            p["batch"] = p["batch"] + cry_off
+            node_off += p["pos"].shape[0]
+            cry_off += p["ptr"].shape[0] - 1
+        for k in parts[0]:
+            if k == "edge_index":
+                out[k] = torch.cat([p[k] for p in parts], dim=1)
+            elif k != "ptr":
+                out[k] = torch.cat([p[k] for p in parts], dim=0)
+        for k, v in (y or {}).items():
+            out[k] = torch.as_tensor(v).to(out["pos"].device)
+        out["ptr"] = torch.from_numpy(ptr).to(out["pos"].device)
+        return out
     batch = np.repeat(np.arange(n_crystals, dtype=np.int64), sizes)
     # image_reach for all crystals at once
     inv = np.linalg.inv(cell)

@@ -594,3 +594,18 @@ def test_isolated_atom_and_ragged_degrees():
     assert torch.isfinite(got).all()
     close(got, want, RTOL, "batch with an isolated atom")
     assert torch.equal(got[0], got[2])
+
+
+def test_neighbor_list_slabs_match_single_launch(monkeypatch):
+    """More crystals than one launch of the neighbour kernels takes (65535, blockIdx.y): the slab path must give the
+    same batch; exercised by lowering the limit."""
+    from matten_amd.data import graph, synthetic
+
+    structs = synthetic.fcc64_structures(7)
+    triples = [(s["cart_coords"], s["lattice"], s["atomic_numbers"]) for s in structs]
+    want = graph.batch_graphs_gpu(triples, 5.0, DEV)
+    monkeypatch.setattr(graph, "_MAX_CRYSTALS_PER_LAUNCH", 3)
+    got = graph.batch_graphs_gpu(triples, 5.0, DEV)
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), k
