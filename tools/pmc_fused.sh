@@ -17,6 +17,6 @@ for i in (1,2,3):
         if "tp_fused" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items():
-    # launches: 2 warm + 5 timed 'all' first => take index 3
-    print("%-28s all=%.4g  (n=%d)" % (k, v[3], len(v)))
+    # launches: (2 warm + 5 timed) x [all, l1=0, ..., l1=4] => indices 3, 10, 17, 24, 31, 38
+    print("%-26s all=%.4g  l1=0..4: %s  (n=%d)" % (k, v[3], " ".join("%.3g" % v[i] for i in (10, 17, 24, 31, 38) if i < len(v)), len(v)))
 PY
