@@ -3,6 +3,8 @@
 // here each forward operator has a hand-written adjoint.  Training graphs are small (batch 32 crystals,
 // ~150 nodes, ~4.5 k edges), so these kernels favour simplicity: one thread per output element or per
 // (edge, channel), atomics only where contributions genuinely collide (gather adjoints).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -72,7 +74,13 @@ __global__ void species_linear_wgrad_kernel(const float* __restrict__ x, int d_i
                                             float* __restrict__ dwp) {
     const int s = blockIdx.x;
     const LinSeg L = segs[blockIdx.y];
-    const int lo = seg ? seg[s] : 0, hi = seg ? seg[s + 1] : n_rows;
+    int lo = seg ? seg[s] : 0, hi = seg ? seg[s + 1] : n_rows;
+    if (gridDim.z > 1) {  // rows of the species are cut into gridDim.z slices whose partial sums meet in dwp (zeroed by the caller)
+        const int per = (hi - lo + (int)gridDim.z - 1) / (int)gridDim.z;
+        lo += (int)blockIdx.z * per;
+        hi = min(hi, lo + per);
+        if (lo >= hi) return;
+    }
     for (int p = threadIdx.x; p < L.mul_in * L.mo; p += blockDim.x) {
         const int u = p / L.mo, w = p - u * L.mo;
         float a = 0.0f;
@@ -82,7 +90,9 @@ __global__ void species_linear_wgrad_kernel(const float* __restrict__ x, int d_i
             const float* gp = dy + (int64_t)n * d_out + L.o_off + w * L.d;
             for (int k = 0; k < L.d; ++k) a = fmaf(xp[k], gp[k], a);
         }
-        dwp[(int64_t)s * w_stride + L.w_off + p] = a;
+        float* dst = dwp + (int64_t)s * w_stride + L.w_off + p;
+        if (gridDim.z > 1) atomicAdd(dst, a);
+        else *dst = a;
     }
 }
 
@@ -292,7 +302,9 @@ extern "C" int matten_species_linear_wgrad(const float* x, int64_t d_in, const f
     if (!x || !dy || !segs || !dwp) return MATTEN_EINVAL;
     if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
     if (!order && n_species != 1) return MATTEN_EINVAL;
-    dim3 grid((unsigned)n_species, (unsigned)n_segs);
+    // one slice per ~16 rows of an average species (a single slice keeps the plain, order-fixed store)
+    const int64_t slices = std::min<int64_t>(256, std::max<int64_t>(1, n_rows / (16 * n_species)));
+    dim3 grid((unsigned)n_species, (unsigned)n_segs, (unsigned)slices);
     species_linear_wgrad_kernel<<<grid, 256, 0, stream>>>(x, (int)d_in, dy, (int)d_out, order, seg, (int)n_rows,
                                                           (const LinSeg*)segs, (int)w_stride, dwp);
     MATTEN_LAUNCH_CHECK();
