@@ -145,10 +145,13 @@ int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t 
 /* ------------------------------------------------------------------------------------------
  * Fused production path of one conv layer's edge work (reference nn/utils.py:246-251,260,263 +
  * nn/conv.py:113-120): the per-edge radial weights are never written to memory.
- *   matten_radial_hidden: rbf(|v|) -> 32 -> 32 (silu), fp32 MFMA; writes h2p[E,32] where column g*8+kk
+ *   matten_radial_hidden: rbf(|v|) -> 32 -> 32 (silu), fp32 MFMA; writes h2s[E,2,32] fp16 (128 B per edge): every
+ *                         hidden feature v as two pieces, v = hi + 2^-11 lo (hi = fp16(v), lo = fp16(2^11 (v - hi)),
+ *                         fp16 subnormals zeroed: v to 2^-24 relative); column g*8+kk of piece 0 (hi) / piece 1 (lo)
  *                         holds hidden feature 16*(kk>>2) + 4*g + (kk&3)
  *   matten_tp_fused:      per (input block, l2 group, node group) wave: last MLP layer on the matrix
- *                         cores (w = h2 . W2p) into a wave-private LDS tile, consumed in place by the
+ *                         cores (w = h2 . W2p as three fp16 products hi.hi + 2^-11 (hi.lo + lo.hi) accumulated in
+ *                         fp32: fp32-class rounding at 1/5 of the fp32 MFMA time) into a wave-private LDS tile, consumed in place by the
  *                         literal-coefficient CG contraction + CSR neighbour sum
  *   w2p[32, w_pad]: last layer weights pre-scaled (1/sqrt(32) * normalize2mom(silu)), columns in the
  *                   fused [entry][u][coupling] order of group_entries, w_pad >= w_cols + 16
@@ -157,9 +160,9 @@ int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t 
  *                   (sh_sorted rows must be 32 floats apart: sh_stride == 32)
  * ------------------------------------------------------------------------------------------ */
 int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
-                         const float* w0p, int nb_pad, const float* w1p, int hidden, float* h2p,
+                         const float* w0p, int nb_pad, const float* w1p, int hidden, uint16_t* h2s,
                          matten_stream_t stream);
-int matten_tp_fused(const float* x, int64_t d_in, const float* h2p, const float* w2p, int64_t w_pad,
+int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
                     const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
                     int64_t n_nodes, const int32_t* group_entries, const int32_t* unit_start, int64_t n_entries,
                     int64_t units_per_tile, int64_t lds_floats_per_wave, int64_t d_mid, float avg_num_neighbors,

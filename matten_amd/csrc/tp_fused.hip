@@ -7,6 +7,16 @@
 //
 //      w[e, col] = sum_k h2[e, k] * W2p[k, col]          (h2 = 32 hidden features per edge, 128 B)
 //
+// Arithmetic of that GEMM.  On gfx950 the fp32 matrix instruction (v_mfma_f32_16x16x4_f32, 33 cycles) runs at the
+// fp32 VALU rate and does NOT overlap with fp32 VALU work of any wave of the SIMD (tools/ubench/mfma_chain.hip,
+// mfma_valu_coissue.hip: the times add), so every MFMA cycle is taken from the contraction.  The fp16 one
+// (v_mfma_f32_16x16x32_f16, 17 cycles for 8x the K) is 16x faster per flop, so both operands are split into two
+// fp16 pieces, v = hi + 2^-11 lo with hi = fp16(v), lo = fp16(2^11 (v - hi)): 22+ significant bits, i.e. the fp32
+// value to within 2^-24 relative.  Three products (hi hi, hi lo, lo hi; lo lo is below 2^-24) accumulate in fp32:
+// the result carries the rounding of an fp32 dot product, at 51 instead of 264 matrix cycles per 16x16 tile.
+// fp16 range: the A tile is scaled by a power of two per wave (folded into the output normalisation; the
+// contraction is linear in w); h2 are silu outputs of a normalised MLP, |h2| < 65504 is assumed (inf otherwise).
+//
 // A wave owns one (input block, l2 group, node group) unit exactly like tp_block_kernel (a lane = one
 // channel u of one destination node, walking the node's CSR segment).  It proceeds in chunks of
 // CH edge slots:
@@ -19,9 +29,9 @@
 // Matrix-core and vector work of different waves overlap on the SIMD; HBM traffic per edge drops from
 // ~7.7 KB (write + read of w) to ~0.3 KB (h2 + harmonics + indices).
 //
-// h2p layout: [E, 32] with column g*8 + kk  <->  hidden feature pi(kk,g) = 16 (kk>>2) + 4 g + (kk&3):
-// exactly the registers lane group g of the hidden-layer kernel holds, and the order in which this
-// kernel's MFMA lane group g consumes the contraction index (A rows follow the same pi).
+// h2s layout: [E, 2, 32] fp16 (128 B per edge): piece 0 = hi, piece 1 = lo; column g*8 + kk of a piece  <->  hidden
+// feature pi(kk,g) = 16 (kk>>2) + 4 g + (kk&3): exactly the registers lane group g of the hidden-layer kernel
+// holds, and the 8 K-slots lane group g feeds to the MFMA (A rows follow the same pi).
 #include "cg_gen.h"
 #include "common.h"
 #include "sh.h"
@@ -29,6 +39,20 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float SPLIT_LO_SCALE = 2048.0f;          // 2^11
+constexpr float SPLIT_LO_INV = 1.0f / 2048.0f;
+constexpr float F16_MIN_NORMAL = 6.103515625e-05f;  // 2^-14
+
+// v ~= hi + 2^-11 lo.  fp16 subnormals are zeroed in software (hi: the residual then moves into lo), so the result
+// does not depend on whether the matrix unit flushes them.
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    const float h = fabsf(v) < F16_MIN_NORMAL ? 0.0f : (float)(_Float16)v;
+    const float r = (v - h) * SPLIT_LO_SCALE;
+    hi = (_Float16)h;
+    lo = fabsf(r) < F16_MIN_NORMAL ? (_Float16)0.0f : (_Float16)r;
+}
 
 constexpr int TILE_NODES = 64;
 constexpr int WAVES_PER_BLOCK = 4;
@@ -51,7 +75,7 @@ static_assert(sizeof(GroupEntry) == 32 * 4, "GroupEntry layout");
 
 struct Args {
     const float* x;
-    const float* h2p;   // [E, 32] permuted hidden features
+    const _Float16* h2s;  // [E, 2, 32] split hidden features (see header)
     const float* w2p;   // [32, w_pad] last MLP layer, pre-scaled, fused column order
     const float* sh;
     const int* rowptr;
@@ -93,13 +117,36 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
     // MTMAX: the plan caps an entry at the largest power-of-two channel count whose [u][c] block fits 64 columns
     constexpr int CAPC = NC > 32 ? 1 : NC > 16 ? 2 : NC > 8 ? 4 : NC > 4 ? 8 : NC > 2 ? 16 : NC > 1 ? 32 : 64;
     constexpr int MTMAX = (CAPC * NC + 15) / 16;
-    float av[MTMAX][8];
+    f16x8 ah[MTMAX], al[MTMAX];
+    float a_scale_inv;
+    {
+        float av[MTMAX][8];
+        float amax = 0.0f;
 #pragma unroll
-    for (int mt = 0; mt < MTMAX; ++mt) {
+        for (int mt = 0; mt < MTMAX; ++mt) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
-            av[mt][kk] = (mt < MT) ? a.w2p[(int64_t)k * a.w_pad + ge.w_base + mt * 16 + c] : 0.0f;
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+                av[mt][kk] = (mt < MT) ? a.w2p[(int64_t)k * a.w_pad + ge.w_base + mt * 16 + c] : 0.0f;
+                amax = fmaxf(amax, fabsf(av[mt][kk]));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        // power-of-two scale that puts the tile's largest magnitude in [2^13, 2^14)
+        int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+        e = amax > 0.0f ? max(-100, min(100, e)) : 13;
+        const float a_scale = __uint_as_float((unsigned)(127 + 13 - e) << 23);
+        a_scale_inv = __uint_as_float((unsigned)(127 - 13 + e) << 23);
+#pragma unroll
+        for (int mt = 0; mt < MTMAX; ++mt) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                _Float16 hi, lo;
+                split_f16(av[mt][kk] * a_scale, hi, lo);
+                ah[mt][kk] = hi;
+                al[mt][kk] = lo;
+            }
         }
     }
 
@@ -125,18 +172,18 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
                 const int jn = n >> ch_log2, so = n & (CH - 1);
                 const int begn = __shfl(beg, jn << cu_log2);
                 const int degn = __shfl(deg_node, jn << cu_log2);
-                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+                f16x8 bh = {0, 0, 0, 0, 0, 0, 0, 0}, bl = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef MATTEN_ABLATE_NO_H2LOAD
-                b0 = f32x4{1.f, 2.f, 3.f, 4.f};
-                b1 = b0;
+                bh = f16x8{1, 2, 3, 4, 1, 2, 3, 4};
+                bl = bh;
                 if (false) {
 #else
                 if (s0 + so < degn) {
 #endif
                     const int64_t en = begn + s0 + so;
-                    const f32x4* hp = reinterpret_cast<const f32x4*>(a.h2p + en * HID + g * 8);
-                    b0 = hp[0];
-                    b1 = hp[1];
+                    const f16x8* hp = reinterpret_cast<const f16x8*>(a.h2s + en * (2 * HID) + g * 8);
+                    bh = hp[0];
+                    bl = hp[HID / 8];
                     // stage the edge's harmonics once per edge (4 lanes x 32 B) instead of once per channel lane
                     const f32x4* yp4 = reinterpret_cast<const f32x4*>(a.sh + en * a.sh_stride + g * 8);
                     f32x4* yd = reinterpret_cast<f32x4*>(tile + (16 * t + c) * stride + ycol + g * 8);
@@ -147,18 +194,16 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
 #pragma unroll
                 for (int mt = 0; mt < MTMAX; ++mt) {
                     if (mt < MT) {
-                        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][kk], b0[kk], d, 0, 0, 0);
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][4 + kk], b1[kk], d, 0, 0, 0);
-                        *reinterpret_cast<f32x4*>(tile + (16 * t + c) * stride + mt * 16 + 4 * g) = d;
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        f32x4 dx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh, zero, 0, 0, 0);
+                        f32x4 dh = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, zero, 0, 0, 0);
+                        dx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, dx, 0, 0, 0);
+                        *reinterpret_cast<f32x4*>(tile + (16 * t + c) * stride + mt * 16 + 4 * g) =
+                            dh + SPLIT_LO_INV * dx;
                     }
                 }
 #else
-                if (b0[0] == 12345.f) tile[c] = b1[0];
+                if ((float)bh[0] == 12345.f) tile[c] = (float)bl[0];
 #endif
             }
         }
@@ -194,7 +239,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
     }
     if (valid) {
         const float nn = a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node];
-        const float norm = 1.0f / sqrtf(nn);
+        const float norm = a_scale_inv / sqrtf(nn);  // undoes the power-of-two scale of the A tile
         float* orow = a.agg + (int64_t)node * a.d_mid;
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) {
@@ -260,7 +305,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
     }
 }
 
-// Hidden layers of the radial MLP: rbf(|v|) -> 32 -> 32, written as h2p [E,32] (see header comment).
+// Hidden layers of the radial MLP: rbf(|v|) -> 32 -> 32, written as the split fp16 form h2s [E,2,32] (see header comment).
 constexpr int NT = 4;
 // silu on the hardware transcendental units: v_exp_f32 (2^x) + v_rcp_f32, ~1 ulp each, against the ~25-instruction
 // expf + IEEE division; the hidden kernel is bound by exactly this arithmetic (64 silu per edge and layer)
@@ -272,7 +317,7 @@ template <int KS0>
 __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __restrict__ geom, int64_t E, int n_basis,
                                                             float r_start, float r_end,
                                                             const float* __restrict__ w0p,
-                                                            const float* __restrict__ w1p, float* __restrict__ h2p) {
+                                                            const float* __restrict__ w1p, _Float16* __restrict__ h2s) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -323,9 +368,18 @@ __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __rest
             o1[r] = silu(o1[r]);
         }
         if (e < E) {
-            f32x4* dst = reinterpret_cast<f32x4*>(h2p + e * HID + g * 8);
-            dst[0] = o0;
-            dst[1] = o1;
+            f16x8 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                _Float16 h, l;
+                split_f16(o0[r], h, l);
+                hi[r] = h, lo[r] = l;
+                split_f16(o1[r], h, l);
+                hi[4 + r] = h, lo[4 + r] = l;
+            }
+            f16x8* dst = reinterpret_cast<f16x8*>(h2s + e * (2 * HID) + g * 8);
+            dst[0] = hi;
+            dst[HID / 8] = lo;
         }
     }
 }
@@ -333,15 +387,15 @@ __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __rest
 }  // namespace
 
 extern "C" int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
-                                    const float* w0p, int nb_pad, const float* w1p, int hidden, float* h2p,
+                                    const float* w0p, int nb_pad, const float* w1p, int hidden, uint16_t* h2s,
                                     matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || hidden != HID || (nb_pad & 3) || nb_pad < n_basis || nb_pad > 16) return MATTEN_EINVAL;
     if (n_edges == 0) return MATTEN_OK;
-    if (!geom_sorted || !w0p || !w1p || !h2p) return MATTEN_EINVAL;
+    if (!geom_sorted || !w0p || !w1p || !h2s) return MATTEN_EINVAL;
     unsigned grid = (unsigned)matten_cdiv(n_edges, 4 * NT * 16);
 #define LAUNCH(K) \
-    radial_hidden_kernel<K><<<grid, 256, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis, r_start, r_end, w0p, w1p, h2p)
+    radial_hidden_kernel<K><<<grid, 256, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis, r_start, r_end, w0p, w1p, (_Float16*)h2s)
     switch (nb_pad >> 2) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -353,7 +407,7 @@ extern "C" int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, i
     return MATTEN_OK;
 }
 
-extern "C" int matten_tp_fused(const float* x, int64_t d_in, const float* h2p, const float* w2p, int64_t w_pad,
+extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
                                const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr,
                                const int32_t* src_sorted, int64_t n_nodes, const int32_t* group_entries,
                                const int32_t* unit_start, int64_t n_entries, int64_t units_per_tile,
@@ -364,12 +418,12 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const float* h2p, c
         units_per_tile <= 0 || d_mid <= 0 || lds_floats_per_wave <= 0 || (lds_floats_per_wave & 3))
         return MATTEN_EINVAL;
     if (n_nodes == 0) return MATTEN_OK;
-    if (!x || !h2p || !w2p || !sh_sorted || !rowptr || !src_sorted || !group_entries || !unit_start || !agg)
+    if (!x || !h2s || !w2p || !sh_sorted || !rowptr || !src_sorted || !group_entries || !unit_start || !agg)
         return MATTEN_EINVAL;
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
     const size_t lds = sizeof(float) * (size_t)lds_floats_per_wave * WAVES_PER_BLOCK;
     if (lds > 64 * 1024) return MATTEN_EINVAL;
-    Args a{x, h2p, w2p, sh_sorted, rowptr, src_sorted, num_neigh, agg, (int)d_in, (int)w_pad, (int)sh_stride,
+    Args a{x, (const _Float16*)h2s, w2p, sh_sorted, rowptr, src_sorted, num_neigh, agg, (int)d_in, (int)w_pad, (int)sh_stride,
            (int)d_mid, (int)n_nodes, (int)lds_floats_per_wave, avg_num_neighbors};
     const int n_tiles = (int)matten_cdiv(n_nodes, TILE_NODES);
     const int blocks_per_tile = (int)matten_cdiv(units_per_tile, WAVES_PER_BLOCK);

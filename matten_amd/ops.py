@@ -231,12 +231,23 @@ def tp_blocks(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, uni
     return agg
 
 
+def split_hidden(h2p: torch.Tensor) -> torch.Tensor:
+    """fp32 [E,32] (already in the permuted column order) -> the split fp16 form [E,2,32] matten_tp_fused consumes:
+    v = hi + 2^-11 lo.  Test/tool helper: the production path gets this form from matten_radial_hidden."""
+    tiny = 2.0 ** -14
+    hi = torch.where(h2p.abs() < tiny, torch.zeros_like(h2p), h2p.half().float())
+    lo = (h2p - hi) * 2048.0
+    lo = torch.where(lo.abs() < tiny, torch.zeros_like(lo), lo)
+    return torch.stack([hi.half(), lo.half()], dim=1).contiguous()
+
+
 def radial_hidden(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p) -> torch.Tensor:
+    """-> h2s [E,2,32] fp16 (hi | lo pieces of the 32 hidden features, see include/matten_hip.h)"""
     lib = _lib.load()
     geom_sorted = _need(geom_sorted, torch.float32, "geom_sorted")
     w0p, w1p = _need(w0p, torch.float32, "w0p"), _need(w1p, torch.float32, "w1p")
     E = geom_sorted.shape[0]
-    h2p = torch.empty(E, 32, dtype=torch.float32, device=geom_sorted.device)
+    h2p = torch.empty(E, 2, 32, dtype=torch.float16, device=geom_sorted.device)
     with _timed("radial_hidden"):
         rc = lib.matten_radial_hidden(_ptr(geom_sorted), E, n_basis, r_start, r_end, _ptr(w0p), w0p.shape[0],
                                       _ptr(w1p), w0p.shape[1], _ptr(h2p), _stream())
@@ -252,7 +263,9 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_start, un
     if lib.matten_tp_tile_nodes() != TP_TILE_NODES:
         raise _lib.MattenHipError("plan.TP_TILE_NODES does not match the library's node tile")
     x = _need(x, torch.float32, "node_features")
-    h2p = _need(h2p, torch.float32, "h2p")
+    h2p = _need(h2p, torch.float16, "h2s")
+    if h2p.dim() != 3 or h2p.shape[1:] != (2, 32):
+        raise ValueError(f"h2s must be [E,2,32] fp16 (ops.split_hidden / ops.radial_hidden), got {tuple(h2p.shape)}")
     w2p = _need(w2p, torch.float32, "w2p")
     sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
     N, d_in = x.shape

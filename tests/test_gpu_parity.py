@@ -323,7 +323,7 @@ def test_tp_kernels_agree_and_match_oracle(per_node_norm):
     w2f = torch.nn.functional.pad(w2f, (0, (-w2f.shape[1]) % 16 + 16)).contiguous()
     # h2p column g*8+kk <-> hidden feature 16*(kk>>2) + 4*g + (kk&3)
     feat = torch.tensor([16 * (kk >> 2) + 4 * g + (kk & 3) for g in range(4) for kk in range(8)], device=DEV)
-    h2p = h2[perm.long()][:, feat].contiguous()
+    h2p = ops.split_hidden(h2[perm.long()][:, feat].contiguous())
     f = ops.tp_fused(x.to(DEV), h2p, w2f, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV), t.get("gstart", DEV),
                      p.group_units_per_tile, p.fused_lds_floats_per_wave, p.d_mid, avg, nn_)
     close(f, want_lr, 5e-5, "tp_fused vs oracle")

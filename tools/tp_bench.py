@@ -47,7 +47,7 @@ for kind in sorted(set(p.group_entries[:, 0])):
 
 
 # ---- fused kernel (radial hidden features + in-kernel last MLP layer) ----
-h2p = torch.randn(E, 32, device=dev)
+h2p = ops.split_hidden(torch.randn(E, 32, device=dev))
 w2p = torch.randn(32, wpad + 16, device=dev)
 def run_fused(entries_np, label):
     ent = torch.from_numpy(np.ascontiguousarray(entries_np)).to(dev)
