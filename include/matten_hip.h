@@ -155,7 +155,10 @@ int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t 
  *                         literal-coefficient CG contraction + CSR neighbour sum
  *   w2p[32, w_pad]: last layer weights pre-scaled (1/sqrt(32) * normalize2mom(silu)), columns in the
  *                   fused [entry][u][coupling] order of group_entries, w_pad >= w_cols + 16
- *   group_entries / unit_start: as matten_tp_blocks, with mul * couplings <= 64 weight columns per entry
+ *   group_entries: as matten_tp_blocks, with mul * couplings <= 64 weight columns per entry
+ *   unit_map[units_per_tile]: wave index inside a node tile -> entry << 8 | node group (of 64 >> cu_log2 nodes); any
+ *                   bijection is valid, the host orders it node group first (plan.fused_unit_map) so the waves of a
+ *                   workgroup read the same hidden-feature / harmonics rows
  *   lds_floats_per_wave: max over entries of 16*T*(16*ceil(mul*NC/16)+36), T = max(1, nodes_per_wave/16)
  *                   (sh_sorted rows must be 32 floats apart: sh_stride == 32)
  * ------------------------------------------------------------------------------------------ */
@@ -164,7 +167,7 @@ int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, int n_basis,
                          matten_stream_t stream);
 int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
                     const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
-                    int64_t n_nodes, const int32_t* group_entries, const int32_t* unit_start, int64_t n_entries,
+                    int64_t n_nodes, const int32_t* group_entries, const int32_t* unit_map, int64_t n_entries,
                     int64_t units_per_tile, int64_t lds_floats_per_wave, int64_t d_mid, float avg_num_neighbors,
                     const float* num_neigh, float* agg /*[N,d_mid]*/, matten_stream_t stream);
 

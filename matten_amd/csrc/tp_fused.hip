@@ -237,7 +237,11 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
 #endif
         __builtin_amdgcn_wave_barrier();  // LDS is in order per wave: the next chunk's stores follow these reads
     }
+#ifdef MATTEN_ABLATE_NO_STORE
+    if (valid && acc[0] == 12345.678f) {
+#else
     if (valid) {
+#endif
         const float nn = a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node];
         const float norm = a_scale_inv / sqrtf(nn);  // undoes the power-of-two scale of the A tile
         float* orow = a.agg + (int64_t)node * a.d_mid;
@@ -254,6 +258,224 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
     }
 }
 
+
+// ---- workgroup-shared staging (units flagged by the host, plan.fused_unit_map) --------------------------------------
+// When the four waves of a workgroup contract four entries of the SAME destination nodes (equal lanes per node, one or
+// two 16-edge MFMA tiles per chunk) they need the same hidden-feature and harmonics rows.  Each of the 256 threads then
+// fetches ONE 16-byte piece per MFMA tile of the chunk's edge rows (hi 64 B | lo 64 B | harmonics 128 B), one chunk
+// ahead of its use (4-8 registers in flight instead of 16-32 per wave), and publishes it in a double-buffered LDS
+// stage: a quarter of the vector-memory requests per wave, their latency behind a whole chunk of work, and the
+// harmonics are no longer copied into every wave's private tile.  One workgroup barrier per chunk.  Workgroups with
+// fewer than four entries for their nodes are filled up by the host with loader-only units (run_loader_only).
+constexpr int STAGE_ROW = 68;               // floats per staged edge row: 16 hi | 16 lo | 32 harmonics | 4 pad (banks)
+constexpr int STAGE_TMAX = 2;               // MFMA tiles (16 edge rows each) per chunk a shared workgroup may have
+constexpr int STAGE_FLOATS = 16 * STAGE_TMAX * STAGE_ROW;
+constexpr int STAGE_TOTAL_FLOATS = 2 * STAGE_FLOATS;
+
+// loader role of a thread: (edge row of the chunk, 16-byte piece of the row) per MFMA tile; fixed for the whole walk
+struct StageLoader {
+    const char* base;
+    int64_t row_bytes;
+    float* st_w;
+    int beg_ld[STAGE_TMAX], deg_ld[STAGE_TMAX], so_ld[STAGE_TMAX];
+    int T, CH;
+    f32x4 pf[STAGE_TMAX];
+
+    __device__ __forceinline__ void init(const Args& a, float* stage, int cu_log2, int beg, int deg_node) {
+        const int npw = 64 >> cu_log2;
+        T = npw > 16 ? 2 : 1;
+        const int ch_log2 = npw >= 16 ? 0 : 4 - (6 - cu_log2);
+        CH = 1 << ch_log2;
+        const int piece = threadIdx.x & 15;
+        base = piece < 8 ? reinterpret_cast<const char*>(a.h2s) + piece * 16
+                         : reinterpret_cast<const char*>(a.sh) + (piece - 8) * 16;
+        row_bytes = piece < 8 ? (int64_t)(2 * HID * sizeof(_Float16)) : (int64_t)a.sh_stride * 4;
+        st_w = stage + (threadIdx.x >> 4) * STAGE_ROW + piece * 4;
+#pragma unroll
+        for (int t = 0; t < STAGE_TMAX; ++t) {
+            const int n = (int)(threadIdx.x >> 4) + 16 * t;
+            const int jn = (n >> ch_log2) & (npw - 1);
+            so_ld[t] = n & (CH - 1);
+            beg_ld[t] = __shfl(beg, jn << cu_log2);
+            deg_ld[t] = __shfl(deg_node, jn << cu_log2);
+            pf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // fetch the pieces of the chunk starting at slot s0 (past the end of a segment: its last edge again, never consumed)
+    __device__ __forceinline__ void issue(int s0) {
+#pragma unroll
+        for (int t = 0; t < STAGE_TMAX; ++t)
+            if (t < T && deg_ld[t] > 0)
+                pf[t] = *reinterpret_cast<const f32x4*>(base + (int64_t)(beg_ld[t] + min(s0 + so_ld[t], deg_ld[t] - 1)) * row_bytes);
+    }
+    __device__ __forceinline__ void publish(int buf) {
+#pragma unroll
+        for (int t = 0; t < STAGE_TMAX; ++t)
+            if (t < T) *reinterpret_cast<f32x4*>(st_w + buf * STAGE_FLOATS + 16 * t * STAGE_ROW) = pf[t];
+    }
+};
+
+// a unit that only feeds the stage (same barrier sequence as run_group_shared)
+__device__ __forceinline__ void run_loader_only(const Args& a, int cu_log2, float* __restrict__ stage, int beg, int deg_node,
+                                                int maxdeg) {
+    StageLoader ld;
+    ld.init(a, stage, cu_log2, beg, deg_node);
+    ld.issue(0);
+    ld.publish(0);
+    __syncthreads();
+    int buf = 0;
+    for (int s0 = 0; s0 < maxdeg; s0 += ld.CH, buf ^= 1) {
+        ld.issue(s0 + ld.CH);
+        ld.publish(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+template <int L1, int GI>
+__device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry& ge, float* __restrict__ tile,
+                                                 float* __restrict__ stage, int node, int lane, bool valid, int beg,
+                                                 int deg_node, int maxdeg) {
+    const int deg = valid ? deg_node : 0;
+    using G = matten::Group<L1, GI>;
+    constexpr int NC = G::NC;
+    float acc[G::NACC];
+#pragma unroll
+    for (int k = 0; k < G::NACC; ++k) acc[k] = 0.0f;
+
+    const unsigned mask = ge.mask;
+    const int cu_log2 = ge.cu_log2;              // >= 1 here: at most 32 nodes per wave
+    const int cu = 1 << cu_log2;
+    const int npw = 64 >> cu_log2;
+    const int ch_log2 = npw >= 16 ? 0 : 4 - (6 - cu_log2);
+    const int CH = 1 << ch_log2;
+    const int T = npw > 16 ? 2 : 1;
+    const int ncols = ge.mul * NC;
+    const int MT = (ncols + 15) >> 4;
+    const int stride = MT * 16 + 4;              // floats per edge row of the wave's weight tile
+
+    const int j = lane >> cu_log2;
+    const int u = lane & (cu - 1);
+    const int g = lane >> 4, c = lane & 15;
+    const int xcol = ge.x_off + u * G::D1;
+    constexpr int CAPC = NC > 32 ? 1 : NC > 16 ? 2 : NC > 8 ? 4 : NC > 4 ? 8 : NC > 2 ? 16 : NC > 1 ? 32 : 64;
+    constexpr int MTMAX = (CAPC * NC + 15) / 16;
+    f16x8 ah[MTMAX], al[MTMAX];
+    float a_scale_inv;
+    {
+        float av[MTMAX][8];
+        float amax = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MTMAX; ++mt) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+                av[mt][kk] = (mt < MT) ? a.w2p[(int64_t)k * a.w_pad + ge.w_base + mt * 16 + c] : 0.0f;
+                amax = fmaxf(amax, fabsf(av[mt][kk]));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+        e = amax > 0.0f ? max(-100, min(100, e)) : 13;
+        const float a_scale = __uint_as_float((unsigned)(127 + 13 - e) << 23);
+        a_scale_inv = __uint_as_float((unsigned)(127 - 13 + e) << 23);
+#pragma unroll
+        for (int mt = 0; mt < MTMAX; ++mt) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                _Float16 hi, lo;
+                split_f16(av[mt][kk] * a_scale, hi, lo);
+                ah[mt][kk] = hi;
+                al[mt][kk] = lo;
+            }
+        }
+    }
+
+    StageLoader ld;
+    ld.init(a, stage, cu_log2, beg, deg_node);
+    ld.issue(0);
+
+    const int e_last = deg > 0 ? beg + deg - 1 : 0;
+    float xn[G::D1];
+    int src_nn;
+    {
+        const int src0 = a.src_sorted[min(beg, e_last)];
+        src_nn = a.src_sorted[min(beg + 1, e_last)];
+        const float* xp0 = a.x + (int64_t)src0 * a.d_in + xcol;
+#pragma unroll
+        for (int i = 0; i < G::D1; ++i) xn[i] = xp0[i];
+    }
+    ld.publish(0);
+    __syncthreads();
+    int buf = 0;
+    for (int s0 = 0; s0 < maxdeg; s0 += CH, buf ^= 1) {
+        ld.issue(s0 + CH);
+        const float* sb = stage + buf * STAGE_FLOATS;
+#pragma unroll
+        for (int t = 0; t < STAGE_TMAX; ++t) {
+            if (t < T) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(sb + (16 * t + c) * STAGE_ROW + g * 4);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(sb + (16 * t + c) * STAGE_ROW + 16 + g * 4);
+#pragma unroll
+                for (int mt = 0; mt < MTMAX; ++mt) {
+                    if (mt < MT) {
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        f32x4 dx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh, zero, 0, 0, 0);
+                        f32x4 dh = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, zero, 0, 0, 0);
+                        dx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, dx, 0, 0, 0);
+                        *reinterpret_cast<f32x4*>(tile + (16 * t + c) * stride + mt * 16 + 4 * g) = dh + SPLIT_LO_INV * dx;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the weight tile is written
+        __builtin_amdgcn_wave_barrier();
+        for (int so = 0; so < CH; ++so) {
+            const int s = s0 + so;
+            if (s >= maxdeg) break;
+            float x[G::D1];
+#pragma unroll
+            for (int i = 0; i < G::D1; ++i) x[i] = xn[i];
+            {
+                const float* xp = a.x + (int64_t)src_nn * a.d_in + xcol;
+#pragma unroll
+                for (int i = 0; i < G::D1; ++i) xn[i] = xp[i];
+                src_nn = a.src_sorted[min(beg + s + 2, e_last)];
+            }
+            if (s < deg) {
+                const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
+                const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
+                float y[G::NY], w[NC];
+#pragma unroll
+                for (int jj = 0; jj < G::NY; ++jj) y[jj] = yp[jj];
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+                G::apply(mask, x, y, w, acc);
+            }
+        }
+        ld.publish(buf ^ 1);
+        __syncthreads();  // the next stage is published; every wave is done with this chunk's rows
+    }
+    if (valid) {
+        const float nn = a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node];
+        const float norm = a_scale_inv / sqrtf(nn);
+        float* orow = a.agg + (int64_t)node * a.d_mid;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            if ((mask >> cc) & 1u) {
+                const int d3 = 2 * G::L3[cc] + 1;
+                float* op = orow + ge.out_off[cc] + u * d3;
+#pragma unroll
+                for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
+                    if (k < d3) op[k] = acc[G::OFF[cc] + k] * norm;
+            }
+        }
+    }
+}
+
+#define MATTEN_GROUP_CASE_SHARED(L1, GI) \
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI>(a, ge, tile, stage, node, lane, valid, beg, deg, maxdeg); break;
+
 #define MATTEN_GROUP_CASE(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, node, lane, valid, beg, deg, maxdeg); break;
 
@@ -261,7 +483,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
 #define TPF_MIN_BLOCKS 3
 #endif
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused_kernel(Args a, const GroupEntry* __restrict__ entries,
-                                                                        const int* __restrict__ ustart,
+                                                                        const int* __restrict__ umap,
                                                                         int n_entries, int units_per_tile,
                                                                         int blocks_per_tile, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -275,13 +497,12 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
     const int lane = threadIdx.x & 63;
     float* tile = lds + wave * a.lds_per_wave;
 
-    int lo = 0, hi = n_entries;  // last entry with ustart[entry] <= unit (wave-uniform)
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (ustart[mid] <= unit) lo = mid; else hi = mid;
-    }
-    const GroupEntry& ge = entries[lo];
-    const int r = unit - ustart[lo];
+    // unit -> (entry, node group of the tile), host-ordered (plan.fused_unit_map)
+    const int um = __builtin_amdgcn_readfirstlane(umap[unit]);
+    if (((um >> 8) & 0xffff) >= n_entries) return;
+    const GroupEntry& ge = entries[(um >> 8) & 0xffff];
+    const int r = um & 255;
+    const bool shared_stage = (um >> 24) & 1;  // uniform over the workgroup (host contract)
 
     const int cu_log2 = ge.cu_log2;
     const int cu = 1 << cu_log2;
@@ -299,6 +520,18 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
     int maxdeg = deg;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+    if (shared_stage) {
+        float* stage = lds + WAVES_PER_BLOCK * a.lds_per_wave;
+        if ((um >> 25) & 1) {  // loader-only unit: fills the workgroup up to four waves
+            run_loader_only(a, cu_log2, stage, beg, deg, maxdeg);
+            return;
+        }
+        switch (ge.kind) {
+            MATTEN_FOR_EACH_GROUP(MATTEN_GROUP_CASE_SHARED)
+            default: break;
+        }
+        return;
+    }
     switch (ge.kind) {
         MATTEN_FOR_EACH_GROUP(MATTEN_GROUP_CASE)
         default: break;
@@ -410,7 +643,7 @@ extern "C" int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, i
 extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
                                const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr,
                                const int32_t* src_sorted, int64_t n_nodes, const int32_t* group_entries,
-                               const int32_t* unit_start, int64_t n_entries, int64_t units_per_tile,
+                               const int32_t* unit_map, int64_t n_entries, int64_t units_per_tile,
                                int64_t lds_floats_per_wave, int64_t d_mid, float avg_num_neighbors,
                                const float* num_neigh, float* agg, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -418,10 +651,10 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
         units_per_tile <= 0 || d_mid <= 0 || lds_floats_per_wave <= 0 || (lds_floats_per_wave & 3))
         return MATTEN_EINVAL;
     if (n_nodes == 0) return MATTEN_OK;
-    if (!x || !h2s || !w2p || !sh_sorted || !rowptr || !src_sorted || !group_entries || !unit_start || !agg)
+    if (!x || !h2s || !w2p || !sh_sorted || !rowptr || !src_sorted || !group_entries || !unit_map || !agg)
         return MATTEN_EINVAL;
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
-    const size_t lds = sizeof(float) * (size_t)lds_floats_per_wave * WAVES_PER_BLOCK;
+    const size_t lds = sizeof(float) * ((size_t)lds_floats_per_wave * WAVES_PER_BLOCK + STAGE_TOTAL_FLOATS);
     if (lds > 64 * 1024) return MATTEN_EINVAL;
     Args a{x, (const _Float16*)h2s, w2p, sh_sorted, rowptr, src_sorted, num_neigh, agg, (int)d_in, (int)w_pad, (int)sh_stride,
            (int)d_mid, (int)n_nodes, (int)lds_floats_per_wave, avg_num_neighbors};
@@ -430,7 +663,7 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
     const int64_t grid = matten_cdiv(n_tiles, N_XCD) * N_XCD * (int64_t)blocks_per_tile;
     if (grid >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
     tp_fused_kernel<<<(unsigned)grid, WAVES_PER_BLOCK * 64, lds, stream>>>(
-        a, (const GroupEntry*)group_entries, unit_start, (int)n_entries, (int)units_per_tile, blocks_per_tile, n_tiles);
+        a, (const GroupEntry*)group_entries, unit_map, (int)n_entries, (int)units_per_tile, blocks_per_tile, n_tiles);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

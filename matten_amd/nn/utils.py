@@ -181,7 +181,7 @@ class UVUTensorProduct(torch.nn.Module):
         self._tables = DeviceTables(
             m_idx=self.plan.m_terms_idx, m_coef=self.plan.m_terms_coef, out_meta=self.plan.out_meta,
             entries=self.plan.path_entries, unit_start=self.plan.unit_start,
-            gentries=self.plan.group_entries, gstart=self.plan.group_unit_start,
+            gentries=self.plan.group_entries, gstart=self.plan.group_unit_start, gumap=self.plan.fused_unit_map,
             bw_col_meta=self.plan.bw_col_meta, bw_nnz_ijk=self.plan.bw_nnz_ijk, bw_nnz_c=self.plan.bw_nnz_c,
         )
 
@@ -207,7 +207,7 @@ class UVUTensorProduct(torch.nn.Module):
             h2p, w2p = self.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1)
             return ops.tp_fused(
                 node_feats, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
-                self._tables.get("gentries", dev), self._tables.get("gstart", dev), self.plan.group_units_per_tile,
+                self._tables.get("gentries", dev), self._tables.get("gumap", dev), len(self.plan.fused_unit_map),
                 self.plan.fused_lds_floats_per_wave, self.plan.d_mid, avg, num_neigh,
             )
         w_edge = self.weight_nn(data[DataKey.AMD_GEOM], int(nb), r0, r1)

@@ -255,7 +255,7 @@ def radial_hidden(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, 
     return h2p
 
 
-def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_start, units_per_tile: int,
+def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, units_per_tile: int,
              lds_floats_per_wave: int, d_mid: int, avg_num_neighbors: float, num_neigh=None) -> torch.Tensor:
     lib = _lib.load()
     from .plan import TP_TILE_NODES
@@ -271,11 +271,13 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_start, un
     N, d_in = x.shape
     if num_neigh is not None:
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
+    if unit_map.numel() != units_per_tile:
+        raise ValueError(f"unit_map has {unit_map.numel()} units, expected {units_per_tile} (plan.fused_unit_map)")
     agg = torch.empty(N, d_mid, dtype=torch.float32, device=x.device)
     with _timed(f"tp_scatter/d_mid={d_mid}"):
         rc = lib.matten_tp_fused(_ptr(x), d_in, _ptr(h2p), _ptr(w2p), w2p.shape[1], _ptr(sh_sorted),
                                  sh_sorted.shape[1], _ptr(rowptr), _ptr(src_sorted), N, _ptr(entries),
-                                 _ptr(unit_start), entries.shape[0], units_per_tile, lds_floats_per_wave, d_mid,
+                                 _ptr(unit_map), entries.shape[0], units_per_tile, lds_floats_per_wave, d_mid,
                                  float(avg_num_neighbors or 0.0), _ptr(num_neigh), _ptr(agg), _stream())
     _lib.check(rc, "matten_tp_fused")
     return agg

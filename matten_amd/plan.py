@@ -37,6 +37,48 @@ TP_KIND_STRIDE = 8
 ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
 
 
+FUSED_UNIT_SHARED = 1 << 24       # the unit's workgroup stages hidden features / harmonics once for its four waves
+FUSED_UNIT_LOADER_ONLY = 1 << 25  # padding unit of a shared workgroup: feeds the stage, contracts nothing
+
+
+def fused_unit_map(group_entries, order: Optional[str] = None) -> np.ndarray:
+    """Wave (unit) index inside a node tile -> packed (flags | entry << 8 | node group) for matten_tp_fused.
+
+    'node' order (default): runs of consecutive entries with the same lanes-per-node are sorted by kind, cut into
+    workgroups of at most four entries and walked node group first, so the four waves of a workgroup (units 4b..4b+3)
+    contract different entries of the SAME destination nodes and fetch each hidden-feature / harmonics row once per
+    workgroup through a double-buffered LDS stage (FUSED_UNIT_SHARED, see tp_fused.hip).  Workgroups with fewer than
+    four entries are filled with FUSED_UNIT_LOADER_ONLY units.  Entries with one lane per node (64 nodes per wave)
+    and the 'entry' order (MATTEN_FUSED_UNIT_ORDER=entry, A/B harness) use the unshared path, entry-major."""
+    order = order or os.environ.get("MATTEN_FUSED_UNIT_ORDER", "node")
+    ent = np.asarray(group_entries).reshape(-1, 32)
+    assert len(ent) < 65536
+    shared_units: List[int] = []
+    plain_units: List[int] = []
+    i = 0
+    while i < len(ent):
+        j = i
+        while j < len(ent) and ent[j][3] == ent[i][3]:
+            j += 1
+        cu_log2 = int(ent[i][3])
+        npw = max(1, 64 >> cu_log2)
+        groups = -(-TP_TILE_NODES // npw)
+        assert groups < 256
+        run = sorted(range(i, j), key=lambda e: int(ent[e][0]))  # stable: kind-homogeneous workgroups where possible
+        if order == "node" and cu_log2 >= 1:
+            nblk = -(-len(run) // 4)
+            cuts = [round(k * len(run) / nblk) for k in range(nblk + 1)]
+            for r in range(groups):
+                for k in range(nblk):
+                    blk = run[cuts[k]:cuts[k + 1]]
+                    shared_units += [FUSED_UNIT_SHARED | (e << 8) | r for e in blk]
+                    shared_units += [FUSED_UNIT_SHARED | FUSED_UNIT_LOADER_ONLY | (blk[-1] << 8) | r] * (4 - len(blk))
+        else:
+            plain_units += [(e << 8) | r for e in run for r in range(groups)]
+        i = j
+    return np.array(shared_units + plain_units, dtype=np.int64).astype(np.int32)
+
+
 def tp_path_exists(irreps_in1, irreps_in2, ir_out) -> bool:
     """reference nn/utils.py:358-367"""
     ir_out = Irrep(ir_out)
@@ -93,6 +135,7 @@ class UVUPlan:
     group_units_per_tile: int = 0
     fused_cols: np.ndarray = None     # int64 [W_fused]: fused weight column -> reference weight column, -1 = zero
     fused_lds_floats_per_wave: int = 0  # LDS tile of matten_tp_fused
+    fused_unit_map: np.ndarray = None   # int32 [fused units per tile]: unit -> flags | entry << 8 | node group
     # adjoint tables (matten_tp_backward)
     bw_col_meta: np.ndarray = None    # int32 [W, 4] {x_base, out_base, nnz_begin, nnz_count | y_off << 16}
     bw_nnz_ijk: np.ndarray = None     # uint8 [nnz, 4]
@@ -208,7 +251,9 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                 cap //= 2
             for u0 in range(0, mul, cap):
                 mul_c = min(cap, mul - u0)
-                cu_log2 = max(0, (mul_c - 1).bit_length())
+                # at least two lanes per node (a multiplicity-1 entry idles one of them): at most 32 nodes, i.e. two
+                # 16-edge MFMA tiles, per wave and chunk, which is what the fused kernel's shared LDS stage holds
+                cu_log2 = max(1, (mul_c - 1).bit_length())
                 nodes_per_wave = max(1, 64 // (1 << cu_log2))
                 n_tiles16 = max(1, nodes_per_wave // 16)
                 lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(combos)) // 16)) + 32 + 4))
@@ -254,6 +299,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         group_entries=np.array(gentries, dtype=np.int64).astype(np.int32), group_unit_start=np.array(gstart, dtype=np.int32),
         group_units_per_tile=gstart[-1], fused_cols=np.array(fused_cols, dtype=np.int64),
         fused_lds_floats_per_wave=(lds_need + 3) // 4 * 4,
+        fused_unit_map=fused_unit_map(np.array(gentries, dtype=np.int64)),
     )
 
 

@@ -294,7 +294,7 @@ def test_tp_kernels_agree_and_match_oracle(per_node_norm):
     p = mplan.plan_uvu(irreps_in, sh, irreps_in)
     assert p.weight_numel == ref_tp.tp.weight_numel and p.d_mid == msg.shape[1]
     t = DeviceTables(m_idx=p.m_terms_idx, m_coef=p.m_terms_coef, out_meta=p.out_meta, entries=p.path_entries,
-                     unit_start=p.unit_start, gentries=p.group_entries, gstart=p.group_unit_start)
+                     unit_start=p.unit_start, gentries=p.group_entries, gstart=p.group_unit_start, gumap=p.fused_unit_map)
     g = _to(cpu, DEV)
     perm, rowptr, src, _ = ops.csr_build(g["edge_index"], N)
     geo = ops.edge_geom(g["pos"], g["edge_index"], g["edge_cell_shift"], g["cell"], g["batch"], perm, 4)
@@ -324,8 +324,8 @@ def test_tp_kernels_agree_and_match_oracle(per_node_norm):
     # h2p column g*8+kk <-> hidden feature 16*(kk>>2) + 4*g + (kk&3)
     feat = torch.tensor([16 * (kk >> 2) + 4 * g + (kk & 3) for g in range(4) for kk in range(8)], device=DEV)
     h2p = ops.split_hidden(h2[perm.long()][:, feat].contiguous())
-    f = ops.tp_fused(x.to(DEV), h2p, w2f, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV), t.get("gstart", DEV),
-                     p.group_units_per_tile, p.fused_lds_floats_per_wave, p.d_mid, avg, nn_)
+    f = ops.tp_fused(x.to(DEV), h2p, w2f, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV), t.get("gumap", DEV),
+                     len(p.fused_unit_map), p.fused_lds_floats_per_wave, p.d_mid, avg, nn_)
     close(f, want_lr, 5e-5, "tp_fused vs oracle")
     close(c, want, 2e-5, "tp_blocks vs oracle")
     close(c, a, 2e-5, "tp_blocks vs tp_paths")

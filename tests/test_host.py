@@ -309,3 +309,31 @@ def test_dataset_json_reader_matches_oracle_reader(golden_dir):
     for a, b in zip(got, want):
         for k in ("lattice", "cart_coords", "atomic_numbers", "elastic_tensor_full"):
             assert np.array_equal(a[k], b[k]), k
+
+
+def test_fused_unit_map_covers_every_entry_and_node_group_once():
+    """plan.fused_unit_map: every (entry, node group) appears exactly once as a working unit; shared workgroups
+    (four consecutive units) are homogeneous in node group and lanes-per-node and padded with loader-only units."""
+    from matten_amd import plan as mp
+    from matten_amd.o3 import Irreps
+
+    for irr in ("32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e", "16x0e", "3x0e+5x1o+1x2e", "64x0e+1x1o+7x2e+2x4e"):
+        p = mp.plan_uvu(irr, Irreps.spherical_harmonics(4), irr)
+        for order in ("node", "entry"):
+            m = mp.fused_unit_map(p.group_entries, order)
+            work = [(int(v) >> 8 & 0xFFFF, int(v) & 255) for v in m if not int(v) & mp.FUSED_UNIT_LOADER_ONLY]
+            want = set()
+            for e, row in enumerate(p.group_entries):
+                npw = max(1, 64 >> int(row[3]))
+                want |= {(e, r) for r in range(-(-mp.TP_TILE_NODES // npw))}
+            assert len(work) == len(set(work)) and set(work) == want
+            shared = [bool(int(v) & mp.FUSED_UNIT_SHARED) for v in m]
+            assert order == "node" or not any(shared)
+            n_shared = sum(shared)
+            assert n_shared % 4 == 0 and all(shared[:n_shared]) and not any(shared[n_shared:])
+            for b in range(0, n_shared, 4):
+                blk = [int(v) for v in m[b:b + 4]]
+                assert len({v & 255 for v in blk}) == 1
+                assert len({int(p.group_entries[v >> 8 & 0xFFFF][3]) for v in blk}) == 1
+                assert int(p.group_entries[blk[0] >> 8 & 0xFFFF][3]) >= 1
+                assert not blk[0] & mp.FUSED_UNIT_LOADER_ONLY

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""tp_fused on the last conv layer (fcc-64 x B crystals), one launch per group kind: where the kernel's time goes."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from matten_amd import ops, plan as mplan
+from matten_amd.data import synthetic
+from matten_amd.data.graph import collate
+from matten_amd.o3 import Irreps
+
+B = int(os.environ.get("B", 1000))
+dev = "cuda:0"
+graphs = synthetic.fcc64_graphs(min(B, 64))
+graphs = [graphs[i % len(graphs)] for i in range(B)]
+b = collate(graphs, device=dev)
+N, E = b["pos"].shape[0], b["edge_index"].shape[1]
+irr = "32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e"
+p = mplan.plan_uvu(irr, Irreps.spherical_harmonics(4), irr)
+perm, rowptr, src, _ = ops.csr_build(b["edge_index"], N)
+geo = ops.edge_geom(b["pos"], b["edge_index"], b["edge_cell_shift"], b["cell"], b["batch"], perm, 4)
+x = torch.randn(N, p.d_in, device=dev)
+wpad = (len(p.fused_cols) + 15) // 16 * 16
+h2p = ops.split_hidden(torch.randn(E, 32, device=dev))
+w2p = torch.randn(32, wpad + 16, device=dev)
+
+def run_fused(entries_np, label):
+    ent = torch.from_numpy(np.ascontiguousarray(entries_np)).to(dev)
+    ust = torch.from_numpy(mplan.fused_unit_map(entries_np)).to(dev)
+    upt = ust.numel()
+    f = lambda: ops.tp_fused(x, h2p, w2p, geo["sh_sorted"], rowptr, src, ent, ust, upt, p.fused_lds_floats_per_wave, p.d_mid, 18.0)
+    for _ in range(2): f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5): f()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
+    cols = sum(int(r[2]) * bin(int(r[4]) & 0xffffffff).count("1") for r in entries_np)
+    print(f"fused {label:14s} entries {len(entries_np):2d} waves/tile {upt:3d} cols {cols:4d}  {dt*1e3:7.3f} ms", flush=True)
+
+run_fused(p.group_entries, "all")
+for kind in sorted(set(p.group_entries[:, 0])):
+    run_fused(p.group_entries[p.group_entries[:, 0] == kind], f"l1={kind // mplan.TP_KIND_STRIDE} g={kind % mplan.TP_KIND_STRIDE}")

@@ -51,11 +51,8 @@ h2p = ops.split_hidden(torch.randn(E, 32, device=dev))
 w2p = torch.randn(32, wpad + 16, device=dev)
 def run_fused(entries_np, label):
     ent = torch.from_numpy(np.ascontiguousarray(entries_np)).to(dev)
-    waves = []
-    for row in entries_np:
-        cu = 1 << int(row[3]); npw = max(1, 64 // cu); waves.append(-(-mplan.TP_TILE_NODES // npw))
-    ust = torch.tensor(np.concatenate([[0], np.cumsum(waves)]), dtype=torch.int32, device=dev)
-    upt = int(ust[-1])
+    ust = torch.from_numpy(mplan.fused_unit_map(entries_np)).to(dev)
+    upt = ust.numel()
     f = lambda: ops.tp_fused(x, h2p, w2p, geo["sh_sorted"], rowptr, src, ent, ust, upt, p.fused_lds_floats_per_wave, p.d_mid, 18.0)
     for _ in range(2): f()
     torch.cuda.synchronize(); t = time.perf_counter()
