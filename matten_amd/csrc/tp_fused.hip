@@ -272,6 +272,23 @@ constexpr int STAGE_TMAX = 2;               // MFMA tiles (16 edge rows each) pe
 constexpr int STAGE_FLOATS = 16 * STAGE_TMAX * STAGE_ROW;
 constexpr int STAGE_TOTAL_FLOATS = 2 * STAGE_FLOATS;
 
+// w tile rows [edge][col]: D fragments of MTC column tiles, hi.hi + 2^-11 (lo.hi + hi.lo), 16-byte LDS stores
+template <int MTC>
+__device__ __forceinline__ void mfma_tiles(const f16x8* __restrict__ ah, const f16x8* __restrict__ al, f16x8 bh, f16x8 bl,
+                                           float* __restrict__ trow) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dx[MTC], dh[MTC];
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) {
+        dx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh, zero, 0, 0, 0);
+        dh[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, zero, 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) dx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, dx[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) *reinterpret_cast<f32x4*>(trow + mt * 16) = dh[mt] + SPLIT_LO_INV * dx[mt];
+}
+
 // loader role of a thread: (edge row of the chunk, 16-byte piece of the row) per MFMA tile; fixed for the whole walk
 struct StageLoader {
     const char* base;
@@ -305,7 +322,11 @@ struct StageLoader {
     __device__ __forceinline__ void issue(int s0) {
 #pragma unroll
         for (int t = 0; t < STAGE_TMAX; ++t)
+#ifdef MATTEN_ABLATE_NO_H2LOAD
+            if (false)
+#else
             if (t < T && deg_ld[t] > 0)
+#endif
                 pf[t] = *reinterpret_cast<const f32x4*>(base + (int64_t)(beg_ld[t] + min(s0 + so_ld[t], deg_ld[t] - 1)) * row_bytes);
     }
     __device__ __forceinline__ void publish(int buf) {
@@ -351,7 +372,6 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const int T = npw > 16 ? 2 : 1;
     const int ncols = ge.mul * NC;
     const int MT = (ncols + 15) >> 4;
-    const int stride = MT * 16 + 4;              // floats per edge row of the wave's weight tile
 
     const int j = lane >> cu_log2;
     const int u = lane & (cu - 1);
@@ -359,6 +379,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const int xcol = ge.x_off + u * G::D1;
     constexpr int CAPC = NC > 32 ? 1 : NC > 16 ? 2 : NC > 8 ? 4 : NC > 4 ? 8 : NC > 2 ? 16 : NC > 1 ? 32 : 64;
     constexpr int MTMAX = (CAPC * NC + 15) / 16;
+    const int stride = MT * 16 + 4;              // floats per edge row of the wave's weight tile
     f16x8 ah[MTMAX], al[MTMAX];
     float a_scale_inv;
     {
@@ -416,20 +437,21 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             if (t < T) {
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(sb + (16 * t + c) * STAGE_ROW + g * 4);
                 const f16x8 bl = *reinterpret_cast<const f16x8*>(sb + (16 * t + c) * STAGE_ROW + 16 + g * 4);
-#pragma unroll
-                for (int mt = 0; mt < MTMAX; ++mt) {
-                    if (mt < MT) {
-                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                        f32x4 dx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh, zero, 0, 0, 0);
-                        f32x4 dh = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, zero, 0, 0, 0);
-                        dx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, dx, 0, 0, 0);
-                        *reinterpret_cast<f32x4*>(tile + (16 * t + c) * stride + mt * 16 + 4 * g) = dh + SPLIT_LO_INV * dx;
-                    }
-                }
+#ifndef MATTEN_ABLATE_NO_MFMA
+                float* trow = tile + (16 * t + c) * stride + 4 * g;
+                // branch-free per tile count: the 3 MTC matrix instructions of a chunk interleave freely
+                if (MTMAX == 1 || MT == 1) mfma_tiles<1>(ah, al, bh, bl, trow);
+                else if (MTMAX == 2 || MT == 2) mfma_tiles<(MTMAX < 2 ? MTMAX : 2)>(ah, al, bh, bl, trow);
+                else if (MTMAX == 3 || MT == 3) mfma_tiles<(MTMAX < 3 ? MTMAX : 3)>(ah, al, bh, bl, trow);
+                else mfma_tiles<MTMAX>(ah, al, bh, bl, trow);
+#else
+                if ((float)bh[0] == 12345.f) tile[c] = (float)bl[0];
+#endif
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the weight tile is written
         __builtin_amdgcn_wave_barrier();
+#ifndef MATTEN_ABLATE_NO_VALU
         for (int so = 0; so < CH; ++so) {
             const int s = s0 + so;
             if (s >= maxdeg) break;
@@ -453,10 +475,15 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                 G::apply(mask, x, y, w, acc);
             }
         }
+#endif
         ld.publish(buf ^ 1);
         __syncthreads();  // the next stage is published; every wave is done with this chunk's rows
     }
+#ifdef MATTEN_ABLATE_NO_STORE
+    if (valid && acc[0] == 12345.678f) {
+#else
     if (valid) {
+#endif
         const float nn = a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node];
         const float norm = a_scale_inv / sqrtf(nn);
         float* orow = a.agg + (int64_t)node * a.d_mid;
