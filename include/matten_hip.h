@@ -176,6 +176,8 @@ int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const flo
  * (nn/conv.py:59-61,77-79,84-86 called :109,112,123), and e3nn o3.Linear when species == NULL
  * (nn/nodewise.py:111-117, model_factory/tfn_scalar_tensor.py:49-51,68).
  *   out[n, o_off + w*d + k] = (add ? add[..] : 0) + sum_{u<mul_in} Wp[species(n), w_off + u*mo + w] * x[n, x_off + u*d + k]
+ *   x rows are d_in floats apart, out rows d_out, add rows add_ld (>= d_out; a column slice of a wider matrix is fine:
+ *   the conv layer evaluates lin1 and the self-connection as one call and hands the second half on as the addend)
  *   for every segment, w < mo, k < d.  fp32 MFMA over tiles of 16 rows x 16 output channels.
  *   segs[n_segs, 8] int32 {x_off, d, mul_in, w_off, mo, o_off, 0, 0}: one per (input irrep block ->
  *       output irrep block) path; outputs no segment covers are NOT written (the caller zero-fills
@@ -188,7 +190,7 @@ int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const flo
  * ------------------------------------------------------------------------------------------ */
 int matten_species_linear(const float* x, int64_t d_in, const int32_t* order, const int32_t* seg, int64_t n_species,
                           const float* wp, int64_t w_stride, const int32_t* segs, int64_t n_segs, int64_t d_out,
-                          const float* add, int64_t n_rows, float* out, matten_stream_t stream);
+                          const float* add, int64_t add_ld, int64_t n_rows, float* out, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * e3nn Gate (nn/utils.py:134-140,158-159 <- nn/conv.py:209) fused with e3nn BatchNorm in eval

@@ -283,7 +283,7 @@ template <bool W_LDS>
 __global__ __launch_bounds__(SL_WAVES * 64, SL_MIN_BLOCKS) void species_linear_kernel(
     const float* __restrict__ x, int d_in, const int32_t* __restrict__ order, const int32_t* __restrict__ seg,
     int n_species, const float* __restrict__ wp, int w_stride, const LinSeg* __restrict__ segs, int n_segs,
-    int segs_per_block, int d_out, const float* __restrict__ add, int n_rows, float* __restrict__ out) {
+    int segs_per_block, int d_out, const float* __restrict__ add, int add_ld, int n_rows, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ws_lds = lds + SL_WAVES * SL_ROWS * XS_RS;  // [w_stride] packed table of this block's species
     // ---- block -> (species, 64 rows) ----
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(SL_WAVES * 64, SL_MIN_BLOCKS) void species_linear_k
     const int row = row_in ? lo + c : lo;
     const int node = order ? order[row] : row;
     float* orow = out + (int64_t)node * d_out;
-    const int64_t x_bytes = (int64_t)n_rows * d_in * 4, a_bytes = (int64_t)n_rows * d_out * 4;
+    const int64_t x_bytes = (int64_t)n_rows * d_in * 4, a_bytes = ((int64_t)(n_rows - 1) * add_ld + d_out) * 4;
     const int st_first = add ? -1 : 0;
 
     // Rows of a tile ascend in memory; a descriptor addresses 4 GB from its base.  Tiles whose rows are further
@@ -345,10 +345,10 @@ __global__ __launch_bounds__(SL_WAVES * 64, SL_MIN_BLOCKS) void species_linear_k
         if (nmin == 0x7fffffff) break;
         nmin = __builtin_amdgcn_readfirstlane(nmin);
         const int64_t rel = (int64_t)node - nmin;
-        const bool row_ok = pending && rel >= 0 && rel * max(d_in, d_out) * 4 < SRD_SPAN;
+        const bool row_ok = pending && rel >= 0 && rel * max(d_in, max(d_out, add_ld)) * 4 < SRD_SPAN;
         Stream sm;
         {
-            const int64_t xb = (int64_t)nmin * d_in * 4, ab = (int64_t)nmin * d_out * 4;
+            const int64_t xb = (int64_t)nmin * d_in * 4, ab = (int64_t)nmin * add_ld * 4;
             const uint64_t xp = (uint64_t)(reinterpret_cast<const char*>(x) + xb);
             const uint64_t ap = (uint64_t)(reinterpret_cast<const char*>(add ? add : x) + (add ? ab : 0));
             const int64_t xl = x_bytes - xb, al = add ? a_bytes - ab : 0;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(SL_WAVES * 64, SL_MIN_BLOCKS) void species_linear_k
             sm.a_rsrc = sl_i32x4{(int)(uint32_t)ap, (int)((uint32_t)(ap >> 32) & 0xffffu),
                                  (int)(uint32_t)(al > 0xffffffffll ? 0xffffffffll : al), (int)SRD_WORD3};
             sm.x_voff = row_ok ? (int)(rel * d_in * 4) : 0;
-            sm.a_voff = row_ok ? (int)(rel * d_out * 4) : 0;
+            sm.a_voff = row_ok ? (int)(rel * add_ld * 4) : 0;
         }
 
         sl_f32x4 acc[NACC];
@@ -401,14 +401,16 @@ __global__ __launch_bounds__(SL_WAVES * 64, SL_MIN_BLOCKS) void species_linear_k
 
 extern "C" int matten_species_linear(const float* x, int64_t d_in, const int32_t* order, const int32_t* seg,
                                      int64_t n_species, const float* wp, int64_t w_stride, const int32_t* segs,
-                                     int64_t n_segs, int64_t d_out, const float* add, int64_t n_rows, float* out,
-                                     matten_stream_t stream_) {
+                                     int64_t n_segs, int64_t d_out, const float* add, int64_t add_ld, int64_t n_rows,
+                                     float* out, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows < 0 || d_in <= 0 || d_out <= 0 || n_species <= 0 || w_stride < 0 || n_segs < 0 ||
         n_rows >= ((int64_t)1 << 31))
         return MATTEN_EINVAL;
     if (n_rows == 0 || n_segs == 0) return MATTEN_OK;
     if (!x || !wp || !out || !segs) return MATTEN_EINVAL;
+    if (add && add_ld < d_out) return MATTEN_EINVAL;
+    if (!add) add_ld = d_out;
     if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
     if (!order && n_species != 1) return MATTEN_EINVAL;
     const size_t lds_tiles = sizeof(float) * SL_WAVES * SL_ROWS * XS_RS;
@@ -429,11 +431,11 @@ extern "C" int matten_species_linear(const float* x, int64_t d_in, const int32_t
     if (w_lds)
         species_linear_kernel<true><<<grid, SL_WAVES * 64, lds, stream>>>(
             x, (int)d_in, order, seg, (int)n_species, wp, (int)w_stride, (const LinSeg*)segs, (int)n_segs,
-            segs_per_block, (int)d_out, add, (int)n_rows, out);
+            segs_per_block, (int)d_out, add, (int)add_ld, (int)n_rows, out);
     else
         species_linear_kernel<false><<<grid, SL_WAVES * 64, lds, stream>>>(
             x, (int)d_in, order, seg, (int)n_species, wp, (int)w_stride, (const LinSeg*)segs, (int)n_segs,
-            segs_per_block, (int)d_out, add, (int)n_rows, out);
+            segs_per_block, (int)d_out, add, (int)add_ld, (int)n_rows, out);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

@@ -10,8 +10,13 @@ from typing import Dict
 
 import torch
 
+import numpy as np
+
+from .. import autograd as _ag
+from .. import ops
 from ..data.irreps import DataKey, ModuleIrreps
 from ..o3 import Irreps
+from ._tables import DerivedWeight, DeviceTables
 from .utils import ActivationLayer, NormalizationLayer, SpeciesLinear, UVUTensorProduct
 
 
@@ -46,12 +51,42 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         self.lin2 = SpeciesLinear(self.tp.irreps_out, n_species, conv_layer_irreps)
         self.sc = SpeciesLinear(feats_in, n_species, conv_layer_irreps)
         self.irreps_out[DataKey.NODE_FEATURES] = conv_layer_irreps
+        self._lin1_sc = None  # built at first inference forward
+        self._lin1_sc_packed = DerivedWeight(self._pack_lin1_sc)
+
+    def _pack_lin1_sc(self, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+        return torch.cat([self.lin1._pack(w1), self.sc._pack(w2)], dim=1).contiguous()
+
+    def _fused_lin1_sc_tables(self):
+        """lin1 and the self-connection read the same rows with the same species order: in inference they run as ONE
+        matten_species_linear launch writing [x1 | self_connection] side by side (segment tables concatenated, the
+        self-connection's weight and output offsets shifted).  The parameters stay two reference-layout tensors."""
+        if self._lin1_sc is None:
+            p1, p2 = self.lin1.plan, self.sc.plan
+            if len(p1.passes) != 1 or len(p2.passes) != 1 or not (p1.fully_covered and p2.fully_covered):
+                self._lin1_sc = False
+            else:
+                seg2 = p2.passes[0].copy()
+                seg2[:, 3] += p1.w_stride
+                seg2[:, 5] += p1.d_out
+                segs = np.concatenate([p1.passes[0], seg2])
+                segs = segs[np.argsort(segs[:, 0], kind="stable")]  # blocks reading the same input columns adjacent
+                self._lin1_sc = DeviceTables(meta=segs)
+        return self._lin1_sc
 
     def forward(self, data: DataKey.Type) -> DataKey.Type:
         x = data[DataKey.NODE_FEATURES]
         species = data[DataKey.AMD_SPECIES]
-        self_connection = self.sc(x, species)
-        x1 = self.lin1(x, species)
+        fused = None if _ag.needs_grad(x, self.lin1.weight, self.sc.weight) else self._fused_lin1_sc_tables()
+        if fused:
+            wp = self._lin1_sc_packed.get(self.lin1.weight, self.sc.weight)
+            d1, d2 = self.lin1.plan.d_out, self.sc.plan.d_out
+            both = ops.species_linear(x, species, wp, self.lin1.plan.w_stride + self.sc.plan.w_stride,
+                                      [fused.get("meta", x.device)], d1 + d2)
+            x1, self_connection = both[:, :d1], both[:, d1:]
+        else:
+            self_connection = self.sc(x, species)
+            x1 = self.lin1(x, species)
         agg = self.tp(x1, data, self.avg_num_neighbors)
         data[DataKey.NODE_FEATURES] = self.lin2(agg, species, add=self_connection)
         return data

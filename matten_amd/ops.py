@@ -71,6 +71,15 @@ def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _need_rows(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    """like _need, but a column slice of a wider row-major matrix (unit column stride) is passed through as is: the
+    kernels that take it address rows by the tensor's own row stride"""
+    if isinstance(t, torch.Tensor) and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.is_cuda \
+            and t.dtype == dtype:
+        return t
+    return _need(t, dtype, name)
+
+
 def csr_build(edge_index: torch.Tensor, n_nodes: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> (perm[E] i32, rowptr[N+1] i32, src_sorted[E] i32, err_flag[1] i32)"""
     lib = _lib.load()
@@ -262,13 +271,13 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
 
     if lib.matten_tp_tile_nodes() != TP_TILE_NODES:
         raise _lib.MattenHipError("plan.TP_TILE_NODES does not match the library's node tile")
-    x = _need(x, torch.float32, "node_features")
+    x = _need_rows(x, torch.float32, "node_features")  # a column slice is fine: d_in below is the row stride
     h2p = _need(h2p, torch.float16, "h2s")
     if h2p.dim() != 3 or h2p.shape[1:] != (2, 32):
         raise ValueError(f"h2s must be [E,2,32] fp16 (ops.split_hidden / ops.radial_hidden), got {tuple(h2p.shape)}")
     w2p = _need(w2p, torch.float32, "w2p")
     sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
-    N, d_in = x.shape
+    N, d_in = x.shape[0], x.stride(0)
     if num_neigh is not None:
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
     if unit_map.numel() != units_per_tile:
@@ -295,7 +304,7 @@ def species_linear(x, species_order, wp, w_stride: int, item_tables, d_out: int,
     n_species = wp.shape[0] if wp.dim() == 2 else 1
     cur_add = add
     if cur_add is not None:
-        cur_add = _need(cur_add, torch.float32, "add")
+        cur_add = _need_rows(cur_add, torch.float32, "add")
     if fully_covered:
         out = torch.empty(n_rows, d_out, dtype=torch.float32, device=x.device)
     else:  # irreps without an input path stay zero (e3nn output_mask semantics)
@@ -303,8 +312,8 @@ def species_linear(x, species_order, wp, w_stride: int, item_tables, d_out: int,
     for items in item_tables:
         _lib.check(
             lib.matten_species_linear(_ptr(x), d_in, _ptr(order), _ptr(seg), n_species, _ptr(wp), w_stride,
-                                      _ptr(items), items.shape[0], d_out, _ptr(cur_add), n_rows, _ptr(out),
-                                      _stream()),
+                                      _ptr(items), items.shape[0], d_out, _ptr(cur_add),
+                                      cur_add.stride(0) if cur_add is not None else d_out, n_rows, _ptr(out), _stream()),
             "matten_species_linear",
         )
         cur_add = out
