@@ -292,6 +292,7 @@ __device__ __forceinline__ void mfma_tiles(const f16x8* __restrict__ ah, const f
 // loader role of a thread: (edge row of the chunk, 16-byte piece of the row) per MFMA tile; fixed for the whole walk
 struct StageLoader {
     const char* base;
+    const char* safe;
     int64_t row_bytes;
     float* st_w;
     int beg_ld[STAGE_TMAX], deg_ld[STAGE_TMAX], so_ld[STAGE_TMAX];
@@ -307,6 +308,7 @@ struct StageLoader {
         base = piece < 8 ? reinterpret_cast<const char*>(a.h2s) + piece * 16
                          : reinterpret_cast<const char*>(a.sh) + (piece - 8) * 16;
         row_bytes = piece < 8 ? (int64_t)(2 * HID * sizeof(_Float16)) : (int64_t)a.sh_stride * 4;
+        safe = reinterpret_cast<const char*>(a.w2p);
         st_w = stage + (threadIdx.x >> 4) * STAGE_ROW + piece * 4;
 #pragma unroll
         for (int t = 0; t < STAGE_TMAX; ++t) {
@@ -318,16 +320,17 @@ struct StageLoader {
             pf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    // fetch the pieces of the chunk starting at slot s0 (past the end of a segment: its last edge again, never consumed)
+    // fetch the pieces of the chunk starting at slot s0 (past the end of a segment: its last edge again, never consumed).
+    // The loads are unconditional (rows of an empty segment read the weight table instead): with a branch around a
+    // load the compiler cannot count the loads in flight and falls back to s_waitcnt vmcnt(0) at the next gather.
     __device__ __forceinline__ void issue(int s0) {
-#pragma unroll
-        for (int t = 0; t < STAGE_TMAX; ++t)
-#ifdef MATTEN_ABLATE_NO_H2LOAD
-            if (false)
-#else
-            if (t < T && deg_ld[t] > 0)
+#ifndef MATTEN_ABLATE_NO_H2LOAD
+        pf[0] = *reinterpret_cast<const f32x4*>(
+            deg_ld[0] > 0 ? base + (int64_t)(beg_ld[0] + min(s0 + so_ld[0], deg_ld[0] - 1)) * row_bytes : safe);
+        if (T > 1)  // uniform over the workgroup
+            pf[1] = *reinterpret_cast<const f32x4*>(
+                deg_ld[1] > 0 ? base + (int64_t)(beg_ld[1] + min(s0 + so_ld[1], deg_ld[1] - 1)) * row_bytes : safe);
 #endif
-                pf[t] = *reinterpret_cast<const f32x4*>(base + (int64_t)(beg_ld[t] + min(s0 + so_ld[t], deg_ld[t] - 1)) * row_bytes);
     }
     __device__ __forceinline__ void publish(int buf) {
 #pragma unroll
@@ -416,15 +419,31 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     ld.init(a, stage, cu_log2, beg, deg_node);
     ld.issue(0);
 
+    // Neighbour gather.  Two-slot chunks (8 nodes per wave: short steps) keep TWO rows in flight, one per slot of the
+    // chunk: a row is refilled right after its contraction with the edge two steps on, so a gather has a whole step,
+    // the stage hand-over and the next MFMA phase to land, and nothing is copied.  Other chunk shapes (long steps) keep
+    // the one-step-ahead pipeline: source index two edges ahead, row one edge ahead.  All loads are unconditional on a
+    // clamped edge index.
     const int e_last = deg > 0 ? beg + deg - 1 : 0;
-    float xn[G::D1];
-    int src_nn;
+    // (compiled in only for the kinds with registers to spare: the second row buffer costs the heavy kinds spills)
+    constexpr bool TWO_DEEP_OK = L1 == 0 || (L1 == 1 && GI == 0);
+    const bool two_deep = TWO_DEEP_OK && CH == 2;
+    float xn[G::D1], xb[G::D1];
+    int src_nn, src_b = 0;
     {
         const int src0 = a.src_sorted[min(beg, e_last)];
-        src_nn = a.src_sorted[min(beg + 1, e_last)];
+        const int src1 = a.src_sorted[min(beg + 1, e_last)];
         const float* xp0 = a.x + (int64_t)src0 * a.d_in + xcol;
 #pragma unroll
         for (int i = 0; i < G::D1; ++i) xn[i] = xp0[i];
+        src_nn = src1;
+        if (two_deep) {
+            const float* xp1 = a.x + (int64_t)src1 * a.d_in + xcol;
+#pragma unroll
+            for (int i = 0; i < G::D1; ++i) xb[i] = xp1[i];
+            src_nn = a.src_sorted[min(beg + 2, e_last)];
+            src_b = a.src_sorted[min(beg + 3, e_last)];
+        }
     }
     ld.publish(0);
     __syncthreads();
@@ -452,27 +471,45 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the weight tile is written
         __builtin_amdgcn_wave_barrier();
 #ifndef MATTEN_ABLATE_NO_VALU
-        for (int so = 0; so < CH; ++so) {
-            const int s = s0 + so;
-            if (s >= maxdeg) break;
-            float x[G::D1];
+        auto contract = [&](int so, const float* __restrict__ x) {
+            const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
+            const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
+            float y[G::NY], w[NC];
 #pragma unroll
-            for (int i = 0; i < G::D1; ++i) x[i] = xn[i];
+            for (int jj = 0; jj < G::NY; ++jj) y[jj] = yp[jj];
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+            G::apply(mask, x, y, w, acc);
+        };
+        if (two_deep) {
+            if (s0 < deg) contract(0, xn);
             {
                 const float* xp = a.x + (int64_t)src_nn * a.d_in + xcol;
 #pragma unroll
                 for (int i = 0; i < G::D1; ++i) xn[i] = xp[i];
-                src_nn = a.src_sorted[min(beg + s + 2, e_last)];
+                src_nn = a.src_sorted[min(beg + s0 + 4, e_last)];
             }
-            if (s < deg) {
-                const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
-                const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
-                float y[G::NY], w[NC];
+            if (s0 + 1 < deg) contract(1, xb);
+            {
+                const float* xp = a.x + (int64_t)src_b * a.d_in + xcol;
 #pragma unroll
-                for (int jj = 0; jj < G::NY; ++jj) y[jj] = yp[jj];
+                for (int i = 0; i < G::D1; ++i) xb[i] = xp[i];
+                src_b = a.src_sorted[min(beg + s0 + 5, e_last)];
+            }
+        } else {
+            for (int so = 0; so < CH; ++so) {
+                const int s = s0 + so;
+                if (s >= maxdeg) break;
+                float x[G::D1];
 #pragma unroll
-                for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
-                G::apply(mask, x, y, w, acc);
+                for (int i = 0; i < G::D1; ++i) x[i] = xn[i];
+                {
+                    const float* xp = a.x + (int64_t)src_nn * a.d_in + xcol;
+#pragma unroll
+                    for (int i = 0; i < G::D1; ++i) xn[i] = xp[i];
+                    src_nn = a.src_sorted[min(beg + s + 2, e_last)];
+                }
+                if (s < deg) contract(so, x);
             }
         }
 #endif

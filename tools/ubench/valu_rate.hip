@@ -1,49 +1,66 @@
-// Issue rate of fp32 VALU on a gfx950 SIMD: cycles per wave64 v_fma_f32 / v_pk_fma_f32 with W waves per SIMD.
-// hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate
+// Issue rate of fp32 VALU on a gfx950 SIMD by encoding, for W waves per SIMD: cycles per wave64 instruction per SIMD.
+//   hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
-typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr int ITERS = 20000;
-template <int PK>
+constexpr int ITERS = 40000;
+// 16 independent accumulators v[0..15]; operands a (v), b (v), s (sgpr)
+#define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+template <int MODE>
 __global__ void k(const float* in, float* out, long long* cyc) {
     float a = in[threadIdx.x & 63], b = in[(threadIdx.x + 1) & 63];
+    float s = in[blockIdx.x & 63];
     float v[16];
     for (int i = 0; i < 16; ++i) v[i] = in[(threadIdx.x + i) & 63];
     long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITERS; ++it) {
-        if (PK) {
-#pragma unroll
-            for (int i = 0; i < 16; i += 2)
-                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(*reinterpret_cast<f2*>(&v[i])) : "v"(f2{a, a}), "v"(f2{b, b}));
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
-        }
+#define FMA3(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(v[i]) : "v"(a), "v"(b));
+#define FMAC(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
+#define FMACL(i) asm volatile("v_fmac_f32 %0, 0x3f9e0419, %1" : "+v"(v[i]) : "v"(a));
+#define FMACS(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "s"(s), "v"(a));
+#define MUL2(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+#define FMA3L(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(v[i]) : "s"(s), "v"(b));
+        if (MODE == 0) { REP16(FMA3) }
+        if (MODE == 1) { REP16(FMAC) }
+        if (MODE == 2) { REP16(FMACL) }
+        if (MODE == 3) { REP16(FMACS) }
+        if (MODE == 4) { REP16(MUL2) }
+        if (MODE == 5) { REP16(FMA3L) }
     }
     long long t1 = __builtin_readcyclecounter();
-    float s = 0; for (int i = 0; i < 16; ++i) s += v[i];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    float r = 0; for (int i = 0; i < 16; ++i) r += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int MODE> void run(const char* name, const float* in, float* out, long long* cyc) {
+    printf("%-34s", name);
+    for (int wps : {1, 2, 3, 4, 6, 8}) {
+        int threads = 256, blocks = 256 * wps;   // wps blocks of 4 waves per CU -> wps waves per SIMD
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            k<MODE><<<blocks, threads>>>(in, out, cyc);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        long long c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+        double instr = (double)ITERS * 16;
+        // per-SIMD cycles per instruction from the wave's own counter: wave time / instr / waves sharing the SIMD
+        // wall clock: all waves of the launch / 1024 SIMDs, at 2.4 GHz nominal; wave: its own cycle counter
+        printf("  W=%d: %.2f ns/SIMD-instr (wave %.2f cyc)", wps, ms * 1e6 / (instr * wps), (double)c / instr);
+    }
+    printf("\n");
 }
 int main() {
     float *in, *out; long long* cyc;
-    hipMalloc(&in, 256); hipMalloc(&out, 4 * 1024 * 1024); hipMalloc(&cyc, 8 * 4096);
-    hipMemset(in, 0, 256);
-    for (int pk = 0; pk < 2; ++pk)
-        for (int wps : {1, 2, 4}) {   // waves per SIMD: one block of 256*wps threads per CU
-            int threads = 256 * wps, blocks = 256;
-            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            for (int rep = 0; rep < 2; ++rep) {
-                hipEventRecord(e0);
-                if (pk) k<1><<<blocks, threads>>>(in, out, cyc); else k<0><<<blocks, threads>>>(in, out, cyc);
-                hipEventRecord(e1); hipEventSynchronize(e1);
-            }
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-            double instr = (double)ITERS * (pk ? 8 : 16);
-            printf("%s waves/SIMD %d: %.3f ms, counter ticks per instr per wave %.2f, ns per instr per SIMD %.3f, lane-FMA/s chip %.1f T\n",
-                   pk ? "v_pk_fma_f32" : "v_fma_f32   ", wps, ms, c / instr, ms * 1e6 / (instr * wps),
-                   instr * wps * 1024 * 64 * (pk ? 2 : 1) / (ms * 1e-3) / 1e12);
-        }
+    (void)hipMalloc(&in, 256); (void)hipMalloc(&out, 4 * 256 * 8 * 256); (void)hipMalloc(&cyc, 8 * 4096);
+    (void)hipMemset(in, 0, 256);
+    printf("wall-clock ns per wave64 instruction per SIMD (1 / issue rate), and the cycles one wave sees per instruction, vs waves per SIMD\n");
+    run<0>("v_fma_f32 v,v,v (VOP3, 8 B)", in, out, cyc);
+    run<1>("v_fmac_f32 v,v (VOP2, 4 B)", in, out, cyc);
+    run<2>("v_fmac_f32 literal,v (8 B)", in, out, cyc);
+    run<3>("v_fmac_f32 s,v (VOP2, 4 B)", in, out, cyc);
+    run<4>("v_mul_f32 v,v (VOP2, 4 B)", in, out, cyc);
+    run<5>("v_fma_f32 s,v,v (VOP3, 8 B)", in, out, cyc);
     return 0;
 }
