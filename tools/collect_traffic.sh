@@ -25,12 +25,16 @@ out = {}
 for k, d in res.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2 (guide, section HBM)
-        out[k] = {"fetch_kb_raw_max": d["FETCH_SIZE"]["max_kb"], "write_kb_max": d["WRITE_SIZE"]["max_kb"],
-                  "hbm_bytes_max_launch": 2 * 1024 * d["FETCH_SIZE"]["max_kb"] + 1024 * d["WRITE_SIZE"]["max_kb"],
-                  "fetch_kb_raw_mean": d["FETCH_SIZE"]["mean_kb"], "write_kb_mean": d["WRITE_SIZE"]["mean_kb"],
+        out[k] = {"fetch_kb_raw": d["FETCH_SIZE"]["max_kb"], "write_kb": d["WRITE_SIZE"]["max_kb"],
+                  "hbm_bytes_per_launch": 2 * 1024 * d["FETCH_SIZE"]["max_kb"] + 1024 * d["WRITE_SIZE"]["max_kb"],
                   "hbm_bytes_mean_launch": 2 * 1024 * d["FETCH_SIZE"]["mean_kb"] + 1024 * d["WRITE_SIZE"]["mean_kb"],
                   "launches": d["FETCH_SIZE"]["launches"]}
-json.dump(out, open(f"{R}/gpurun_out/traffic_{TAG}.json", "w"), indent=1)
+doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_traffic.sh via "
+                 "tools/round_profile.sh), bench.py --steps 2; gfx950 correction: FETCH_SIZE x2 (MI355X_MICROARCH.md "
+                 "section HBM); KB -> bytes x1024; 'per_launch' = largest launch (last conv layer), 'mean_launch' = "
+                 "average over all launches of the kernel in a forward",
+       "tag": TAG, "kernels": out}
+json.dump(doc, open(f"{R}/gpurun_out/traffic_{TAG}.json", "w"), indent=1)
 for k, v in out.items():
     if any(s in k for s in ("tp_", "radial", "species_linear")):
         print(k, v)
