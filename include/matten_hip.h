@@ -159,6 +159,11 @@ int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t 
  *   unit_map[units_per_tile]: wave index inside a node tile -> entry << 8 | node group (of 64 >> cu_log2 nodes); any
  *                   bijection is valid, the host orders it node group first (plan.fused_unit_map) so the waves of a
  *                   workgroup read the same hidden-feature / harmonics rows
+ *   a_split / a_scale_inv (both or neither; NULL: the kernel splits w2p itself, ~400 instructions per wave):
+ *                   w2p as ready-made MFMA A fragments.  Entry e owns tiles [a_tile, a_tile + n_mt) (group_entries
+ *                   words 6, 7); tile t, lane (g = lane >> 4, c = lane & 15) holds 16 fp16: hi[kk], lo[kk], kk < 8, of
+ *                   s_e * w2p[16 (kk >> 2) + 4 g + (kk & 3)][w_base + 16 (t - a_tile) + c] with s_e the power of two
+ *                   that puts the entry's largest magnitude in [2^13, 2^14); a_scale_inv[e] = 1 / s_e
  *   lds_floats_per_wave: max over entries of 16*T*(16*ceil(mul*NC/16)+36), T = max(1, nodes_per_wave/16)
  *                   (sh_sorted rows must be 32 floats apart: sh_stride == 32)
  * ------------------------------------------------------------------------------------------ */
@@ -169,7 +174,8 @@ int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const flo
                     const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
                     int64_t n_nodes, const int32_t* group_entries, const int32_t* unit_map, int64_t n_entries,
                     int64_t units_per_tile, int64_t lds_floats_per_wave, int64_t d_mid, float avg_num_neighbors,
-                    const float* num_neigh, float* agg /*[N,d_mid]*/, matten_stream_t stream);
+                    const float* num_neigh, const uint16_t* a_split, const float* a_scale_inv,
+                    float* agg /*[N,d_mid]*/, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * FullyConnectedTensorProduct(x, one_hot(species)) == species-indexed per-irrep linear

@@ -67,7 +67,8 @@ struct GroupEntry {  // 32 x int32, built by matten_amd/plan.py (same record as 
     int cu_log2;     // lanes per node = 1 << cu_log2 >= mul
     unsigned mask;   // bit c set <=> coupling c of the group exists in this layer
     int w_base;      // first weight column of this entry ([u][c] order)
-    int pad[2];
+    int a_tile;      // first 16-column tile of this entry in the pre-split A operand (Args::a_split)
+    int n_mt;        // its tile count, ceil(mul * couplings / 16)
     int reserved[MAXC];
     int out_off[MAXC];
 };
@@ -77,6 +78,8 @@ struct Args {
     const float* x;
     const _Float16* h2s;  // [E, 2, 32] split hidden features (see header)
     const float* w2p;   // [32, w_pad] last MLP layer, pre-scaled, fused column order
+    const _Float16* a_split;   // optional: the same weights as ready-made MFMA A fragments (see matten_hip.h), or NULL
+    const float* a_scale_inv;  // [n_entries] with a_split: 1 / the power-of-two scale of the entry's fragments
     const float* sh;
     const int* rowptr;
     const int* src_sorted;
@@ -357,8 +360,8 @@ __device__ __forceinline__ void run_loader_only(const Args& a, int cu_log2, floa
 
 template <int L1, int GI>
 __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry& ge, float* __restrict__ tile,
-                                                 float* __restrict__ stage, int node, int lane, bool valid, int beg,
-                                                 int deg_node, int maxdeg) {
+                                                 float* __restrict__ stage, int entry, int node, int lane, bool valid,
+                                                 int beg, int deg_node, int maxdeg) {
     const int deg = valid ? deg_node : 0;
     using G = matten::Group<L1, GI>;
     constexpr int NC = G::NC;
@@ -385,6 +388,18 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const int stride = MT * 16 + 4;              // floats per edge row of the wave's weight tile
     f16x8 ah[MTMAX], al[MTMAX];
     float a_scale_inv;
+    if (a.a_split) {
+        // ready-made fragments from the host (two 16-byte loads per tile instead of 8 scattered loads and ~110
+        // conversion instructions per tile and wave: a quarter of a light wave's vector instructions)
+        const f16x8* ap = reinterpret_cast<const f16x8*>(a.a_split) + ((int64_t)ge.a_tile * 64 + lane) * 2;
+#pragma unroll
+        for (int mt = 0; mt < MTMAX; ++mt) {
+            const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            ah[mt] = mt < MT ? ap[mt * 128] : z;
+            al[mt] = mt < MT ? ap[mt * 128 + 1] : z;
+        }
+        a_scale_inv = a.a_scale_inv[entry];
+    } else
     {
         float av[MTMAX][8];
         float amax = 0.0f;
@@ -538,13 +553,21 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 }
 
 #define MATTEN_GROUP_CASE_SHARED(L1, GI) \
-    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI>(a, ge, tile, stage, node, lane, valid, beg, deg, maxdeg); break;
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg); break;
 
 #define MATTEN_GROUP_CASE(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, node, lane, valid, beg, deg, maxdeg); break;
 
 #ifndef TPF_MIN_BLOCKS
 #define TPF_MIN_BLOCKS 3
+#endif
+// experiment switches (tools/fused_kind_ablate.sh): compile the kernel for a subset of the group kinds only
+#if defined(TPF_ONLY_LIGHT)
+#define TPF_FOR_EACH_GROUP(X) X(0, 0) X(1, 0) X(1, 1)
+#elif defined(TPF_ONLY_HEAVY)
+#define TPF_FOR_EACH_GROUP(X) X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(4, 0) X(4, 1)
+#else
+#define TPF_FOR_EACH_GROUP(X) MATTEN_FOR_EACH_GROUP(X)
 #endif
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused_kernel(Args a, const GroupEntry* __restrict__ entries,
                                                                         const int* __restrict__ umap,
@@ -591,13 +614,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
             return;
         }
         switch (ge.kind) {
-            MATTEN_FOR_EACH_GROUP(MATTEN_GROUP_CASE_SHARED)
+            TPF_FOR_EACH_GROUP(MATTEN_GROUP_CASE_SHARED)
             default: break;
         }
         return;
     }
     switch (ge.kind) {
-        MATTEN_FOR_EACH_GROUP(MATTEN_GROUP_CASE)
+        TPF_FOR_EACH_GROUP(MATTEN_GROUP_CASE)
         default: break;
     }
 }
@@ -709,7 +732,8 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
                                const int32_t* src_sorted, int64_t n_nodes, const int32_t* group_entries,
                                const int32_t* unit_map, int64_t n_entries, int64_t units_per_tile,
                                int64_t lds_floats_per_wave, int64_t d_mid, float avg_num_neighbors,
-                               const float* num_neigh, float* agg, matten_stream_t stream_) {
+                               const float* num_neigh, const uint16_t* a_split, const float* a_scale_inv, float* agg,
+                               matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_nodes < 0 || d_in <= 0 || w_pad <= 0 || sh_stride < 32 || (sh_stride & 3) || n_entries <= 0 ||
         units_per_tile <= 0 || d_mid <= 0 || lds_floats_per_wave <= 0 || (lds_floats_per_wave & 3))
@@ -720,7 +744,8 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
     const size_t lds = sizeof(float) * ((size_t)lds_floats_per_wave * WAVES_PER_BLOCK + STAGE_TOTAL_FLOATS);
     if (lds > 64 * 1024) return MATTEN_EINVAL;
-    Args a{x, (const _Float16*)h2s, w2p, sh_sorted, rowptr, src_sorted, num_neigh, agg, (int)d_in, (int)w_pad, (int)sh_stride,
+    if ((a_split == nullptr) != (a_scale_inv == nullptr)) return MATTEN_EINVAL;
+    Args a{x, (const _Float16*)h2s, w2p, (const _Float16*)a_split, a_scale_inv, sh_sorted, rowptr, src_sorted, num_neigh, agg, (int)d_in, (int)w_pad, (int)sh_stride,
            (int)d_mid, (int)n_nodes, (int)lds_floats_per_wave, avg_num_neighbors};
     const int n_tiles = (int)matten_cdiv(n_nodes, TILE_NODES);
     const int blocks_per_tile = (int)matten_cdiv(units_per_tile, WAVES_PER_BLOCK);

@@ -185,6 +185,12 @@ class UVUTensorProduct(torch.nn.Module):
             bw_col_meta=self.plan.bw_col_meta, bw_nnz_ijk=self.plan.bw_nnz_ijk, bw_nnz_c=self.plan.bw_nnz_c,
         )
 
+        self._a_split = DerivedWeight(self._split_last_layer)
+
+    def _split_last_layer(self, w2p: Tensor):
+        """the last radial layer as the fp16 hi/lo MFMA fragments of matten_tp_fused (rebuilt when the weights change)"""
+        return ops.split_a_tiles(w2p, self.plan.group_entries)
+
     @property
     def irreps_out(self) -> Irreps:
         return self.irreps_mid.simplify()
@@ -209,6 +215,7 @@ class UVUTensorProduct(torch.nn.Module):
                 node_feats, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
                 self._tables.get("gentries", dev), self._tables.get("gumap", dev), len(self.plan.fused_unit_map),
                 self.plan.fused_lds_floats_per_wave, self.plan.d_mid, avg, num_neigh,
+                a_split=self._a_split.get(w2p),
             )
         w_edge = self.weight_nn(data[DataKey.AMD_GEOM], int(nb), r0, r1)
         if self.impl == "blocks":

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -264,8 +266,37 @@ def radial_hidden(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, 
     return h2p
 
 
+def split_a_tiles(w2p: torch.Tensor, group_entries) -> Tuple[torch.Tensor, torch.Tensor]:
+    """w2p [32, w_pad] -> (a_split [n_tiles, 64, 16] fp16, a_scale_inv [n_entries] fp32): the last radial layer as the
+    MFMA A fragments matten_tp_fused consumes (layout: include/matten_hip.h), per entry scaled by the power of two
+    that puts its largest magnitude in [2^13, 2^14) and split v = hi + 2^-11 lo like ops.split_hidden.  Runs on the
+    device without a host sync; cached by the caller until the weights change."""
+    dev = w2p.device
+    g = torch.arange(4, device=dev)[:, None]
+    kk = torch.arange(8, device=dev)[None, :]
+    k_idx = 16 * (kk >> 2) + 4 * g + (kk & 3)                       # [4 (g), 8 (kk)]
+    tiny = 2.0 ** -14
+    tiles, inv = [], []
+    for row in np.asarray(group_entries).reshape(-1, 32):
+        w_base, n_mt = int(row[5]), int(row[7])
+        A = w2p[k_idx][:, :, w_base:w_base + 16 * n_mt]              # [g, kk, mt*16 + c]
+        A = A.reshape(4, 8, n_mt, 16).permute(2, 0, 3, 1)            # [mt, g, c, kk]
+        amax = A.abs().max()
+        e = torch.where(amax > 0, (torch.frexp(amax)[1] - 1).clamp(-100, 100), torch.full_like(amax, 13, dtype=torch.int32))
+        scale = torch.ldexp(torch.ones_like(amax), 13 - e)
+        inv.append(torch.ldexp(torch.ones_like(amax), e - 13))
+        v = A * scale
+        hi = torch.where(v.abs() < tiny, torch.zeros_like(v), v.half().float())
+        lo = (v - hi) * 2048.0
+        lo = torch.where(lo.abs() < tiny, torch.zeros_like(lo), lo)
+        tiles.append(torch.cat([hi.half(), lo.half()], dim=-1).reshape(n_mt, 64, 16))
+    return torch.cat(tiles).contiguous(), torch.stack(inv).float().contiguous()
+
+
 def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, units_per_tile: int,
-             lds_floats_per_wave: int, d_mid: int, avg_num_neighbors: float, num_neigh=None) -> torch.Tensor:
+             lds_floats_per_wave: int, d_mid: int, avg_num_neighbors: float, num_neigh=None,
+             a_split=None) -> torch.Tensor:
+    """a_split: optional (fragments, scale_inv) from split_a_tiles(w2p, plan.group_entries)"""
     lib = _lib.load()
     from .plan import TP_TILE_NODES
 
@@ -280,6 +311,10 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
     N, d_in = x.shape[0], x.stride(0)
     if num_neigh is not None:
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
+    if a_split is not None:
+        a_split = (_need(a_split[0], torch.float16, "a_split"), _need(a_split[1], torch.float32, "a_scale_inv"))
+        if a_split[1].numel() != entries.shape[0]:
+            raise ValueError("a_scale_inv needs one value per group entry")
     if unit_map.numel() != units_per_tile:
         raise ValueError(f"unit_map has {unit_map.numel()} units, expected {units_per_tile} (plan.fused_unit_map)")
     agg = torch.empty(N, d_mid, dtype=torch.float32, device=x.device)
@@ -287,7 +322,9 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
         rc = lib.matten_tp_fused(_ptr(x), d_in, _ptr(h2p), _ptr(w2p), w2p.shape[1], _ptr(sh_sorted),
                                  sh_sorted.shape[1], _ptr(rowptr), _ptr(src_sorted), N, _ptr(entries),
                                  _ptr(unit_map), entries.shape[0], units_per_tile, lds_floats_per_wave, d_mid,
-                                 float(avg_num_neighbors or 0.0), _ptr(num_neigh), _ptr(agg), _stream())
+                                 float(avg_num_neighbors or 0.0), _ptr(num_neigh),
+                                 _ptr(a_split[0]) if a_split is not None else None,
+                                 _ptr(a_split[1]) if a_split is not None else None, _ptr(agg), _stream())
     _lib.check(rc, "matten_tp_fused")
     return agg
 

@@ -135,6 +135,7 @@ class UVUPlan:
     group_units_per_tile: int = 0
     fused_cols: np.ndarray = None     # int64 [W_fused]: fused weight column -> reference weight column, -1 = zero
     fused_lds_floats_per_wave: int = 0  # LDS tile of matten_tp_fused
+    fused_a_tiles: int = 0              # 16-column tiles of all entries (pre-split A operand of matten_tp_fused)
     fused_unit_map: np.ndarray = None   # int32 [fused units per tile]: unit -> flags | entry << 8 | node group
     # adjoint tables (matten_tp_backward)
     bw_col_meta: np.ndarray = None    # int32 [W, 4] {x_base, out_base, nnz_begin, nnz_count | y_off << 16}
@@ -231,6 +232,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
             ustart.append(ustart[-1] + waves)
     # ---- block-fused groups: all couplings of one input block and one l2 range (cg_gen.h Group<l1,g>) ----
     gentries, gstart = [], [0]
+    fused_a_tiles = 0
     fused_cols: List[int] = []
     lds_need = 0
     by_block: Dict[int, List[UVUPath]] = {}
@@ -257,7 +259,10 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                 nodes_per_wave = max(1, 64 // (1 << cu_log2))
                 n_tiles16 = max(1, nodes_per_wave // 16)
                 lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(combos)) // 16)) + 32 + 4))
-                row = [l1 * TP_KIND_STRIDE + gi, plist[0].x_off + u0 * d1, mul_c, cu_log2, 0, len(fused_cols), 0, 0] + [0] * 24
+                n_mt = -(-(mul_c * len(combos)) // 16)  # 16-column MFMA tiles of the entry's weight block
+                row = [l1 * TP_KIND_STRIDE + gi, plist[0].x_off + u0 * d1, mul_c, cu_log2, 0, len(fused_cols),
+                       fused_a_tiles, n_mt] + [0] * 24
+                fused_a_tiles += n_mt
                 mask = 0
                 for c, key in enumerate(combos):
                     if key in present:
@@ -299,7 +304,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         group_entries=np.array(gentries, dtype=np.int64).astype(np.int32), group_unit_start=np.array(gstart, dtype=np.int32),
         group_units_per_tile=gstart[-1], fused_cols=np.array(fused_cols, dtype=np.int64),
         fused_lds_floats_per_wave=(lds_need + 3) // 4 * 4,
-        fused_unit_map=fused_unit_map(np.array(gentries, dtype=np.int64)),
+        fused_unit_map=fused_unit_map(np.array(gentries, dtype=np.int64)), fused_a_tiles=fused_a_tiles,
     )
 
 

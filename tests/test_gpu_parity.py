@@ -327,6 +327,11 @@ def test_tp_kernels_agree_and_match_oracle(per_node_norm):
     f = ops.tp_fused(x.to(DEV), h2p, w2f, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV), t.get("gumap", DEV),
                      len(p.fused_unit_map), p.fused_lds_floats_per_wave, p.d_mid, avg, nn_)
     close(f, want_lr, 5e-5, "tp_fused vs oracle")
+    # host-built MFMA fragments of the last layer (production path) == the kernel's own split of w2p, bit for bit
+    f_pre = ops.tp_fused(x.to(DEV), h2p, w2f, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV), t.get("gumap", DEV),
+                         len(p.fused_unit_map), p.fused_lds_floats_per_wave, p.d_mid, avg, nn_,
+                         a_split=ops.split_a_tiles(w2f, p.group_entries))
+    assert torch.equal(f, f_pre)
     close(c, want, 2e-5, "tp_blocks vs oracle")
     close(c, a, 2e-5, "tp_blocks vs tp_paths")
     close(a, want, 2e-5, "tp_paths vs oracle")

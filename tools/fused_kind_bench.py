@@ -27,7 +27,8 @@ def run_fused(entries_np, label):
     ent = torch.from_numpy(np.ascontiguousarray(entries_np)).to(dev)
     ust = torch.from_numpy(mplan.fused_unit_map(entries_np)).to(dev)
     upt = ust.numel()
-    f = lambda: ops.tp_fused(x, h2p, w2p, geo["sh_sorted"], rowptr, src, ent, ust, upt, p.fused_lds_floats_per_wave, p.d_mid, 18.0)
+    asp = ops.split_a_tiles(w2p, entries_np) if os.environ.get('NO_ASPLIT') is None else None
+    f = lambda: ops.tp_fused(x, h2p, w2p, geo["sh_sorted"], rowptr, src, ent, ust, upt, p.fused_lds_floats_per_wave, p.d_mid, 18.0, a_split=asp)
     for _ in range(2): f()
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(5): f()
