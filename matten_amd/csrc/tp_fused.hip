@@ -490,8 +490,18 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
             const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
             float y[G::NY], w[NC];
+            {   // the harmonics of a staged row are 16-byte aligned: whole ds_read_b128 over [Y0, Y0 + NY)
+                constexpr int Q0 = G::Y0 / 4 * 4, NQ = (G::Y0 + G::NY - Q0 + 3) / 4;
+                float yq[4 * NQ];
+                const f32x4* y4 = reinterpret_cast<const f32x4*>(yp - (G::Y0 - Q0));
 #pragma unroll
-            for (int jj = 0; jj < G::NY; ++jj) y[jj] = yp[jj];
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 v = y4[q];
+                    yq[4 * q] = v[0], yq[4 * q + 1] = v[1], yq[4 * q + 2] = v[2], yq[4 * q + 3] = v[3];
+                }
+#pragma unroll
+                for (int jj = 0; jj < G::NY; ++jj) y[jj] = yq[G::Y0 - Q0 + jj];
+            }
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
             G::apply(mask, x, y, w, acc);
