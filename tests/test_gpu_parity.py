@@ -332,6 +332,11 @@ def test_tp_kernels_agree_and_match_oracle(per_node_norm):
                          len(p.fused_unit_map), p.fused_lds_floats_per_wave, p.d_mid, avg, nn_,
                          a_split=ops.split_a_tiles(w2f, p.group_entries))
     assert torch.equal(f, f_pre)
+    # the unshared walk (entry-major unit map: every wave fetches its own rows) is the same arithmetic in the same order
+    umap_plain = torch.from_numpy(mplan.fused_unit_map(p.group_entries, "entry")).to(DEV)
+    f_plain = ops.tp_fused(x.to(DEV), h2p, w2f, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV), umap_plain,
+                           umap_plain.numel(), p.fused_lds_floats_per_wave, p.d_mid, avg, nn_)
+    assert torch.equal(f, f_plain)
     close(c, want, 2e-5, "tp_blocks vs oracle")
     close(c, a, 2e-5, "tp_blocks vs tp_paths")
     close(a, want, 2e-5, "tp_paths vs oracle")
