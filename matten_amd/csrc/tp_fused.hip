@@ -539,7 +539,12 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         }
 #endif
         ld.publish(buf ^ 1);
+#ifdef MATTEN_ABLATE_NO_BARRIER
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();  // timing experiment only: results are wrong
+#else
         __syncthreads();  // the next stage is published; every wave is done with this chunk's rows
+#endif
     }
 #ifdef MATTEN_ABLATE_NO_STORE
     if (valid && acc[0] == 12345.678f) {
