@@ -30,6 +30,8 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK = 157.3e12  # flop/s, dense fp32 MFMA (same guide)
+MFMA_F16_PEAK = 2.5e15    # flop/s, dense fp16/bf16 MFMA
 B_ALG_PER_EDGE_TP = 4816.0  # mean algorithmic bytes per edge-TP, 2-kernel architecture
 
 
@@ -192,6 +194,28 @@ def main():
                 "last_layer_traffic": _pmc_traffic("tp_fused_kernel", "hbm_bytes_per_launch"),
             }
         result["kernel_ms_per_launch"] = per_kernel
+        # ---- matrix-core use of the radial MLP (the only GEMM of the path): hidden layers nb -> 32 -> 32 in
+        # radial_hidden_kernel (fp32 MFMA), last layer 32 -> W inside tp_fused_kernel (three fp16-split products) ----
+        if tp_plans and "radial_hidden" in per_kernel:
+            nb = int(PAPER_HPARAMS.get("num_radial_basis", 8))
+            hid_flops = 2.0 * (nb * 32 + 32 * 32) * n_edges
+            hid_ms = per_kernel["radial_hidden"]
+            last_flops = [2.0 * 32 * p.weight_numel * n_edges for p in tp_plans]
+            result["mfma"] = {
+                "radial_hidden_kernel": {
+                    "flops_per_launch": hid_flops, "avg_launch_ms": hid_ms,
+                    "achieved_TFLOPs": hid_flops / (hid_ms * 1e-3) / 1e12, "peak_TFLOPs": MFMA_F32_PEAK / 1e12,
+                    "frac": hid_flops / (hid_ms * 1e-3) / MFMA_F32_PEAK, "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+                },
+                "last_layer_in_tp_fused": {
+                    "algorithmic_flops_per_launch": sum(last_flops) / len(last_flops),
+                    "issued_f16_flops_per_launch": 3.0 * sum(last_flops) / len(last_flops),
+                    "note": "evaluated as hi.hi + 2^-11 (hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16 inside the kernel the "
+                            "HBM roofline above prices; matrix-pipe busy fraction from PMC in DESIGN.md section 4",
+                    "f16_TFLOPs_over_kernel_time": 3.0 * sum(last_flops) / len(last_flops) / (avg_ms * 1e-3) / 1e12,
+                    "peak_f16_TFLOPs": MFMA_F16_PEAK / 1e12,
+                },
+            }
         result["path_roofline"] = {
             "definition": "edge-TP/s x 4816 B (SURVEY 8d two-kernel algorithmic bytes) / 8.0e12 B/s, per GPU",
             "frac": value / world * B_ALG_PER_EDGE_TP / HBM_PEAK,
