@@ -72,7 +72,13 @@ __device__ __forceinline__ void mfma_16x16x4(sl_f32x4& acc, float a, float b) {
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15" ::: "memory"); }
 
-__device__ __forceinline__ constexpr int steps_per_chunk(int d) { return NB / d > 0 ? NB / d : 1; }
+// steps (16 input channels each) per chunk: max(1, NB / d).  d is 2l+1 <= 9 (the host plan rejects anything else), so
+// the run-time value is a select chain: the integer division cost ~30 instructions and a VALU -> SALU round trip three
+// times per chunk on the wave's serial path.
+__device__ __forceinline__ constexpr int steps_per_chunk(int d) {
+    return d <= 1 ? NB : d <= 3 ? (NB / 3 > 0 ? NB / 3 : 1) : d <= 5 ? (NB / 5 > 0 ? NB / 5 : 1)
+                       : d <= 7 ? (NB / 7 > 0 ? NB / 7 : 1) : (NB / 9 > 0 ? NB / 9 : 1);
+}
 
 struct Cursor {  // position of a chunk in the walk over (irrep block, channel-tile group, step); wave-uniform
     int sg, vt0, st;
