@@ -337,3 +337,35 @@ def test_fused_unit_map_covers_every_entry_and_node_group_once():
                 assert len({int(p.group_entries[v >> 8 & 0xFFFF][3]) for v in blk}) == 1
                 assert int(p.group_entries[blk[0] >> 8 & 0xFFFF][3]) >= 1
                 assert not blk[0] & mp.FUSED_UNIT_LOADER_ONLY
+
+
+def test_split_a_tiles_reconstructs_the_last_radial_layer():
+    """ops.split_a_tiles (pure torch, runs on the CPU too): every fragment element is hi + 2^-11 lo of the scaled weight
+    to 2^-22 relative of the entry's largest magnitude, in the lane layout include/matten_hip.h documents."""
+    import torch
+
+    from matten_amd import ops, plan as mp
+    from matten_amd.o3 import Irreps
+
+    irr = "32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e"
+    p = mp.plan_uvu(irr, Irreps.spherical_harmonics(4), irr)
+    w_pad = (len(p.fused_cols) + 15) // 16 * 16 + 16
+    g = torch.Generator().manual_seed(3)
+    w2p = torch.randn(32, w_pad, generator=g) * torch.logspace(-6, 3, w_pad)[None, :]  # wide dynamic range over columns
+    frag, inv = ops.split_a_tiles(w2p, p.group_entries)
+    assert frag.shape == (p.fused_a_tiles, 64, 16) and frag.dtype == torch.float16 and inv.shape == (len(p.group_entries),)
+    assert torch.isfinite(frag.float()).all()
+    for e, row in enumerate(p.group_entries):
+        w_base, t0, n_mt = int(row[5]), int(row[6]), int(row[7])
+        assert n_mt == -(-(int(row[2]) * bin(int(row[4]) & 0xFFFFFFFF).count("1")) // 16) or n_mt >= 1
+        block = w2p[:, w_base:w_base + 16 * n_mt]
+        scale = 1.0 / inv[e].item()
+        assert 2.0 ** 13 <= block.abs().max().item() * scale < 2.0 ** 14
+        for mt in range(n_mt):
+            for lane in (0, 17, 42, 63):
+                gi, c = lane >> 4, lane & 15
+                for kk in range(8):
+                    k = 16 * (kk >> 2) + 4 * gi + (kk & 3)
+                    want = w2p[k, w_base + 16 * mt + c].item()
+                    got = (frag[t0 + mt, lane, kk].float().item() + frag[t0 + mt, lane, 8 + kk].float().item() / 2048.0) * inv[e].item()
+                    assert abs(got - want) <= 2.0 ** -21 * block.abs().max().item() + 1e-30
