@@ -622,6 +622,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
     int maxdeg = deg;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+#ifdef MATTEN_ABLATE_NO_LOOP
+    maxdeg = 0;  // timing experiment: prologue (segment, gather, fragment and stage set-up) + epilogue only
+#endif
     if (shared_stage) {
         float* stage = lds + WAVES_PER_BLOCK * a.lds_per_wave;
         if ((um >> 25) & 1) {  // loader-only unit: fills the workgroup up to four waves
