@@ -648,6 +648,9 @@ constexpr int NT = 4;
 // silu on the hardware transcendental units: v_exp_f32 (2^x) + v_rcp_f32, ~1 ulp each, against the ~25-instruction
 // expf + IEEE division; the hidden kernel is bound by exactly this arithmetic (64 silu per edge and layer)
 __device__ __forceinline__ float silu(float z) {
+#ifdef RH_ABLATE_NO_SILU
+    return z * 0.5f;
+#endif
     return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
 }
 
@@ -670,10 +673,18 @@ __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __rest
         a1[0][kk] = w1p[k * HID + c];
         a1[1][kk] = w1p[k * HID + 16 + c];
     }
+    // all NT edge lengths of the wave are requested up front: the tiles below are long dependent chains (Bessel ->
+    // MFMA -> silu -> MFMA -> silu -> split -> store) and would otherwise each start with an exposed load
+    float lens[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int64_t e = e0 + nt * 16 + c;
-        const float len = geom[e < E ? e : E - 1].w;
+        lens[nt] = geom[e < E ? e : E - 1].w;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t e = e0 + nt * 16 + c;
+        const float len = lens[nt];
         const float xr = len - r_start;
         const float t01 = xr * inv_c, inv_xr = __builtin_amdgcn_rcpf(xr);
         f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
@@ -695,17 +706,25 @@ __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __rest
         }
         f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
+#ifdef RH_ABLATE_NO_L1
+        o0 = h0, o1 = h1;
+#else
         for (int kk = 0; kk < 8; ++kk) {
             float b = kk < 4 ? h0[kk & 3] : h1[kk & 3];
             o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0][kk], b, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1][kk], b, o1, 0, 0, 0);
         }
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             o0[r] = silu(o0[r]);
             o1[r] = silu(o1[r]);
         }
+#ifdef RH_ABLATE_NO_STORE
+        if (e < E && o0[0] == 12345.678f) {
+#else
         if (e < E) {
+#endif
             f16x8 hi, lo;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
