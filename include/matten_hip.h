@@ -198,6 +198,14 @@ int matten_species_linear(const float* x, int64_t d_in, const int32_t* order, co
                           const float* wp, int64_t w_stride, const int32_t* segs, int64_t n_segs, int64_t d_out,
                           const float* add, int64_t add_ld, int64_t n_rows, float* out, matten_stream_t stream);
 
+/* Same operator, same arguments, for SHORT rows (16 * (d_in | 1) + w_stride floats <= 64 KB of LDS, one segment table):
+ * a workgroup keeps its 16 rows and the species' weights in LDS and walks the irrep blocks without the streaming
+ * kernel's chunk pipeline (reference call sites nn/conv.py:109,112 lin1 / self-connection, nn/nodewise.py:116).
+ * Returns MATTEN_EINVAL when the rows do not fit: call matten_species_linear then. */
+int matten_species_linear_rows(const float* x, int64_t d_in, const int32_t* order, const int32_t* seg, int64_t n_species,
+                               const float* wp, int64_t w_stride, const int32_t* segs, int64_t n_segs, int64_t d_out,
+                               const float* add, int64_t add_ld, int64_t n_rows, float* out, matten_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * e3nn Gate (nn/utils.py:134-140,158-159 <- nn/conv.py:209) fused with e3nn BatchNorm in eval
  * mode (nn/utils.py:418,432-433 <- nn/conv.py:211).

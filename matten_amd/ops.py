@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
+
 import numpy as np
 
 import torch
@@ -329,6 +331,9 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
     return agg
 
 
+_SL_ROWS_LDS_BYTES = 52 * 1024  # three workgroups of matten_species_linear_rows per CU
+
+
 def species_linear(x, species_order, wp, w_stride: int, item_tables, d_out: int, add=None,
                    fully_covered: bool = True) -> torch.Tensor:
     """species_order: None (plain linear) or (order[N] i32, seg[S+1] i32) = nodes sorted by species.
@@ -346,9 +351,13 @@ def species_linear(x, species_order, wp, w_stride: int, item_tables, d_out: int,
         out = torch.empty(n_rows, d_out, dtype=torch.float32, device=x.device)
     else:  # irreps without an input path stay zero (e3nn output_mask semantics)
         out = cur_add.clone() if cur_add is not None else torch.zeros(n_rows, d_out, dtype=torch.float32, device=x.device)
+    # short rows (node features: lin1 / self-connection, first-layer lin2, read-out): rows and weights resident in LDS
+    rows_variant = (len(item_tables) == 1 and 4 * (16 * (d_in | 1) + w_stride + 8 * item_tables[0].shape[0] + 4) <= _SL_ROWS_LDS_BYTES
+                    and os.environ.get("MATTEN_SL_ROWS", "1") != "0")
     for items in item_tables:
+        fn = lib.matten_species_linear_rows if rows_variant else lib.matten_species_linear
         _lib.check(
-            lib.matten_species_linear(_ptr(x), d_in, _ptr(order), _ptr(seg), n_species, _ptr(wp), w_stride,
+            fn(_ptr(x), d_in, _ptr(order), _ptr(seg), n_species, _ptr(wp), w_stride,
                                       _ptr(items), items.shape[0], d_out, _ptr(cur_add),
                                       cur_add.stride(0) if cur_add is not None else d_out, n_rows, _ptr(out), _stream()),
             "matten_species_linear",
