@@ -27,17 +27,24 @@ constexpr int TPB = 2;  // 16-row tiles per workgroup: the weight fill and the s
 
 // accumulate-in-place MFMA through inline asm with explicit wait states, see species_linear.hip
 __device__ __forceinline__ void mfma_16x16x4(f32x4& acc, float a, float b) {
+#ifdef SLR_ABLATE_NO_MFMA
+    acc[0] += a * b;
+    return;
+#endif
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15" ::: "memory"); }
 
-template <int D>
+template <int D, bool HAS_ADD>
 __device__ __forceinline__ void run_item(const LinSeg& L, int vt, const float* __restrict__ xs, int xs_stride,
                                          const float* __restrict__ ws, const float* __restrict__ add, int add_ld,
                                          float* __restrict__ out, int d_out, int node, bool row_ok, int g, int c) {
     f32x4 acc[D];
     const int vb = 16 * vt + 4 * g;  // this lane's first output channel of the D fragment
-    if (add && row_ok && vb + 4 <= L.mo) {
+    // HAS_ADD is a template parameter: with a run-time test the compiler must assume addend loads in flight and puts
+    // s_waitcnt vmcnt(0) in front of the first matrix instruction -- which on gfx950 also waits for the previous
+    // item's STORES to be acknowledged (62 % of the waves' cycles)
+    if (HAS_ADD && row_ok && vb + 4 <= L.mo) {
         const float* ap = add + (int64_t)node * add_ld + L.o_off + vb * D;
         float o[4 * D];
 #pragma unroll
@@ -55,7 +62,7 @@ __device__ __forceinline__ void run_item(const LinSeg& L, int vt, const float* _
         for (int m = 0; m < D; ++m) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[m][r] = (add && row_ok && vb + r < L.mo) ? add[(int64_t)node * add_ld + L.o_off + (vb + r) * D + m] : 0.0f;
+                acc[m][r] = (HAS_ADD && row_ok && vb + r < L.mo) ? add[(int64_t)node * add_ld + L.o_off + (vb + r) * D + m] : 0.0f;
         }
     }
     const int va = 16 * vt + c;      // the A operand's output channel
@@ -227,14 +234,19 @@ __global__ __launch_bounds__(WAVES * 64, 3) void species_linear_rows_kernel(
                 if (n_segs >= 0) continue;
 #endif
                 const LinSeg L = sl[sg];
+#define SLR_ITEM(DD)                                                                                              \
+    if (add) run_item<DD, true>(L, vt, xs, xs_stride, ws, add, add_ld, out, d_out, node, row_ok, g, c);           \
+    else run_item<DD, false>(L, vt, xs, xs_stride, ws, add, add_ld, out, d_out, node, row_ok, g, c);              \
+    break;
                 switch (L.d) {
-                    case 1: run_item<1>(L, vt, xs, xs_stride, ws, add, add_ld, out, d_out, node, row_ok, g, c); break;
-                    case 3: run_item<3>(L, vt, xs, xs_stride, ws, add, add_ld, out, d_out, node, row_ok, g, c); break;
-                    case 5: run_item<5>(L, vt, xs, xs_stride, ws, add, add_ld, out, d_out, node, row_ok, g, c); break;
-                    case 7: run_item<7>(L, vt, xs, xs_stride, ws, add, add_ld, out, d_out, node, row_ok, g, c); break;
-                    case 9: run_item<9>(L, vt, xs, xs_stride, ws, add, add_ld, out, d_out, node, row_ok, g, c); break;
+                    case 1: SLR_ITEM(1)
+                    case 3: SLR_ITEM(3)
+                    case 5: SLR_ITEM(5)
+                    case 7: SLR_ITEM(7)
+                    case 9: SLR_ITEM(9)
                     default: break;  // 2l+1 > 9: rejected by the host plan
                 }
+#undef SLR_ITEM
             }
         }
     }
