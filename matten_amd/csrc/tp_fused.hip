@@ -293,18 +293,18 @@ __device__ __forceinline__ void mfma_tiles(const f16x8* __restrict__ ah, const f
 }
 
 // loader role of a thread: (edge row of the chunk, 16-byte piece of the row) per MFMA tile; fixed for the whole walk
+template <int TT>  // MFMA tiles (16 edge rows) per chunk: a compile-time count keeps every load of the loop unconditional
 struct StageLoader {
     const char* base;
     const char* safe;
     int64_t row_bytes;
     float* st_w;
-    int beg_ld[STAGE_TMAX], deg_ld[STAGE_TMAX], so_ld[STAGE_TMAX];
-    int T, CH;
-    f32x4 pf[STAGE_TMAX];
+    int beg_ld[TT], deg_ld[TT], so_ld[TT];
+    int CH;
+    f32x4 pf[TT];
 
     __device__ __forceinline__ void init(const Args& a, float* stage, int cu_log2, int beg, int deg_node) {
         const int npw = 64 >> cu_log2;
-        T = npw > 16 ? 2 : 1;
         const int ch_log2 = npw >= 16 ? 0 : 4 - (6 - cu_log2);
         CH = 1 << ch_log2;
         const int piece = threadIdx.x & 15;
@@ -314,7 +314,7 @@ struct StageLoader {
         safe = reinterpret_cast<const char*>(a.w2p);
         st_w = stage + (threadIdx.x >> 4) * STAGE_ROW + piece * 4;
 #pragma unroll
-        for (int t = 0; t < STAGE_TMAX; ++t) {
+        for (int t = 0; t < TT; ++t) {
             const int n = (int)(threadIdx.x >> 4) + 16 * t;
             const int jn = (n >> ch_log2) & (npw - 1);
             so_ld[t] = n & (CH - 1);
@@ -328,24 +328,23 @@ struct StageLoader {
     // load the compiler cannot count the loads in flight and falls back to s_waitcnt vmcnt(0) at the next gather.
     __device__ __forceinline__ void issue(int s0) {
 #ifndef MATTEN_ABLATE_NO_H2LOAD
-        pf[0] = *reinterpret_cast<const f32x4*>(
-            deg_ld[0] > 0 ? base + (int64_t)(beg_ld[0] + min(s0 + so_ld[0], deg_ld[0] - 1)) * row_bytes : safe);
-        if (T > 1)  // uniform over the workgroup
-            pf[1] = *reinterpret_cast<const f32x4*>(
-                deg_ld[1] > 0 ? base + (int64_t)(beg_ld[1] + min(s0 + so_ld[1], deg_ld[1] - 1)) * row_bytes : safe);
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            pf[t] = *reinterpret_cast<const f32x4*>(
+                deg_ld[t] > 0 ? base + (int64_t)(beg_ld[t] + min(s0 + so_ld[t], deg_ld[t] - 1)) * row_bytes : safe);
 #endif
     }
     __device__ __forceinline__ void publish(int buf) {
 #pragma unroll
-        for (int t = 0; t < STAGE_TMAX; ++t)
-            if (t < T) *reinterpret_cast<f32x4*>(st_w + buf * STAGE_FLOATS + 16 * t * STAGE_ROW) = pf[t];
+        for (int t = 0; t < TT; ++t) *reinterpret_cast<f32x4*>(st_w + buf * STAGE_FLOATS + 16 * t * STAGE_ROW) = pf[t];
     }
 };
 
 // a unit that only feeds the stage (same barrier sequence as run_group_shared)
-__device__ __forceinline__ void run_loader_only(const Args& a, int cu_log2, float* __restrict__ stage, int beg, int deg_node,
-                                                int maxdeg) {
-    StageLoader ld;
+template <int TT>
+__device__ __forceinline__ void run_loader_only_t(const Args& a, int cu_log2, float* __restrict__ stage, int beg,
+                                                  int deg_node, int maxdeg) {
+    StageLoader<TT> ld;
     ld.init(a, stage, cu_log2, beg, deg_node);
     ld.issue(0);
     ld.publish(0);
@@ -357,8 +356,13 @@ __device__ __forceinline__ void run_loader_only(const Args& a, int cu_log2, floa
         __syncthreads();
     }
 }
+__device__ __forceinline__ void run_loader_only(const Args& a, int cu_log2, float* __restrict__ stage, int beg, int deg_node,
+                                                int maxdeg) {
+    if ((64 >> cu_log2) > 16) run_loader_only_t<2>(a, cu_log2, stage, beg, deg_node, maxdeg);
+    else run_loader_only_t<1>(a, cu_log2, stage, beg, deg_node, maxdeg);
+}
 
-template <int L1, int GI>
+template <int L1, int GI, int TT>
 __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry& ge, float* __restrict__ tile,
                                                  float* __restrict__ stage, int entry, int node, int lane, bool valid,
                                                  int beg, int deg_node, int maxdeg) {
@@ -375,7 +379,6 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const int npw = 64 >> cu_log2;
     const int ch_log2 = npw >= 16 ? 0 : 4 - (6 - cu_log2);
     const int CH = 1 << ch_log2;
-    const int T = npw > 16 ? 2 : 1;
     const int ncols = ge.mul * NC;
     const int MT = (ncols + 15) >> 4;
 
@@ -430,7 +433,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         }
     }
 
-    StageLoader ld;
+    StageLoader<TT> ld;
     ld.init(a, stage, cu_log2, beg, deg_node);
     ld.issue(0);
 
@@ -467,8 +470,8 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         ld.issue(s0 + CH);
         const float* sb = stage + buf * STAGE_FLOATS;
 #pragma unroll
-        for (int t = 0; t < STAGE_TMAX; ++t) {
-            if (t < T) {
+        for (int t = 0; t < TT; ++t) {
+            {
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(sb + (16 * t + c) * STAGE_ROW + g * 4);
                 const f16x8 bl = *reinterpret_cast<const f16x8*>(sb + (16 * t + c) * STAGE_ROW + 16 + g * 4);
 #ifndef MATTEN_ABLATE_NO_MFMA
@@ -568,7 +571,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 }
 
 #define MATTEN_GROUP_CASE_SHARED(L1, GI) \
-    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg); break;
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): if (nodes_per_wave > 16) run_group_shared<L1, GI, 2>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg); else run_group_shared<L1, GI, 1>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg); break;
 
 #define MATTEN_GROUP_CASE(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, node, lane, valid, beg, deg, maxdeg); break;
