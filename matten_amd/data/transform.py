@@ -91,3 +91,75 @@ class ScalarNormalize(_Standardizer):
         std = torch.where(std == 0, torch.ones_like(std), std)  # StandardScaler leaves constant features unscaled
         self.load_state_dict({"mean": mean, "norm": std})
         return mean, std
+
+
+class _DelayedStatistics(torch.nn.Module):
+    """Shared part of the two target transforms below: the statistics file is read the first time `inverse` (or
+    `forward`) runs, like the reference (data/transform.py:477-488, 577-589), unless the statistics were handed over
+    directly (a checkpoint that carries the filled normalizer)."""
+
+    def __init__(self, dataset_statistics_path=None):
+        super().__init__()
+        self.dataset_statistics_path = dataset_statistics_path
+        self.dataset_statistics_loaded = False
+
+    def _statistics(self):
+        if self.dataset_statistics_path is None:
+            raise ValueError("Cannot load dataset statistics from file `None`")
+        return torch.load(self.dataset_statistics_path, map_location="cpu", weights_only=True)
+
+
+class TensorTargetTransform(_DelayedStatistics):
+    """reference data/transform.py:520-590: MeanNormNormalize of ONE tensor target given in irreps space"""
+
+    def __init__(self, target_name: str = "elastic_tensor_full", dataset_statistics_path=None, scale: float = 1.0,
+                 irreps: str = "2x0e+2x2e+4e"):
+        super().__init__(dataset_statistics_path)
+        self.target_name = target_name
+        self.normalizer = MeanNormNormalize(irreps=irreps, scale=scale)
+
+    def _fill_state_dict(self, device):
+        if not self.dataset_statistics_loaded:
+            if not self.normalizer.mean_norm_initialized:
+                self.normalizer.load_state_dict(self._statistics()[self.target_name])
+            self.dataset_statistics_loaded = True
+        if self.normalizer.mean.device != torch.device(device):
+            self.to(device)
+
+    def forward(self, target: Tensor) -> Tensor:
+        """the reference takes a Crystal and rewrites struct.y[target_name]; the dataset layer is out of scope here, so
+        this is the same map on the bare [.., D] target"""
+        self._fill_state_dict(target.device)
+        return self.normalizer(target)
+
+    def inverse(self, data: Tensor) -> Tensor:
+        self._fill_state_dict(data.device)
+        return self.normalizer.inverse(data)
+
+
+class ScalarTargetTransform(_DelayedStatistics):
+    """reference data/transform.py:418-517: one ScalarNormalize(1) per scalar target name"""
+
+    def __init__(self, target_names, dataset_statistics_path=None):
+        super().__init__(dataset_statistics_path)
+        self.target_names = list(target_names)
+        self.normalizers = torch.nn.ModuleDict({name: ScalarNormalize(num_features=1) for name in self.target_names})
+
+    def _fill_state_dict(self, device):
+        if not self.dataset_statistics_loaded:
+            stats = None
+            for name in self.target_names:
+                if not self.normalizers[name].mean_norm_initialized:
+                    stats = stats if stats is not None else self._statistics()
+                    self.normalizers[name].load_state_dict(stats[name])
+            self.dataset_statistics_loaded = True
+        if any(n.mean.device != torch.device(device) for n in self.normalizers.values()):
+            self.to(device)
+
+    def forward(self, target: Tensor, target_name: str) -> Tensor:
+        self._fill_state_dict(target.device)
+        return self.normalizers[target_name](target)
+
+    def inverse(self, data: Tensor, target_name: str) -> Tensor:
+        self._fill_state_dict(data.device)
+        return self.normalizers[target_name].inverse(data)

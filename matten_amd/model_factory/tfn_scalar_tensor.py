@@ -165,11 +165,14 @@ class ScalarTensorModel(torch.nn.Module):
         return {names[0]: out}
 
     def transform_prediction(self, preds, task_name: str = "elastic_tensor_full"):
+        """reference tfn_scalar_tensor.py:80-94: undo the target standardisation of the task, if it has one"""
         task = self.tasks.get(task_name)
         normalizer = getattr(task, "normalizer", None)
-        if normalizer is not None:
-            return {task_name: normalizer.inverse(preds[task_name])}
-        return {task_name: preds[task_name]}
+        if normalizer is None:
+            return {task_name: preds[task_name]}
+        if hasattr(normalizer, "normalizers"):  # ScalarTargetTransform keeps one normaliser per target name
+            return {task_name: normalizer.inverse(preds[task_name], task_name)}
+        return {task_name: normalizer.inverse(preds[task_name])}
 
     def transform_target(self, target, task_name: str = "elastic_tensor_full"):
         if task_name not in target:

@@ -55,7 +55,9 @@ class Irrep(tuple):
 class MulIr(tuple):
     __slots__ = ()
 
-    def __new__(cls, mul, ir):
+    def __new__(cls, mul, ir=None):
+        if ir is None:  # MulIr((mul, ir)): the form pickle / copy re-create a tuple subclass with
+            mul, ir = mul
         return tuple.__new__(cls, (int(mul), Irrep(ir)))
 
     mul = property(lambda self: self[0])

@@ -43,17 +43,22 @@ def get_pretrained_model(identifier: str, checkpoint: str = "model_final.ckpt", 
             f"{path} not found. (The reference's own pretrained/20230627/model_final.ckpt is a large blob that is "
             "not shipped with the source tree; pass a directory holding model_final.ckpt + config_final.yaml.)"
         )
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    from .checkpoint import filter_state_dict, load_checkpoint, plain, rebuild_tasks
+
+    # restricted unpickler: the file's matten / e3nn / Lightning objects become inert placeholders (checkpoint.py)
+    ckpt = load_checkpoint(path)
     hp = ckpt["hyper_parameters"]
+    tasks = rebuild_tasks(hp.get("tasks"), path.parent)
     model = model_class(
-        tasks=hp.get("tasks"), backbone_hparams=hp["backbone_hparams"], dataset_hparams=hp["dataset_hparams"],
-        optimizer_hparams=hp.get("optimizer_hparams"), lr_scheduler_hparams=hp.get("lr_scheduler_hparams"),
+        tasks=tasks, backbone_hparams=plain(hp["backbone_hparams"]), dataset_hparams=plain(hp["dataset_hparams"]),
+        optimizer_hparams=plain(hp.get("optimizer_hparams")), lr_scheduler_hparams=plain(hp.get("lr_scheduler_hparams")),
     )
-    missing, unexpected = model.load_state_dict(ckpt["state_dict"], strict=False)
-    tolerated = ("output_mask", "tp.tp.weight")  # e3nn-internal buffers a reference checkpoint carries
-    bad = [k for k in unexpected if not k.endswith(tolerated) and "metrics" not in k]
+    # e3nn-internal buffers (output_mask, empty weight / bias placeholders, fx-graph Wigner-3j constants) and
+    # Lightning metric state are dropped; anything else that does not match is an error
+    state, missing, bad = filter_state_dict(ckpt["state_dict"], list(model.state_dict().keys()))
     if missing or bad:
         raise RuntimeError(f"checkpoint does not match the model: missing={missing} unexpected={bad}")
+    model.load_state_dict(state, strict=True)
     return model.to(device).eval()
 
 
