@@ -175,6 +175,7 @@ def main():
             bytes_per_launch = sum(layer_bytes) / len(layer_bytes)
             avg_ms = sum(layer_ms) / len(layer_ms)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = _pmc_traffic("tp_fused_kernel")
             result["roofline"] = {
                 "kernel": f"tp_fused_kernel (radial GEMM + CG paths + neighbour sum; mean over its {len(tp_plans)} launches "
                           "per forward, one per conv layer)",
@@ -183,7 +184,13 @@ def main():
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK / 1e9),
-                "traffic": _pmc_traffic("tp_fused_kernel"),
+                "traffic": traffic,
+                # `achieved` / `frac` price the CONTRACT bytes (SURVEY 8d two-kernel architecture: they include 4 W
+                # bytes per edge for a w[E,W] this kernel never materialises).  What the memory system really moves:
+                "measured_GBps": None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9,
+                "measured_frac": None if traffic is None else traffic / (avg_ms * 1e-3) / HBM_PEAK,
+                "physical_bound": "fp32 VALU issue at 3 waves/SIMD (DESIGN.md section 4); HBM is the bound of the "
+                                  "contract figure only",
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms,
                 "per_layer": [

@@ -53,6 +53,13 @@ int matten_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes
                      int32_t* rowptr, int32_t* src_sorted, void* workspace, size_t workspace_bytes,
                      int32_t* err_flag, matten_stream_t stream);
 
+/* Grouping of n items by an integer key in [0, n_keys): order[n] = item positions stably sorted by key,
+ * seg[n_keys+1] = first sorted position of each key.  This is the species grouping the species-indexed linears
+ * (FullyConnectedTensorProduct with a one-hot operand, nn/conv.py:59-86) walk instead of evaluating densely over
+ * the one-hot.  workspace: matten_csr_workspace_bytes(n, n_keys) bytes.  A key out of range sets err_flag bit 0. */
+int matten_group_by_key(const int64_t* key, int64_t n, int64_t n_keys, int32_t* order, int32_t* seg,
+                        void* workspace, size_t workspace_bytes, int32_t* err_flag, matten_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * SpeciesEmbedding.forward (nn/embedding.py:85-110) + _AtomicNumberToIndex.forward (:230-259)
  *   species_index[n] = z_to_index[Z[n] - min_z]           (int64 out, reference dtype)

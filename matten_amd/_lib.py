@@ -22,6 +22,7 @@ SIGNATURES = {
     "matten_abi_version": (c_int, []),
     "matten_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "matten_csr_build": (c_int, [P, c_int64, c_int64, P, P, P, P, c_size_t, P, P]),
+    "matten_group_by_key": (c_int, [P, c_int64, c_int64, P, P, P, c_size_t, P, P]),
     "matten_species_embed": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_int64, P, P, P, P, P, P]),
     "matten_edge_geom": (c_int, [P, P, P, P, c_int64, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, c_int, P, P, P, P, P]),
     "matten_radial_mlp": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, P, c_int, c_int, c_float, P, P]),

@@ -44,6 +44,20 @@ __global__ void csr_src_kernel(const int64_t* __restrict__ edge_index, const int
     src_sorted[e] = (int32_t)s;
 }
 
+// keys of a plain grouping (matten_group_by_key): value = position, key clamped into [0, n_keys)
+__global__ void group_keys_kernel(const int64_t* __restrict__ key, int64_t n, int64_t n_keys,
+                                  int32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* err_flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t k = key[i];
+    if (k < 0 || k >= n_keys) {
+        atomicOr(err_flag, 1);
+        k = k < 0 ? 0 : n_keys - 1;
+    }
+    keys[i] = (int32_t)k;
+    vals[i] = (int32_t)i;
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 inline int key_bits(int64_t N) {
@@ -94,6 +108,38 @@ extern "C" int matten_csr_build(const int64_t* edge_index, int64_t E, int64_t N,
     csr_rowptr_kernel<<<(unsigned)matten_cdiv(N + 1, T), T, 0, stream>>>(keys_out, E, N, rowptr);
     MATTEN_LAUNCH_CHECK();
     csr_src_kernel<<<(unsigned)matten_cdiv(E, T), T, 0, stream>>>(edge_index, perm, E, N, src_sorted);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+// order[n] = the positions 0..n-1 stably sorted by key[i] in [0, n_keys); seg[n_keys+1] = first position of each key.
+// Used for the species grouping the species-indexed linears walk (reference nn/conv.py:59-86 evaluates them densely
+// over the one-hot).  err_flag bit 0 is set when a key is out of range (the item is then grouped with the nearest key).
+extern "C" int matten_group_by_key(const int64_t* key, int64_t n, int64_t n_keys, int32_t* order, int32_t* seg,
+                                   void* workspace, size_t workspace_bytes, int32_t* err_flag, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n_keys <= 0 || n_keys >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+    if (!seg || !err_flag) return MATTEN_EINVAL;
+    if (n == 0) {
+        if (hipMemsetAsync(seg, 0, (size_t)(n_keys + 1) * sizeof(int32_t), stream) != hipSuccess) return MATTEN_ELAUNCH;
+        return MATTEN_OK;
+    }
+    if (!key || !order || !workspace) return MATTEN_EINVAL;
+    if (workspace_bytes < matten_csr_workspace_bytes(n, n_keys)) return MATTEN_ENOMEM;
+    char* ws = (char*)workspace;
+    size_t sg = align256((size_t)n * sizeof(int32_t));
+    int32_t* keys_in = (int32_t*)ws;
+    int32_t* keys_out = (int32_t*)(ws + sg);
+    int32_t* vals_in = (int32_t*)(ws + 2 * sg);
+    void* tmp = ws + 3 * sg;
+    size_t tmp_bytes = workspace_bytes - 3 * sg;
+    const int T = 256;
+    group_keys_kernel<<<(unsigned)matten_cdiv(n, T), T, 0, stream>>>(key, n, n_keys, keys_in, vals_in, err_flag);
+    MATTEN_LAUNCH_CHECK();
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, order, (size_t)n, 0, key_bits(n_keys),
+                                  stream, false) != hipSuccess)
+        return MATTEN_ELAUNCH;
+    csr_rowptr_kernel<<<(unsigned)matten_cdiv(n_keys + 1, T), T, 0, stream>>>(keys_out, n, n_keys, seg);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

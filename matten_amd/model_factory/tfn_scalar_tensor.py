@@ -19,12 +19,13 @@ from ..nn.nodewise import NodewiseLinear, NodewiseReduce
 from ..nn.utils import SpeciesLinear
 from ..o3 import Irreps
 from ..utils import CartesianTensor, ToCartesian
-from .utils import create_sequential_module
+from .utils import create_sequential_module, validate_hparams
 
 OUT_FIELD_NAME = "my_model_output"
 
 
 def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any], pooling: bool = True):
+    validate_hparams(hparams, dataset_hparams)
     use_atom_feats = hparams.get("use_atom_feats", False)
     atom_feats_dim = dataset_hparams.get("atom_feats_size", None)
     materialize = bool(hparams.get("materialize_intermediates", False))

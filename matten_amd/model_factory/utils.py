@@ -31,3 +31,57 @@ def create_sequential_module(
             raise RuntimeError(f"Failed instantiate module `{cls_type.__name__}` with kwargs: `{kw}`") from e
         built[name] = prev
     return Sequential(built)
+
+
+class UnsupportedConfig(NotImplementedError):
+    """a hyper-parameter combination of the reference that the gfx950 kernels do not cover"""
+
+
+def validate_hparams(hparams: Dict, dataset_hparams: Dict = None) -> None:
+    """One up-front check of the backbone hyper-parameters against what the accelerated path implements, so that an
+    unsupported reference config fails at construction with the full list instead of deep inside a layer.
+
+    Supported envelope (covers every config the reference ships: pretrained/20230627/config_final.yaml,
+    scripts/configs/{materials_tensor,atomic_tensor}.yaml, tests/model/test_tfn_tensor.py):
+      irreps_edge_sh            0e+1o+...+lmax with lmax <= 4, parity (-1)^l
+      radial_basis_type         bessel                          (reference nn/embedding.py:189-199)
+      invariant_layers/neurons  2 x 32  (radial MLP [nb,32,32,W]; nb <= 16)   (nn/utils.py:246-251)
+      nonlinearity_type         gate                            (nn/utils.py:96-140)
+      normalization             batch | none                    (nn/utils.py:414-418)
+      reduce                    mean | sum                      (nn/nodewise.py:142-148)
+      use_atom_feats            false                           (nn/embedding.py:96-108)
+      dataset_hparams           allowed_species given
+    """
+    from ..o3 import Irreps
+
+    problems = []
+    try:
+        sh = Irreps(hparams["irreps_edge_sh"])
+        lmax = len(sh) - 1
+        if lmax > 4 or sh != Irreps.spherical_harmonics(lmax):
+            problems.append(f"irreps_edge_sh={hparams['irreps_edge_sh']!r}: must be 0e+1o+...+lmax with lmax <= 4")
+    except Exception as e:  # noqa: BLE001
+        problems.append(f"irreps_edge_sh={hparams.get('irreps_edge_sh')!r}: {e}")
+    if str(hparams.get("radial_basis_type", "bessel")).lower() != "bessel":
+        problems.append(f"radial_basis_type={hparams['radial_basis_type']!r}: only 'bessel'")
+    if int(hparams.get("num_radial_basis", 8)) > 16:
+        problems.append(f"num_radial_basis={hparams['num_radial_basis']}: at most 16")
+    if int(hparams.get("invariant_layers", 2)) != 2 or int(hparams.get("invariant_neurons", 32)) != 32:
+        problems.append(f"invariant_layers={hparams.get('invariant_layers')}, invariant_neurons="
+                        f"{hparams.get('invariant_neurons')}: the radial MLP is fixed at 2 hidden layers of 32")
+    if str(hparams.get("nonlinearity_type", "gate")).lower() != "gate":
+        problems.append(f"nonlinearity_type={hparams['nonlinearity_type']!r}: only 'gate'")
+    norm = hparams.get("normalization")
+    if norm is not None and str(norm).lower() not in ("batch", "none"):
+        problems.append(f"normalization={norm!r}: only 'batch' or none")
+    if str(hparams.get("reduce", "mean")).lower() not in ("mean", "sum"):
+        problems.append(f"reduce={hparams['reduce']!r}: only 'mean' or 'sum'")
+    if hparams.get("use_atom_feats", False):
+        problems.append("use_atom_feats=True: extra per-atom input features are not implemented")
+    if dataset_hparams is not None and not dataset_hparams.get("allowed_species"):
+        problems.append("dataset_hparams['allowed_species'] is required")
+    if problems:
+        raise UnsupportedConfig(
+            "this backbone configuration is valid for the reference but outside what matten_amd's MI355X kernels "
+            "implement:\n  - " + "\n  - ".join(problems) + "\n(see validate_hparams.__doc__ for the supported envelope)"
+        )

@@ -113,15 +113,26 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
         sidx, s32, feats, attrs, err = ops.species_embed(
             Z, lut, lo, hi, S, self.linear.weight, self.linear.bias, want_attrs=self.materialize
         )
+        # the destination-sorted CSR every conv layer walks is built here, so that its range check of edge_index
+        # shares this module's one host sync (the reference would raise an IndexError in its first gather,
+        # nn/_nequip.py:238; the kernels clamp, so a malformed batch must not get past this point)
+        csr_err = None
+        if DataKey.EDGE_INDEX in data:
+            from ._nequip import ensure_graph
+
+            csr_err = ensure_graph(data).get("_amd_csr_err")
         if self.check_species:
-            flags = int(err.item())
-            if flags:
-                a2i.raise_for_flags(flags, Z)
+            flags = err if csr_err is None else torch.cat([err, csr_err])
+            flags = flags.tolist()
+            if flags[0]:
+                a2i.raise_for_flags(flags[0], Z)
+            if len(flags) > 1 and flags[1] & 1:
+                n_nodes = data[DataKey.POSITIONS].shape[0]
+                raise IndexError(f"edge_index holds node ids outside [0, {n_nodes}) (a malformed batch)")
         if not provided:
             data[DataKey.SPECIES_INDEX] = sidx
         # nodes grouped by species (stable): the species-indexed linears walk this order
-        ids = torch.stack([torch.arange(sidx.shape[0], dtype=torch.int64, device=sidx.device), sidx.clamp(min=0)])
-        order, seg, _, _ = ops.csr_build(ids, S)
+        order, seg, _ = ops.group_by_key(sidx.clamp(min=0), S)
         data[DataKey.AMD_SPECIES] = (order, seg)
         if attrs is not None:
             data[DataKey.NODE_ATTRS] = attrs

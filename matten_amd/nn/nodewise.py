@@ -70,6 +70,9 @@ class NodewiseReduce(ModuleIrreps, torch.nn.Module):
         if ptr is None:
             # PyG batches are contiguous per crystal: recover segment offsets from `batch`
             batch = data[DataKey.BATCH]
+            # the reference scatters by id (nn/nodewise.py:144) and accepts any order; segments need sorted ids
+            if batch.numel() > 1 and bool((batch[1:] < batch[:-1]).any()):
+                raise ValueError("`batch` must be non-decreasing (nodes grouped per crystal) when `ptr` is not given")
             counts = torch.bincount(batch)
             ptr = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=batch.device)
             ptr[1:] = torch.cumsum(counts, 0)

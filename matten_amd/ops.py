@@ -104,6 +104,22 @@ def csr_build(edge_index: torch.Tensor, n_nodes: int) -> Tuple[torch.Tensor, tor
     return perm, rowptr, src, err
 
 
+def group_by_key(key: torch.Tensor, n_keys: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (order[n] i32: positions stably sorted by key, seg[n_keys+1] i32, err_flag[1] i32)"""
+    lib = _lib.load()
+    key = _need(key, torch.int64, "key")
+    n = key.shape[0]
+    dev = key.device
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    seg = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    nbytes = lib.matten_csr_workspace_bytes(n, n_keys)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    _lib.check(lib.matten_group_by_key(_ptr(key), n, n_keys, _ptr(order), _ptr(seg), _ptr(ws), nbytes, _ptr(err),
+                                       _stream()), "matten_group_by_key")
+    return order, seg, err
+
+
 def species_embed(atomic_numbers, z_to_index, min_z: int, max_z: int, n_species: int, weight, bias,
                   want_attrs: bool = False):
     """-> (species_index i64 [N], species_i32 [N], node_feats [N,dim], node_attrs [N,S] | None, err_flag)"""

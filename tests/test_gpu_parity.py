@@ -63,6 +63,39 @@ def test_csr_empty_and_bad_index():
     assert int(err.item()) & 1
 
 
+def test_group_by_key_is_a_stable_sort():
+    from matten_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    key = torch.randint(0, 7, (1000,), generator=g)
+    order, seg, err = ops.group_by_key(key.to(DEV), 7)
+    assert torch.equal(order.cpu().long(), torch.sort(key, stable=True).indices)
+    assert seg.cpu().tolist() == [0] + torch.cumsum(torch.bincount(key, minlength=7), 0).tolist()
+    assert int(err.item()) == 0
+    *_, err = ops.group_by_key(torch.tensor([0, 9, 1], device=DEV), 3)
+    assert int(err.item()) & 1
+    _, seg, _ = ops.group_by_key(torch.zeros(0, dtype=torch.int64, device=DEV), 4)
+    assert seg.cpu().tolist() == [0] * 5
+
+
+def test_malformed_edge_index_raises_like_the_reference():
+    """reference nn/_nequip.py:238 gathers pos[edge_index] and raises IndexError on an id outside the batch; the kernels
+    clamp, so the backbone has to check: the check rides on the species check's host sync"""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _fcc(2)
+    _, model = build_pair(dict(LMAX2, num_layers=1), ds, device=DEV)
+    good = collate(graphs, device=DEV)
+    with torch.no_grad():
+        model(dict(good))  # a well-formed batch passes
+        for bad_id in (good["pos"].shape[0], -1):
+            bad = dict(good)
+            bad["edge_index"] = good["edge_index"].clone()
+            bad["edge_index"][0, 5] = bad_id
+            with pytest.raises(IndexError, match="edge_index"):
+                model(bad)
+
+
 def test_edge_geometry_sh_and_bessel_vs_oracle():
     from matten_amd import ops
     from matten_amd.data.graph import collate
@@ -417,7 +450,7 @@ def _species_linear_case(irreps_in, irreps_out, S, N, with_add, gen):
     wp = torch.randn(S, lp.w_stride, device=DEV, generator=gen)
     add = torch.randn(N, lp.d_out, device=DEV, generator=gen) if with_add else None
     species = torch.randint(0, S, (N,), device=DEV, generator=gen)
-    order, seg, _, _ = ops.csr_build(torch.stack([torch.arange(N, device=DEV), species]), S)
+    order, seg, _ = ops.group_by_key(species, S)
     items = [torch.from_numpy(np.ascontiguousarray(m)).to(DEV) for m in lp.passes]
     got = ops.species_linear(x, (order, seg), wp, lp.w_stride, items, lp.d_out, add, lp.fully_covered)
     want = add.double().clone() if with_add else torch.zeros(N, lp.d_out, dtype=torch.float64, device=DEV)

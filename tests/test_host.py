@@ -137,8 +137,14 @@ def test_no_cpu_fallback_and_loud_errors():
     for path in glob.glob(os.path.join(ROOT, "matten_amd", "**", "*.py"), recursive=True):
         src = open(path).read()
         assert "import oracle" not in src and "from oracle" not in src, path
-    with pytest.raises(RuntimeError, match="EdgeLengthEmbedding") as ei:
+    with pytest.raises(NotImplementedError, match="radial_basis_type"):  # the up-front validator
         ScalarTensorModel(backbone_hparams=dict(PAPER, radial_basis_type="gaussian"), dataset_hparams=ds)
+    # a module built directly still refuses what it does not implement, wrapped like the reference's factory does
+    from matten_amd.model_factory.utils import create_sequential_module
+    from matten_amd.nn.embedding import EdgeLengthEmbedding, SpeciesEmbedding
+    with pytest.raises(RuntimeError, match="EdgeLengthEmbedding") as ei:
+        create_sequential_module({"one_hot": (SpeciesEmbedding, {"allowed_species": [13]}),
+                                  "radial_basis": (EdgeLengthEmbedding, {"basis": "gaussian"})})
     assert isinstance(ei.value.__cause__, NotImplementedError)
     with pytest.raises(RuntimeError, match="Failed instantiate module"):
         ScalarTensorModel(backbone_hparams=dict(PAPER, conv_layer_irreps="4x5e"), dataset_hparams=ds)
@@ -369,3 +375,24 @@ def test_split_a_tiles_reconstructs_the_last_radial_layer():
                     want = w2p[k, w_base + 16 * mt + c].item()
                     got = (frag[t0 + mt, lane, kk].float().item() + frag[t0 + mt, lane, 8 + kk].float().item() / 2048.0) * inv[e].item()
                     assert abs(got - want) <= 2.0 ** -21 * block.abs().max().item() + 1e-30
+
+
+def test_unsupported_configs_fail_up_front_with_the_full_list():
+    """every hyper-parameter outside the accelerated envelope is reported by ONE error at construction"""
+    from common import PAPER
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+    from matten_amd.model_factory.utils import UnsupportedConfig, validate_hparams
+
+    ds = {"allowed_species": [13, 29], "average_num_neighbors": 18.0}
+    validate_hparams(PAPER, ds)  # the paper config is inside
+    bad = dict(PAPER, nonlinearity_type="norm", normalization="instance", reduce="max", radial_basis_type="gaussian",
+               invariant_neurons=64, use_atom_feats=True, irreps_edge_sh="0e+1o+2e+3o+4e+5o")
+    with pytest.raises(UnsupportedConfig) as ei:
+        ScalarTensorModel(backbone_hparams=bad, dataset_hparams=ds)
+    msg = str(ei.value)
+    for needle in ("nonlinearity_type", "normalization", "reduce", "radial_basis_type", "invariant_neurons",
+                   "use_atom_feats", "irreps_edge_sh"):
+        assert needle in msg, needle
+    assert isinstance(ei.value, NotImplementedError)
+    with pytest.raises(UnsupportedConfig, match="allowed_species"):
+        validate_hparams(PAPER, {"average_num_neighbors": 18.0})
