@@ -185,6 +185,38 @@ int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const flo
                     float* agg /*[N,d_mid]*/, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Conv-fused kernel: tensor product + neighbour sum + lin2 + self-connection of the light input blocks in one launch
+ * (reference nn/conv.py:113-123:  scatter(tp(x[src], Y, w)) / sqrt(avg)  ->  lin2(., species) + sc).
+ * A workgroup owns matten_tp_lin2_group_nodes() = 8 destination nodes and walks `light_entries` (group entries with
+ * 8 lanes per node, l1 <= 1) four per ROUND; after a round the four waves' neighbour sums sit in LDS
+ * ([wave][coupling][node, k][channel 8], matten_tp_lin2_t_wave_floats() floats per wave) and lin2 is applied there:
+ *   rounds[n_rounds, 4]      : entry per wave, -1 = no entry (the wave only feeds the shared stage)
+ *   light_entries[n, 32]     : group entries as matten_tp_fused; words 8..19 = accumulator offset of coupling c in
+ *                              the wave's LDS region (present couplings packed)
+ *   slot_index[n_rounds,4,2] : (first slot, count) of (round, wave)
+ *   slots[n_slots, 8]        : {chain_begin, chain_len, d3, n_pairs = mul_out * d3, out_off, pair_base, magic, 0}: the
+ *                              8 lanes of a node take the (v, k) pairs pair_base .. pair_base+7 of the output irrep at
+ *                              out_off (v = (pair * magic) >> 16 = pair / d3)
+ *   chain[n_chain, 2]        : {float offset of a (wave, coupling) block in the LDS area, float offset of the matching
+ *                              [mul_out][8] weight block in a species' row of atab}
+ *   atab[n_species, a_numel] : lin2 weights W[u, s, v] * fan_in^-1/2 in that layout (zero for channels past the entry)
+ *   species[N] int32, add[N, add_ld] (self-connection) or NULL, out[N, d_out] = add + lin2(light blocks)
+ * a_split / a_scale_inv as matten_tp_fused (required here), a_scale_inv indexed like light_entries.
+ * Host tables: matten_amd/plan.py plan_conv_fused.  The remaining (heavy) entries go through matten_tp_fused into a
+ * compact agg_rest and matten_species_linear(agg_rest, add = out).
+ * ------------------------------------------------------------------------------------------ */
+int matten_tp_lin2_group_nodes(void);
+int matten_tp_lin2_t_wave_floats(void);
+int matten_tp_lin2(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
+                   const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
+                   int64_t n_nodes, const int32_t* light_entries, int64_t n_entries, const int32_t* rounds,
+                   int64_t n_rounds, const int32_t* slot_index, const int32_t* slots, int64_t n_slots,
+                   const int32_t* chain, int64_t n_chain, const float* atab, int64_t a_numel, int64_t n_species,
+                   const int32_t* species, float avg_num_neighbors, const float* num_neigh, const uint16_t* a_split,
+                   const float* a_scale_inv, const float* add, int64_t add_ld, int64_t d_out, float* out,
+                   matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * FullyConnectedTensorProduct(x, one_hot(species)) == species-indexed per-irrep linear
  * (nn/conv.py:59-61,77-79,84-86 called :109,112,123), and e3nn o3.Linear when species == NULL
  * (nn/nodewise.py:111-117, model_factory/tfn_scalar_tensor.py:49-51,68).

@@ -69,7 +69,7 @@ struct GroupEntry {  // 32 x int32, built by matten_amd/plan.py (same record as 
     int w_base;      // first weight column of this entry ([u][c] order)
     int a_tile;      // first 16-column tile of this entry in the pre-split A operand (Args::a_split)
     int n_mt;        // its tile count, ceil(mul * couplings / 16)
-    int reserved[MAXC];
+    int t_off[MAXC];  // conv-fused kernel only: accumulator offset of coupling c in the wave's LDS region (else 0)
     int out_off[MAXC];
 };
 static_assert(sizeof(GroupEntry) == 32 * 4, "GroupEntry layout");
@@ -336,7 +336,8 @@ struct StageLoader {
     }
     __device__ __forceinline__ void publish(int buf) {
 #pragma unroll
-        for (int t = 0; t < TT; ++t) *reinterpret_cast<f32x4*>(st_w + buf * STAGE_FLOATS + 16 * t * STAGE_ROW) = pf[t];
+        for (int t = 0; t < TT; ++t)
+            *reinterpret_cast<f32x4*>(st_w + buf * (16 * TT * STAGE_ROW) + 16 * t * STAGE_ROW) = pf[t];
     }
 };
 
@@ -362,10 +363,59 @@ __device__ __forceinline__ void run_loader_only(const Args& a, int cu_log2, floa
     else run_loader_only_t<1>(a, cu_log2, stage, beg, deg_node, maxdeg);
 }
 
-template <int L1, int GI, int TT>
+// ---- what a unit does with its neighbour sums ------------------------------------------------------------------------
+// StoreAgg: one row slice of agg[N, d_mid] per (node, channel)  (the two-kernel conv: lin2 reads agg afterwards)
+struct StoreAgg {
+    template <class G>
+    __device__ __forceinline__ void store(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
+                                          float a_scale_inv, int node, int j, int u, bool valid) const {
+#ifdef MATTEN_ABLATE_NO_STORE
+        if (valid && acc[0] == 12345.678f) {
+#else
+        if (valid) {
+#endif
+            const float nn = a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node];
+            const float norm = a_scale_inv / sqrtf(nn);
+            float* orow = a.agg + (int64_t)node * a.d_mid;
+#pragma unroll
+            for (int cc = 0; cc < G::NC; ++cc) {
+                if ((ge.mask >> cc) & 1u) {
+                    const int d3 = 2 * G::L3[cc] + 1;
+                    float* op = orow + ge.out_off[cc] + u * d3;
+#pragma unroll
+                    for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
+                        if (k < d3) op[k] = acc[G::OFF[cc] + k] * norm;
+                }
+            }
+        }
+    }
+};
+// StoreLds: the wave's LDS region, [coupling][node j, component k][channel u (8)] -- the operand layout of the lin2
+// stage of tp_lin2_kernel (8 lanes per node).  Every lane writes (idle channels and nodes past the end hold zeros).
+struct StoreLds {
+    float* t;
+    template <class G>
+    __device__ __forceinline__ void store(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
+                                          float a_scale_inv, int node, int j, int u, bool valid) const {
+        float norm = 0.0f;
+        if (valid) norm = a_scale_inv / sqrtf(a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node]);
+#pragma unroll
+        for (int cc = 0; cc < G::NC; ++cc) {
+            if ((ge.mask >> cc) & 1u) {
+                const int d3 = 2 * G::L3[cc] + 1;
+                float* tp = t + 64 * ge.t_off[cc] + j * d3 * 8 + u;
+#pragma unroll
+                for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
+                    if (k < d3) tp[k * 8] = acc[G::OFF[cc] + k] * norm;
+            }
+        }
+    }
+};
+
+template <int L1, int GI, int TT, class Epilogue>
 __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry& ge, float* __restrict__ tile,
                                                  float* __restrict__ stage, int entry, int node, int lane, bool valid,
-                                                 int beg, int deg_node, int maxdeg) {
+                                                 int beg, int deg_node, int maxdeg, const Epilogue& epi) {
     const int deg = valid ? deg_node : 0;
     using G = matten::Group<L1, GI>;
     constexpr int NC = G::NC;
@@ -468,7 +518,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     int buf = 0;
     for (int s0 = 0; s0 < maxdeg; s0 += CH, buf ^= 1) {
         ld.issue(s0 + CH);
-        const float* sb = stage + buf * STAGE_FLOATS;
+        const float* sb = stage + buf * (16 * TT * STAGE_ROW);
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             {
@@ -549,29 +599,11 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         __syncthreads();  // the next stage is published; every wave is done with this chunk's rows
 #endif
     }
-#ifdef MATTEN_ABLATE_NO_STORE
-    if (valid && acc[0] == 12345.678f) {
-#else
-    if (valid) {
-#endif
-        const float nn = a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node];
-        const float norm = a_scale_inv / sqrtf(nn);
-        float* orow = a.agg + (int64_t)node * a.d_mid;
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) {
-            if ((mask >> cc) & 1u) {
-                const int d3 = 2 * G::L3[cc] + 1;
-                float* op = orow + ge.out_off[cc] + u * d3;
-#pragma unroll
-                for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
-                    if (k < d3) op[k] = acc[G::OFF[cc] + k] * norm;
-            }
-        }
-    }
+    epi.template store<G>(a, ge, acc, a_scale_inv, node, j, u, valid);
 }
 
 #define MATTEN_GROUP_CASE_SHARED(L1, GI) \
-    case (L1 * matten::GROUP_KIND_STRIDE + GI): if (nodes_per_wave > 16) run_group_shared<L1, GI, 2>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg); else run_group_shared<L1, GI, 1>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg); break;
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): if (nodes_per_wave > 16) run_group_shared<L1, GI, 2>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); else run_group_shared<L1, GI, 1>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); break;
 
 #define MATTEN_GROUP_CASE(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, node, lane, valid, beg, deg, maxdeg); break;
@@ -643,6 +675,127 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
     switch (ge.kind) {
         TPF_FOR_EACH_GROUP(MATTEN_GROUP_CASE)
         default: break;
+    }
+}
+
+// ---- conv-fused kernel: tensor product + neighbour sum + lin2 of the light input blocks ---------------------------------
+// (reference nn/conv.py:113-123: tp -> scatter -> / sqrt(avg) -> lin2(., species) + self-connection)
+//
+// agg[N, d_mid] exists only to carry the neighbour sums from the tensor-product kernel to lin2: 1.07 GB written and
+// read back per launch in the last layer, three quarters of it from the l1 <= 1 input blocks (32 and 16 channels).
+// Here a workgroup owns LIN2_NODES = 8 destination nodes and walks those blocks' group entries itself, four at a time
+// (a ROUND: one entry per wave, 8 lanes per node, the workgroup-shared stage of run_group_shared).  After a round the
+// waves leave their sums in LDS (StoreLds) and the workgroup applies lin2 to them on the spot:
+//     out[n, io, v, k] += fan^-1/2 sum_{paths p -> io} sum_u W_p[u, species(n), v] * acc_p[n, u, k]
+// A SLOT is 8 consecutive (v, k) pairs of one output irrep; the 8 lanes of a node take one pair each and run the
+// slot's CHAIN (every (wave, coupling) of the round that feeds the irrep) as 8-channel dot products: one 16-byte
+// global load of the node's species' weights (L2 resident: 27 KB per species) + one ds_read_b128 per 4 FMAs.  The
+// weights are per NODE, so nodes need no species sorting (the x[src] gathers keep their crystal locality) and a slot
+// belongs to one wave: the accumulation order into the output tile is fixed.  The tile starts as the self-connection
+// and leaves as out[8, d_out]; the heavy blocks (l1 >= 2: 2-4 channels, a quarter of agg) keep the agg_rest + lin2 route.
+// Host tables: plan.plan_conv_fused.
+constexpr int LIN2_NODES = 8;
+constexpr int LIN2_T_WAVE_FLOATS = 64 * 28;   // == plan.LIN2_T_WAVE_FLOATS
+constexpr int LIN2_STAGE_FLOATS = 2 * 16 * STAGE_ROW;
+
+struct Lin2Args {
+    const int* rounds;        // [n_rounds, 4] entry or -1
+    const int* slot_index;    // [n_rounds, 4, 2]
+    const int4* slots;        // [n_slots, 2] {chain_begin, chain_len, d3, n_pairs} {out_off, pair_base, magic, 0}
+    const int2* chain;        // [n_chain] {t_off, a_off}
+    const float* atab;        // [n_species, a_numel]
+    const int* species;       // [N]
+    const float* add;         // [N, add_ld] or NULL
+    float* out;               // [N, d_out]
+    int n_rounds, a_numel, n_species, add_ld, d_out, ld, n_groups;
+};
+
+#define MATTEN_LIN2_CASE(L1, GI) \
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI, 1>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreLds{tile}); break;
+
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_lin2_kernel(Args a, Lin2Args la,
+                                                                                      const GroupEntry* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // 8 consecutive groups = one 64-node tile, pinned to an XCD like tp_fused_kernel's tiles
+    const int xcd = blockIdx.x % N_XCD;
+    const int q8 = blockIdx.x / N_XCD;
+    const int grp = ((q8 >> 3) * N_XCD + xcd) * 8 + (q8 & 7);
+    if (grp >= la.n_groups) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    float* tarea = lds;                                        // [4][LIN2_T_WAVE_FLOATS]: weight tile during a walk, sums after
+    float* tile = tarea + wave * LIN2_T_WAVE_FLOATS;
+    float* stage = lds + WAVES_PER_BLOCK * LIN2_T_WAVE_FLOATS;  // [2][16][STAGE_ROW]
+    float* otile = stage + LIN2_STAGE_FLOATS;                    // [8][ld]
+
+    const int j = lane >> 3, q = lane & 7;
+    const int node = grp * LIN2_NODES + j;
+    const bool in_range = node < a.n_nodes;
+    int beg = 0, deg = 0;
+    if (in_range) {
+        beg = a.rowptr[node];
+        deg = a.rowptr[node + 1] - beg;
+    }
+    int maxdeg = deg;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+
+    // output tile <- self-connection (or zero)
+    for (int i = threadIdx.x; i < LIN2_NODES * la.d_out; i += WAVES_PER_BLOCK * 64) {
+        const int jj = i / la.d_out, col = i - jj * la.d_out;
+        const int nn = grp * LIN2_NODES + jj;
+        otile[jj * la.ld + col] = (la.add && nn < a.n_nodes) ? la.add[(int64_t)nn * la.add_ld + col] : 0.0f;
+    }
+    int sp = in_range ? la.species[node] : 0;
+    sp = min(max(sp, 0), la.n_species - 1);
+    const float* arow = la.atab + (int64_t)sp * la.a_numel;
+
+    for (int r = 0; r < la.n_rounds; ++r) {
+        const int e = __builtin_amdgcn_readfirstlane(la.rounds[r * WAVES_PER_BLOCK + wave]);
+        if (e < 0) {
+            run_loader_only_t<1>(a, 3, stage, beg, deg, maxdeg);
+        } else {
+            const GroupEntry& ge = entries[e];
+            const bool valid = in_range && (q < ge.mul);
+            switch (ge.kind) {
+                MATTEN_LIN2_CASE(0, 0)
+                MATTEN_LIN2_CASE(1, 0)
+                MATTEN_LIN2_CASE(1, 1)
+                default: break;
+            }
+        }
+        __syncthreads();  // every wave's sums are in LDS (and, in round 0, the output tile is initialised)
+        const int s_beg = __builtin_amdgcn_readfirstlane(la.slot_index[(r * WAVES_PER_BLOCK + wave) * 2]);
+        const int s_cnt = __builtin_amdgcn_readfirstlane(la.slot_index[(r * WAVES_PER_BLOCK + wave) * 2 + 1]);
+        for (int si = s_beg; si < s_beg + s_cnt; ++si) {
+            const int4 s0 = la.slots[2 * si], s1 = la.slots[2 * si + 1];
+            const int d3 = s0.z, n_pairs = s0.w;
+            const int idx = s1.y + q;
+            const bool act = idx < n_pairs;
+            const int idc = act ? idx : n_pairs - 1;     // clamped: the loads below stay unconditional
+            const int v = (idc * s1.z) >> 16, k = idc - v * d3;
+            const float* ap = arow + v * 8;
+            const float* tp = tarea + (j * d3 + k) * 8;
+            float sum0 = 0.0f, sum1 = 0.0f;
+            for (int ci = 0; ci < s0.y; ++ci) {
+                const int2 ch = la.chain[s0.x + ci];
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + ch.y);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap + ch.y + 4);
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp + ch.x);
+                const f32x4 t1 = *reinterpret_cast<const f32x4*>(tp + ch.x + 4);
+                sum0 = fmaf(a0[0], t0[0], sum0); sum1 = fmaf(a1[0], t1[0], sum1);
+                sum0 = fmaf(a0[1], t0[1], sum0); sum1 = fmaf(a1[1], t1[1], sum1);
+                sum0 = fmaf(a0[2], t0[2], sum0); sum1 = fmaf(a1[2], t1[2], sum1);
+                sum0 = fmaf(a0[3], t0[3], sum0); sum1 = fmaf(a1[3], t1[3], sum1);
+            }
+            if (act) otile[j * la.ld + s1.x + idx] += sum0 + sum1;
+        }
+        __syncthreads();  // the sums are consumed: the next round may overwrite the regions
+    }
+    for (int i = threadIdx.x; i < LIN2_NODES * la.d_out; i += WAVES_PER_BLOCK * 64) {
+        const int jj = i / la.d_out, col = i - jj * la.d_out;
+        const int nn = grp * LIN2_NODES + jj;
+        if (nn < a.n_nodes) la.out[(int64_t)nn * la.d_out + col] = otile[jj * la.ld + col];
     }
 }
 
@@ -793,6 +946,46 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
     if (grid >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
     tp_fused_kernel<<<(unsigned)grid, WAVES_PER_BLOCK * 64, lds, stream>>>(
         a, (const GroupEntry*)group_entries, unit_map, (int)n_entries, (int)units_per_tile, blocks_per_tile, n_tiles);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_tp_lin2_group_nodes(void) { return LIN2_NODES; }
+extern "C" int matten_tp_lin2_t_wave_floats(void) { return LIN2_T_WAVE_FLOATS; }
+
+extern "C" int matten_tp_lin2(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
+                              const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr,
+                              const int32_t* src_sorted, int64_t n_nodes, const int32_t* light_entries,
+                              int64_t n_entries, const int32_t* rounds, int64_t n_rounds, const int32_t* slot_index,
+                              const int32_t* slots, int64_t n_slots, const int32_t* chain, int64_t n_chain,
+                              const float* atab, int64_t a_numel, int64_t n_species, const int32_t* species,
+                              float avg_num_neighbors, const float* num_neigh, const uint16_t* a_split,
+                              const float* a_scale_inv, const float* add, int64_t add_ld, int64_t d_out, float* out,
+                              matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_nodes < 0 || d_in <= 0 || w_pad <= 0 || sh_stride < 32 || (sh_stride & 3) || n_entries <= 0 || n_rounds <= 0 ||
+        n_slots < 0 || n_chain < 0 || a_numel <= 0 || (a_numel & 7) || n_species <= 0 || d_out <= 0)
+        return MATTEN_EINVAL;
+    if (n_nodes == 0) return MATTEN_OK;
+    if (!x || !h2s || !w2p || !sh_sorted || !rowptr || !src_sorted || !light_entries || !rounds || !slot_index ||
+        !slots || !chain || !atab || !species || !a_split || !a_scale_inv || !out)
+        return MATTEN_EINVAL;
+    if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
+    if (add && add_ld < d_out) return MATTEN_EINVAL;
+    const int ld = (int)((d_out + 23) / 32 * 32 + 8);   // row stride of the output tile: == 8 mod 32 (bank spread)
+    const size_t lds = sizeof(float) * ((size_t)WAVES_PER_BLOCK * LIN2_T_WAVE_FLOATS + LIN2_STAGE_FLOATS +
+                                        (size_t)LIN2_NODES * ld);
+    if (lds > 64 * 1024) return MATTEN_EINVAL;
+    Args a{x, (const _Float16*)h2s, w2p, (const _Float16*)a_split, a_scale_inv, sh_sorted, rowptr, src_sorted, num_neigh,
+           nullptr, (int)d_in, (int)w_pad, (int)sh_stride, 0, (int)n_nodes, LIN2_T_WAVE_FLOATS, avg_num_neighbors};
+    const int n_groups = (int)matten_cdiv(n_nodes, LIN2_NODES);
+    Lin2Args la{rounds, slot_index, (const int4*)slots, (const int2*)chain, atab, species, add, out,
+                (int)n_rounds, (int)a_numel, (int)n_species, (int)add_ld, (int)d_out, ld, n_groups};
+    // groups are numbered tile-major (8 per 64-node tile); the grid covers whole sets of N_XCD tiles
+    const int64_t n_tiles = matten_cdiv(n_groups, 8);
+    const int64_t grid = matten_cdiv(n_tiles, N_XCD) * N_XCD * 8;
+    if (grid >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+    tp_lin2_kernel<<<(unsigned)grid, WAVES_PER_BLOCK * 64, lds, stream>>>(a, la, (const GroupEntry*)light_entries);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

@@ -39,4 +39,5 @@ AMD_SRC = "_amd_src_sorted"       # [E] i32
 AMD_GEOM = "_amd_geom_sorted"     # [E,4] f32 (vx,vy,vz,|v|)
 AMD_SH = "_amd_sh_sorted"         # [E,(lmax+1)^2] f32
 AMD_SPECIES = "_amd_species_order"  # (order[N] i32 nodes sorted by species, seg[S+1] i32)
+AMD_SPECIES_I32 = "_amd_species_i32"  # [N] i32 species index per node (the conv-fused kernel's per-node weight row)
 AMD_RBF = "_amd_rbf_params"       # [3] f64 cpu tensor (num_basis, start, end)

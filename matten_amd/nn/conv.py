@@ -53,6 +53,23 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         self.irreps_out[DataKey.NODE_FEATURES] = conv_layer_irreps
         self._lin1_sc = None  # built at first inference forward
         self._lin1_sc_packed = DerivedWeight(self._pack_lin1_sc)
+        # conv-fused inference path (matten_tp_lin2): the light input blocks' tensor product, neighbour sum and lin2 in
+        # one kernel; None when the layer has no such block or the variant is not the fused one
+        from .. import plan as _plan
+        self.fused_plan = (_plan.plan_conv_fused(self.tp.plan, n_species, conv_layer_irreps)
+                           if self.tp.impl == "fused" else None)
+        if self.fused_plan is not None:
+            fp = self.fused_plan
+            self._fused_tables = DeviceTables(
+                light=fp.light_entries, rounds=fp.rounds, slot_index=fp.slot_index, slots=fp.slots, chain=fp.chain,
+                a_base=fp.a_base, a_stride=fp.a_stride, a_scale=fp.a_scale, light_ids=fp.light_ids,
+                heavy_ids=fp.heavy_ids, heavy=fp.heavy_entries, heavy_umap=fp.heavy_unit_map,
+                **({"rest_gather": fp.rest.gather, "rest_scale": fp.rest.scale,
+                    **{f"rest_meta{i}": m for i, m in enumerate(fp.rest.passes)}} if fp.rest is not None else {}),
+            )
+            self._fused_atab = DerivedWeight(self._build_atab)
+            self._fused_rest_w = DerivedWeight(self._pack_rest)
+            self._fused_split = DerivedWeight(self._split_by_role)
 
     def _pack_lin1_sc(self, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
         return torch.cat([self.lin1._pack(w1), self.sc._pack(w2)], dim=1).contiguous()
@@ -74,6 +91,51 @@ class PointConv(ModuleIrreps, torch.nn.Module):
                 self._lin1_sc = DeviceTables(meta=segs)
         return self._lin1_sc
 
+    # ---- derived tensors of the conv-fused path (rebuilt when the parameters change) ----
+    def _build_atab(self, w: torch.Tensor) -> torch.Tensor:
+        """lin2.weight (flat, reference layout) -> [S, a_numel] table of matten_tp_lin2"""
+        t, dev = self._fused_tables, w.device
+        base, stride, scale = t.get("a_base", dev), t.get("a_stride", dev), t.get("a_scale", dev)
+        s = torch.arange(self.lin2.n_species, device=dev, dtype=torch.int64)[:, None]
+        idx = base.clamp(min=0)[None, :] + s * stride[None, :]
+        return torch.where(base[None, :] >= 0, w[idx] * scale[None, :], w.new_zeros(())).contiguous()
+
+    def _pack_rest(self, w: torch.Tensor) -> torch.Tensor:
+        t, dev = self._fused_tables, w.device
+        return (w[t.get("rest_gather", dev)] * t.get("rest_scale", dev)).contiguous()
+
+    def _split_by_role(self, frag: torch.Tensor, scale_inv: torch.Tensor):
+        """per-entry power-of-two scales of the A fragments, re-indexed for the light and the heavy entry lists"""
+        t, dev = self._fused_tables, frag.device
+        return scale_inv[t.get("light_ids", dev)].contiguous(), scale_inv[t.get("heavy_ids", dev)].contiguous()
+
+    def _forward_fused(self, x1, self_connection, species, data):
+        """out = lin2(agg) + self_connection without the light three quarters of agg ever reaching memory"""
+        fp, t, dev = self.fused_plan, self._fused_tables, x1.device
+        tp = self.tp
+        nb, r0, r1 = data[DataKey.AMD_RBF].tolist()
+        avg = self.avg_num_neighbors if self.avg_num_neighbors is not None else 0.0
+        num_neigh = None if self.avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
+        h2p, w2p = tp.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1)
+        frag, scale_inv = tp._a_split.get(w2p)
+        inv_light, inv_heavy = self._fused_split.get(frag, scale_inv)
+        out = ops.tp_lin2(
+            x1, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC], t.get("light", dev),
+            t.get("rounds", dev), t.get("slot_index", dev), t.get("slots", dev), t.get("chain", dev),
+            self._fused_atab.get(self.lin2.weight), data[DataKey.AMD_SPECIES_I32], avg, num_neigh, (frag, inv_light),
+            self_connection, fp.d_out,
+        )
+        if fp.rest is None:
+            return out
+        agg_rest = ops.tp_fused(
+            x1, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC], t.get("heavy", dev),
+            t.get("heavy_umap", dev), len(fp.heavy_unit_map), tp.plan.fused_lds_floats_per_wave, fp.d_rest, avg,
+            num_neigh, a_split=(frag, inv_heavy),
+        )
+        metas = [t.get(f"rest_meta{i}", dev) for i in range(len(fp.rest.passes))]
+        return ops.species_linear(agg_rest, species, self._fused_rest_w.get(self.lin2.weight), fp.rest.w_stride, metas,
+                                  fp.d_out, add=out, fully_covered=True)
+
     def forward(self, data: DataKey.Type) -> DataKey.Type:
         x = data[DataKey.NODE_FEATURES]
         species = data[DataKey.AMD_SPECIES]
@@ -87,6 +149,10 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         else:
             self_connection = self.sc(x, species)
             x1 = self.lin1(x, species)
+        if (self.fused_plan is not None and DataKey.AMD_SPECIES_I32 in data
+                and not _ag.needs_grad(x1, self_connection, self.lin2.weight, *self.tp.weight_nn.parameters())):
+            data[DataKey.NODE_FEATURES] = self._forward_fused(x1, self_connection, species, data)
+            return data
         agg = self.tp(x1, data, self.avg_num_neighbors)
         data[DataKey.NODE_FEATURES] = self.lin2(agg, species, add=self_connection)
         return data

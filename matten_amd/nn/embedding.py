@@ -134,6 +134,7 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
         # nodes grouped by species (stable): the species-indexed linears walk this order
         order, seg, _ = ops.group_by_key(sidx.clamp(min=0), S)
         data[DataKey.AMD_SPECIES] = (order, seg)
+        data[DataKey.AMD_SPECIES_I32] = s32
         if attrs is not None:
             data[DataKey.NODE_ATTRS] = attrs
         if torch.is_grad_enabled() and self.linear.weight.requires_grad:

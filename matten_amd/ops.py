@@ -347,6 +347,41 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
     return agg
 
 
+def tp_lin2(x, h2p, w2p, sh_sorted, rowptr, src_sorted, light_entries, rounds, slot_index, slots, chain, atab, species_i32,
+            avg_num_neighbors: float, num_neigh, a_split, add, d_out: int) -> torch.Tensor:
+    """out[N, d_out] = add + lin2(neighbour sums of the light group entries)  (include/matten_hip.h matten_tp_lin2;
+    tables from plan.plan_conv_fused).  a_split = (fragments, scale_inv per LIGHT entry)."""
+    lib = _lib.load()
+    from .plan import LIN2_GROUP_NODES, LIN2_T_WAVE_FLOATS
+
+    if lib.matten_tp_lin2_group_nodes() != LIN2_GROUP_NODES or lib.matten_tp_lin2_t_wave_floats() != LIN2_T_WAVE_FLOATS:
+        raise _lib.MattenHipError("plan.LIN2_* constants do not match the library")
+    x = _need_rows(x, torch.float32, "node_features")
+    h2p = _need(h2p, torch.float16, "h2s")
+    w2p = _need(w2p, torch.float32, "w2p")
+    sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
+    atab = _need(atab, torch.float32, "atab")
+    species_i32 = _need(species_i32, torch.int32, "species")
+    N, d_in = x.shape[0], x.stride(0)
+    if num_neigh is not None:
+        num_neigh = _need(num_neigh, torch.float32, "num_neigh")
+    frag, scale_inv = _need(a_split[0], torch.float16, "a_split"), _need(a_split[1], torch.float32, "a_scale_inv")
+    if scale_inv.numel() != light_entries.shape[0]:
+        raise ValueError("a_scale_inv needs one value per light entry")
+    if add is not None:
+        add = _need_rows(add, torch.float32, "add")
+    out = torch.empty(N, d_out, dtype=torch.float32, device=x.device)
+    with _timed(f"tp_lin2/d_out={d_out}"):
+        rc = lib.matten_tp_lin2(_ptr(x), d_in, _ptr(h2p), _ptr(w2p), w2p.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
+                                _ptr(rowptr), _ptr(src_sorted), N, _ptr(light_entries), light_entries.shape[0],
+                                _ptr(rounds), rounds.shape[0], _ptr(slot_index), _ptr(slots), slots.shape[0],
+                                _ptr(chain), chain.shape[0], _ptr(atab), atab.shape[1], atab.shape[0], _ptr(species_i32),
+                                float(avg_num_neighbors or 0.0), _ptr(num_neigh), _ptr(frag), _ptr(scale_inv), _ptr(add),
+                                add.stride(0) if add is not None else d_out, d_out, _ptr(out), _stream())
+    _lib.check(rc, "matten_tp_lin2")
+    return out
+
+
 _SL_ROWS_LDS_BYTES = 52 * 1024  # three workgroups of matten_species_linear_rows per CU
 
 

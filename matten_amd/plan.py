@@ -596,6 +596,8 @@ class ConvFusedPlan:
     d_rest: int                    # row width of agg_rest
     rest: Optional[LinearPlan]     # lin2 restricted to the heavy paths; gather / scale index the FULL lin2 weight
     d_out: int
+    light_ids: np.ndarray = None   # int64: index of each light / heavy entry in UVUPlan.group_entries
+    heavy_ids: np.ndarray = None
 
 
 def _div_magic(d: int) -> int:
@@ -782,4 +784,5 @@ def plan_conv_fused(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[ConvFu
         heavy_entries=np.ascontiguousarray(heavy_entries).astype(np.int32),
         heavy_unit_map=fused_unit_map(heavy_entries) if heavy_ids else np.zeros(0, dtype=np.int32),
         d_rest=d_rest, rest=rest, d_out=irreps_out.dim,
+        light_ids=np.array(light_ids, dtype=np.int64), heavy_ids=np.array(heavy_ids, dtype=np.int64),
     )

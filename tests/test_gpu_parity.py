@@ -652,3 +652,39 @@ def test_neighbor_list_slabs_match_single_launch(monkeypatch):
     assert set(got) == set(want)
     for k in want:
         assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), k
+
+
+def test_conv_fused_kernel_matches_two_kernel_path(monkeypatch):
+    """matten_tp_lin2 (tensor product + neighbour sum + lin2 of the light input blocks in one kernel, heavy blocks through
+    the compact agg_rest) against the two-kernel conv (full agg + lin2) and the oracle, layer by layer: mixed species in
+    every 8-node group, a node count that is not a multiple of 8, per-node neighbour normalisation, and an isolated atom."""
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import collate, crystal_graph
+
+    lone = crystal_graph(np.array([[0.0, 0, 0], [1.5, 0, 0], [6.0, 6.0, 6.0]]), 12.0 * np.eye(3), [29, 79, 29], 5.0)
+    lone_pair = crystal_graph(np.array([[0.0, 0, 0], [1.5, 0, 0], [2.5, 1.0, 0]]), 12.0 * np.eye(3), [29, 79, 29], 5.0)
+    for avg in (18.0, None):
+        # per-node normalisation divides by sqrt(num_neigh): 0 / 0 for the isolated atom in the reference too, so that
+        # case only goes with the fixed normalisation
+        graphs = synthetic.fcc64_graphs(2) + ([lone] if avg else [lone_pair])
+        ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": avg}
+        hp = dict(PAPER, average_num_neighbors="auto" if avg else None)
+        ref, fused = build_pair(hp, ds, randomize_bn=True)
+        monkeypatch.setenv("MATTEN_CONV_FUSED", "0")
+        _, plain = build_pair(hp, ds, randomize_bn=True)
+        monkeypatch.delenv("MATTEN_CONV_FUSED")
+        convs = [m for m in fused.backbone.modules() if type(m).__name__ == "PointConv"]
+        assert all(m.fused_plan is not None for m in convs) and len(convs) == 4
+        assert all(m.fused_plan is None for m in plain.backbone.modules() if type(m).__name__ == "PointConv")
+        plain.load_state_dict(fused.state_dict())
+        cpu, a, b = collate(graphs), collate(graphs, device=DEV), collate(graphs, device=DEV)
+        with torch.no_grad():
+            for (name, rmod), (_, fmod), (_, pmod) in zip(ref.backbone.named_children(), fused.backbone.named_children(),
+                                                          plain.backbone.named_children()):
+                cpu, a, b = rmod(cpu), fmod(a), pmod(b)
+                if "node_features" in cpu:
+                    close(a["node_features"], b["node_features"], 2e-5, f"{name}: fused vs two-kernel")
+                    close(a["node_features"], cpu["node_features"], RTOL, f"{name}: fused vs oracle")
+            # run twice: the accumulation order is fixed
+            again = fused.backbone(collate(graphs, device=DEV))["my_model_output"]
+            assert torch.equal(again, a["my_model_output"])
