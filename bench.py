@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -167,59 +168,99 @@ def main():
         # conv layer and step) -- the same average rocprofv3 --stats reports for the kernel ----
         deg = n_edges / n_nodes
         per_kernel = {k: sum(v) / len(v) for k, v in kernel_ms.items()}
-        tp_plans = [m.tp.plan for m in model.backbone.modules() if hasattr(m, "tp") and hasattr(m.tp, "plan")]
-        tp_keys = [f"tp_scatter/d_mid={p.d_mid}" for p in tp_plans]
-        if tp_plans and all(k in per_kernel for k in tp_keys):
-            layer_bytes = [algorithmic_bytes_tp_kernel(p, deg) * n_edges for p in tp_plans]
-            layer_ms = [per_kernel[k] for k in tp_keys]
-            bytes_per_launch = sum(layer_bytes) / len(layer_bytes)
-            avg_ms = sum(layer_ms) / len(layer_ms)
+        convs = [m for m in model.backbone.modules() if type(m).__name__ == "PointConv"]
+
+        def contract_bytes(plan, cols, d_in_part, d_mid_part):
+            """SURVEY 8d per-edge algorithmic bytes of a tensor-product launch restricted to a set of input blocks:
+            edge ids (8) + edge vector (12) + their radial weights read once (4 per column) + node rows over the degree"""
+            return (8.0 + 12.0 + 4.0 * cols + 4.0 * (d_in_part + d_mid_part) / deg) * n_edges
+
+        layers = []
+        for m in convs:
+            p, fp = m.tp.plan, m.fused_plan
+            ent = np.asarray(p.group_entries).reshape(-1, 32)
+            cols = lambda ids: float(sum(int(ent[e][2]) * len(p.group_entry_paths[e]) for e in ids))
+
+            def blocks(ids):  # floats of the input blocks a set of entries reads
+                seen = {}
+                for e in ids:
+                    pth = p.paths[next(iter(p.group_entry_paths[e].values()))]
+                    seen[pth.i_in1] = pth.mul * (2 * pth.l1 + 1)
+                return float(sum(seen.values()))
+
+            if fp is not None:
+                lk = f"tp_lin2/d_out={fp.d_out}/d_in={p.d_in}"
+                hk = f"tp_scatter/d_mid={fp.d_rest}/d_in={p.d_in}"
+                rec = {"d_mid": p.d_mid, "weight_numel": p.weight_numel, "light_ms": per_kernel.get(lk),
+                       "heavy_ms": per_kernel.get(hk, 0.0) if fp.rest is not None else 0.0,
+                       "light_bytes": contract_bytes(p, cols(fp.light_ids), blocks(fp.light_ids), p.d_mid - fp.d_rest),
+                       "heavy_bytes": contract_bytes(p, cols(fp.heavy_ids), blocks(fp.heavy_ids), fp.d_rest)
+                       if fp.rest is not None else 0.0}
+            else:
+                k = f"tp_scatter/d_mid={p.d_mid}/d_in={p.d_in}"
+                rec = {"d_mid": p.d_mid, "weight_numel": p.weight_numel, "light_ms": None, "heavy_ms": per_kernel.get(k),
+                       "light_bytes": 0.0, "heavy_bytes": contract_bytes(p, p.weight_numel, p.d_in, p.d_mid)}
+            rec["ms"] = (rec["light_ms"] or 0.0) + (rec["heavy_ms"] or 0.0)
+            rec["algorithmic_bytes"] = algorithmic_bytes_tp_kernel(p, deg) * n_edges
+            rec["achieved_GBps"] = rec["algorithmic_bytes"] / (rec["ms"] * 1e-3) / 1e9 if rec["ms"] else None
+            layers.append(rec)
+        light = [r for r in layers if r["light_ms"]]
+        avg_ms = None
+        # dominant kernel, averaged over its launches of the timed region like rocprofv3 --stats does: tp_fused_kernel
+        # (default), or tp_lin2_kernel when the opt-in conv-fused variant is on (MATTEN_CONV_FUSED=1)
+        dom = [(r["light_ms"], r["light_bytes"]) for r in light] if light else \
+              [(r["heavy_ms"], r["heavy_bytes"]) for r in layers if r["heavy_ms"]]
+        dom_name = "tp_lin2_kernel" if light else "tp_fused_kernel"
+        if dom:
+            bytes_per_launch = sum(b for _, b in dom) / len(dom)
+            avg_ms = sum(m for m, _ in dom) / len(dom)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = _pmc_traffic("tp_fused_kernel")
+            traffic = _pmc_traffic(dom_name)
             result["roofline"] = {
-                "kernel": f"tp_fused_kernel (radial GEMM + CG paths + neighbour sum; mean over its {len(tp_plans)} launches "
-                          "per forward, one per conv layer)",
+                "kernel": f"{dom_name} (last radial-MLP layer on MFMA + CG paths + neighbour sum"
+                          f"{' + lin2 of the l1<=1 input blocks' if light else ''}; mean over its {len(dom)} launches per "
+                          "forward, one per conv layer)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK / 1e9),
                 "traffic": traffic,
-                # `achieved` / `frac` price the CONTRACT bytes (SURVEY 8d two-kernel architecture: they include 4 W
-                # bytes per edge for a w[E,W] this kernel never materialises).  What the memory system really moves:
+                # `achieved` / `frac` price the CONTRACT bytes of the launch (SURVEY 8d two-kernel architecture restricted
+                # to the input blocks this kernel takes: radial weights w[E, W] and agg[N, d_mid] that never exist here).
+                # What the memory system really moves:
                 "measured_GBps": None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9,
                 "measured_frac": None if traffic is None else traffic / (avg_ms * 1e-3) / HBM_PEAK,
                 "physical_bound": "fp32 VALU issue at 3 waves/SIMD (DESIGN.md section 4); HBM is the bound of the "
                                   "contract figure only",
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms,
-                "per_layer": [
-                    {"d_mid": p.d_mid, "weight_numel": p.weight_numel, "ms": ms, "algorithmic_bytes": by,
-                     "achieved_GBps": by / (ms * 1e-3) / 1e9}
-                    for p, ms, by in zip(tp_plans, layer_ms, layer_bytes)
-                ],
-                "last_layer_traffic": _pmc_traffic("tp_fused_kernel", "hbm_bytes_per_launch"),
+                "per_layer": layers,
+                "edge_work_per_layer": "heavy_ms = tp_fused_kernel; light_ms = tp_lin2_kernel (only with MATTEN_CONV_FUSED=1, "
+                                       "then heavy_ms covers the l1>=2 blocks only); algorithmic_bytes / achieved_GBps = "
+                                       "the whole layer's contract bytes over both",
             }
         result["kernel_ms_per_launch"] = per_kernel
         # ---- matrix-core use of the radial MLP (the only GEMM of the path): hidden layers nb -> 32 -> 32 in
-        # radial_hidden_kernel (fp32 MFMA), last layer 32 -> W inside tp_fused_kernel (three fp16-split products) ----
-        if tp_plans and "radial_hidden" in per_kernel:
+        # radial_hidden_kernel (fp32 MFMA), last layer 32 -> W inside the tensor-product kernels (three fp16-split products) ----
+        if layers and "radial_hidden" in per_kernel:
             nb = int(PAPER_HPARAMS.get("num_radial_basis", 8))
             hid_flops = 2.0 * (nb * 32 + 32 * 32) * n_edges
             hid_ms = per_kernel["radial_hidden"]
-            last_flops = [2.0 * 32 * p.weight_numel * n_edges for p in tp_plans]
+            last_flops = [2.0 * 32 * r["weight_numel"] * n_edges for r in layers]
+            tp_ms = sum(r["ms"] for r in layers) / len(layers)
             result["mfma"] = {
                 "radial_hidden_kernel": {
                     "flops_per_launch": hid_flops, "avg_launch_ms": hid_ms,
                     "achieved_TFLOPs": hid_flops / (hid_ms * 1e-3) / 1e12, "peak_TFLOPs": MFMA_F32_PEAK / 1e12,
                     "frac": hid_flops / (hid_ms * 1e-3) / MFMA_F32_PEAK, "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
                 },
-                "last_layer_in_tp_fused": {
-                    "algorithmic_flops_per_launch": sum(last_flops) / len(last_flops),
-                    "issued_f16_flops_per_launch": 3.0 * sum(last_flops) / len(last_flops),
-                    "note": "evaluated as hi.hi + 2^-11 (hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16 inside the kernel the "
-                            "HBM roofline above prices; matrix-pipe busy fraction from PMC in DESIGN.md section 4",
-                    "f16_TFLOPs_over_kernel_time": 3.0 * sum(last_flops) / len(last_flops) / (avg_ms * 1e-3) / 1e12,
+                "last_layer_in_tp_kernels": {
+                    "algorithmic_flops_per_layer": sum(last_flops) / len(last_flops),
+                    "issued_f16_flops_per_layer": 3.0 * sum(last_flops) / len(last_flops),
+                    "note": "evaluated as hi.hi + 2^-11 (hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16 inside tp_lin2_kernel / "
+                            "tp_fused_kernel; matrix-pipe busy fraction from PMC in DESIGN.md section 4",
+                    "f16_TFLOPs_over_kernel_time": 3.0 * sum(last_flops) / len(last_flops) / (tp_ms * 1e-3) / 1e12,
                     "peak_f16_TFLOPs": MFMA_F16_PEAK / 1e12,
                 },
             }

@@ -194,11 +194,13 @@ int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const flo
  *   light_entries[n, 32]     : group entries as matten_tp_fused; words 8..19 = accumulator offset of coupling c in
  *                              the wave's LDS region (present couplings packed)
  *   slot_index[n_rounds,4,2] : (first slot, count) of (round, wave)
- *   slots[n_slots, 8]        : {chain_begin, chain_len, d3, n_pairs = mul_out * d3, out_off, pair_base, magic, 0}: the
- *                              8 lanes of a node take the (v, k) pairs pair_base .. pair_base+7 of the output irrep at
- *                              out_off (v = (pair * magic) >> 16 = pair / d3)
- *   chain[n_chain, 2]        : {float offset of a (wave, coupling) block in the LDS area, float offset of the matching
- *                              [mul_out][8] weight block in a species' row of atab}
+ *   slots[n_slots, 8]        : {d3, n_pairs = mul_out * d3, out_off, pair_base, magic, first item, item count, 0}: a SLOT is
+ *                              8 consecutive (v, k) pairs of the output irrep at out_off; the 8 lanes of a node take
+ *                              the pairs pair_base .. pair_base+7 (v = (pair * magic) >> 16 = pair / d3)
+ *   items[n_items, 4]        : {t_off, a_off, n_chunks <= 4, a_stride}: the channel chunks of one path that feeds the
+ *                              slot's irrep: chunk c = the [node, k][channel 8] block at float offset
+ *                              t_off + c * t_wave_floats of the LDS area (consecutive waves) times the [mul_out][8]
+ *                              weight block at float offset a_off + c * a_stride of a species' row of atab
  *   atab[n_species, a_numel] : lin2 weights W[u, s, v] * fan_in^-1/2 in that layout (zero for channels past the entry)
  *   species[N] int32, add[N, add_ld] (self-connection) or NULL, out[N, d_out] = add + lin2(light blocks)
  * a_split / a_scale_inv as matten_tp_fused (required here), a_scale_inv indexed like light_entries.
@@ -211,7 +213,7 @@ int matten_tp_lin2(const float* x, int64_t d_in, const uint16_t* h2s, const floa
                    const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
                    int64_t n_nodes, const int32_t* light_entries, int64_t n_entries, const int32_t* rounds,
                    int64_t n_rounds, const int32_t* slot_index, const int32_t* slots, int64_t n_slots,
-                   const int32_t* chain, int64_t n_chain, const float* atab, int64_t a_numel, int64_t n_species,
+                   const int32_t* items, int64_t n_items, const float* atab, int64_t a_numel, int64_t n_species,
                    const int32_t* species, float avg_num_neighbors, const float* num_neigh, const uint16_t* a_split,
                    const float* a_scale_inv, const float* add, int64_t add_ld, int64_t d_out, float* out,
                    matten_stream_t stream);

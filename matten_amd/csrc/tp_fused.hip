@@ -697,17 +697,20 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
 constexpr int LIN2_NODES = 8;
 constexpr int LIN2_T_WAVE_FLOATS = 64 * 28;   // == plan.LIN2_T_WAVE_FLOATS
 constexpr int LIN2_STAGE_FLOATS = 2 * 16 * STAGE_ROW;
+#ifndef LIN2_NB
+#define LIN2_NB 8
+#endif
 
 struct Lin2Args {
     const int* rounds;        // [n_rounds, 4] entry or -1
-    const int* slot_index;    // [n_rounds, 4, 2]
-    const int4* slots;        // [n_slots, 2] {chain_begin, chain_len, d3, n_pairs} {out_off, pair_base, magic, 0}
-    const int2* chain;        // [n_chain] {t_off, a_off}
+    const int* slot_index;    // [n_rounds, 4, 2] (first slot, count) of (round, wave)
+    const int4* slots;        // [n_slots, 2] {d3, n_pairs, out_off, pair_base} {magic, first item, item count, 0}
+    const int4* items;        // [n_items] {t_off, a_off, n_chunks, a_stride}
     const float* atab;        // [n_species, a_numel]
     const int* species;       // [N]
     const float* add;         // [N, add_ld] or NULL
     float* out;               // [N, d_out]
-    int n_rounds, a_numel, n_species, add_ld, d_out, ld, n_groups;
+    int n_rounds, n_slots, n_items, a_numel, n_species, add_ld, d_out, ld, n_groups;
 };
 
 #define MATTEN_LIN2_CASE(L1, GI) \
@@ -727,6 +730,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_lin2_
     float* tile = tarea + wave * LIN2_T_WAVE_FLOATS;
     float* stage = lds + WAVES_PER_BLOCK * LIN2_T_WAVE_FLOATS;  // [2][16][STAGE_ROW]
     float* otile = stage + LIN2_STAGE_FLOATS;                    // [8][ld]
+    int4* slots = reinterpret_cast<int4*>(otile + LIN2_NODES * la.ld);  // [n_slots][2], [n_items]: the lin2 work lists
+    int4* items = slots + 2 * la.n_slots;
+    for (int i = threadIdx.x; i < 2 * la.n_slots + la.n_items; i += WAVES_PER_BLOCK * 64)
+        slots[i] = i < 2 * la.n_slots ? la.slots[i] : la.items[i - 2 * la.n_slots];
 
     const int j = lane >> 3, q = lane & 7;
     const int node = grp * LIN2_NODES + j;
@@ -748,7 +755,6 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_lin2_
     }
     int sp = in_range ? la.species[node] : 0;
     sp = min(max(sp, 0), la.n_species - 1);
-    const float* arow = la.atab + (int64_t)sp * la.a_numel;
 
     for (int r = 0; r < la.n_rounds; ++r) {
         const int e = __builtin_amdgcn_readfirstlane(la.rounds[r * WAVES_PER_BLOCK + wave]);
@@ -765,31 +771,62 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_lin2_
             }
         }
         __syncthreads();  // every wave's sums are in LDS (and, in round 0, the output tile is initialised)
+        // lin2 of this round.  Per slot the lane's (v, k) pair, weight row and LDS row are set up once; an item is the
+        // <= 4 channel chunks of one path (constant strides), all its weight loads in flight before the first is used.
         const int s_beg = __builtin_amdgcn_readfirstlane(la.slot_index[(r * WAVES_PER_BLOCK + wave) * 2]);
         const int s_cnt = __builtin_amdgcn_readfirstlane(la.slot_index[(r * WAVES_PER_BLOCK + wave) * 2 + 1]);
+#ifndef MATTEN_ABLATE_NO_EPI
         for (int si = s_beg; si < s_beg + s_cnt; ++si) {
-            const int4 s0 = la.slots[2 * si], s1 = la.slots[2 * si + 1];
-            const int d3 = s0.z, n_pairs = s0.w;
-            const int idx = s1.y + q;
-            const bool act = idx < n_pairs;
-            const int idc = act ? idx : n_pairs - 1;     // clamped: the loads below stay unconditional
-            const int v = (idc * s1.z) >> 16, k = idc - v * d3;
-            const float* ap = arow + v * 8;
-            const float* tp = tarea + (j * d3 + k) * 8;
+            const int4 r0 = slots[2 * si], r1 = slots[2 * si + 1];
+            const int d3 = __builtin_amdgcn_readfirstlane(r0.x), n_pairs = __builtin_amdgcn_readfirstlane(r0.y);
+            const int i_beg = __builtin_amdgcn_readfirstlane(r1.y), i_cnt = __builtin_amdgcn_readfirstlane(r1.z);
+            const int idx = __builtin_amdgcn_readfirstlane(r0.w) + q;
+            const int idc = min(idx, n_pairs - 1);                      // clamped: the loads stay unconditional
+            const int v = (idc * __builtin_amdgcn_readfirstlane(r1.x)) >> 16, k = idc - v * d3;
+            const unsigned aoff = (unsigned)(sp * la.a_numel + v * 8);  // floats from atab: this node's species row, row v
+            const float* trow = tarea + (j * d3 + k) * 8;
             float sum0 = 0.0f, sum1 = 0.0f;
-            for (int ci = 0; ci < s0.y; ++ci) {
-                const int2 ch = la.chain[s0.x + ci];
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + ch.y);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap + ch.y + 4);
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp + ch.x);
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(tp + ch.x + 4);
-                sum0 = fmaf(a0[0], t0[0], sum0); sum1 = fmaf(a1[0], t1[0], sum1);
-                sum0 = fmaf(a0[1], t0[1], sum0); sum1 = fmaf(a1[1], t1[1], sum1);
-                sum0 = fmaf(a0[2], t0[2], sum0); sum1 = fmaf(a1[2], t1[2], sum1);
-                sum0 = fmaf(a0[3], t0[3], sum0); sum1 = fmaf(a1[3], t1[3], sum1);
+            for (int ii = i_beg; ii < i_beg + i_cnt; ++ii) {
+                const int4 it = items[ii];
+                const int t_off = __builtin_amdgcn_readfirstlane(it.x), nch = __builtin_amdgcn_readfirstlane(it.z);
+                const int astr = __builtin_amdgcn_readfirstlane(it.w);
+                const float* ab = la.atab + __builtin_amdgcn_readfirstlane(it.y);   // uniform base + per-lane 32-bit offset
+                f32x4 a0[4], a1[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int cc = min(c, nch - 1);
+#ifdef LIN2_ABL_NOGL
+                    a0[c] = f32x4{1.f, 2.f, 3.f, (float)(cc * astr + aoff)};
+                    a1[c] = a0[c];
+#else
+                    a0[c] = *reinterpret_cast<const f32x4*>(ab + (unsigned)(cc * astr) + aoff);
+                    a1[c] = *reinterpret_cast<const f32x4*>(ab + (unsigned)(cc * astr) + aoff + 4);
+#endif
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < nch) {
+#ifdef LIN2_ABL_NOLDS
+                        const f32x4 t0 = f32x4{1.f, 2.f, 3.f, (float)(t_off + c)};
+                        const f32x4 t1 = t0;
+#else
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(trow + t_off + c * LIN2_T_WAVE_FLOATS);
+                        const f32x4 t1 = *reinterpret_cast<const f32x4*>(trow + t_off + c * LIN2_T_WAVE_FLOATS + 4);
+#endif
+                        sum0 = fmaf(a0[c][0], t0[0], sum0); sum1 = fmaf(a1[c][0], t1[0], sum1);
+                        sum0 = fmaf(a0[c][1], t0[1], sum0); sum1 = fmaf(a1[c][1], t1[1], sum1);
+                        sum0 = fmaf(a0[c][2], t0[2], sum0); sum1 = fmaf(a1[c][2], t1[2], sum1);
+                        sum0 = fmaf(a0[c][3], t0[3], sum0); sum1 = fmaf(a1[c][3], t1[3], sum1);
+                    }
+                }
             }
-            if (act) otile[j * la.ld + s1.x + idx] += sum0 + sum1;
+#ifdef LIN2_ABL_NOOUT
+            if (idx < n_pairs && sum0 + sum1 == 12345.678f) otile[j * la.ld + __builtin_amdgcn_readfirstlane(r0.z) + idx] += sum0 + sum1;
+#else
+            if (idx < n_pairs) otile[j * la.ld + __builtin_amdgcn_readfirstlane(r0.z) + idx] += sum0 + sum1;
+#endif
         }
+#endif
         __syncthreads();  // the sums are consumed: the next round may overwrite the regions
     }
     for (int i = threadIdx.x; i < LIN2_NODES * la.d_out; i += WAVES_PER_BLOCK * 64) {
@@ -957,30 +994,30 @@ extern "C" int matten_tp_lin2(const float* x, int64_t d_in, const uint16_t* h2s,
                               const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr,
                               const int32_t* src_sorted, int64_t n_nodes, const int32_t* light_entries,
                               int64_t n_entries, const int32_t* rounds, int64_t n_rounds, const int32_t* slot_index,
-                              const int32_t* slots, int64_t n_slots, const int32_t* chain, int64_t n_chain,
+                              const int32_t* slots, int64_t n_slots, const int32_t* items, int64_t n_items,
                               const float* atab, int64_t a_numel, int64_t n_species, const int32_t* species,
                               float avg_num_neighbors, const float* num_neigh, const uint16_t* a_split,
                               const float* a_scale_inv, const float* add, int64_t add_ld, int64_t d_out, float* out,
                               matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_nodes < 0 || d_in <= 0 || w_pad <= 0 || sh_stride < 32 || (sh_stride & 3) || n_entries <= 0 || n_rounds <= 0 ||
-        n_slots < 0 || n_chain < 0 || a_numel <= 0 || (a_numel & 7) || n_species <= 0 || d_out <= 0)
+        n_slots < 0 || n_items < 0 || a_numel <= 0 || (a_numel & 7) || n_species <= 0 || d_out <= 0)
         return MATTEN_EINVAL;
     if (n_nodes == 0) return MATTEN_OK;
     if (!x || !h2s || !w2p || !sh_sorted || !rowptr || !src_sorted || !light_entries || !rounds || !slot_index ||
-        !slots || !chain || !atab || !species || !a_split || !a_scale_inv || !out)
+        !slots || !items || !atab || !species || !a_split || !a_scale_inv || !out)
         return MATTEN_EINVAL;
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
     if (add && add_ld < d_out) return MATTEN_EINVAL;
     const int ld = (int)((d_out + 23) / 32 * 32 + 8);   // row stride of the output tile: == 8 mod 32 (bank spread)
     const size_t lds = sizeof(float) * ((size_t)WAVES_PER_BLOCK * LIN2_T_WAVE_FLOATS + LIN2_STAGE_FLOATS +
-                                        (size_t)LIN2_NODES * ld);
+                                        (size_t)LIN2_NODES * ld + 8 * (size_t)n_slots + 4 * (size_t)n_items);
     if (lds > 64 * 1024) return MATTEN_EINVAL;
     Args a{x, (const _Float16*)h2s, w2p, (const _Float16*)a_split, a_scale_inv, sh_sorted, rowptr, src_sorted, num_neigh,
            nullptr, (int)d_in, (int)w_pad, (int)sh_stride, 0, (int)n_nodes, LIN2_T_WAVE_FLOATS, avg_num_neighbors};
     const int n_groups = (int)matten_cdiv(n_nodes, LIN2_NODES);
-    Lin2Args la{rounds, slot_index, (const int4*)slots, (const int2*)chain, atab, species, add, out,
-                (int)n_rounds, (int)a_numel, (int)n_species, (int)add_ld, (int)d_out, ld, n_groups};
+    Lin2Args la{rounds, slot_index, (const int4*)slots, (const int4*)items, atab, species, add, out,
+                (int)n_rounds, (int)n_slots, (int)n_items, (int)a_numel, (int)n_species, (int)add_ld, (int)d_out, ld, n_groups};
     // groups are numbered tile-major (8 per 64-node tile); the grid covers whole sets of N_XCD tiles
     const int64_t n_tiles = matten_cdiv(n_groups, 8);
     const int64_t grid = matten_cdiv(n_tiles, N_XCD) * N_XCD * 8;

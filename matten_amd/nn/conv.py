@@ -61,7 +61,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         if self.fused_plan is not None:
             fp = self.fused_plan
             self._fused_tables = DeviceTables(
-                light=fp.light_entries, rounds=fp.rounds, slot_index=fp.slot_index, slots=fp.slots, chain=fp.chain,
+                light=fp.light_entries, rounds=fp.rounds, slot_index=fp.slot_index, slots=fp.slot_recs, items=fp.slot_items,
                 a_base=fp.a_base, a_stride=fp.a_stride, a_scale=fp.a_scale, light_ids=fp.light_ids,
                 heavy_ids=fp.heavy_ids, heavy=fp.heavy_entries, heavy_umap=fp.heavy_unit_map,
                 **({"rest_gather": fp.rest.gather, "rest_scale": fp.rest.scale,
@@ -121,7 +121,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         inv_light, inv_heavy = self._fused_split.get(frag, scale_inv)
         out = ops.tp_lin2(
             x1, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC], t.get("light", dev),
-            t.get("rounds", dev), t.get("slot_index", dev), t.get("slots", dev), t.get("chain", dev),
+            t.get("rounds", dev), t.get("slot_index", dev), t.get("slots", dev), t.get("items", dev),
             self._fused_atab.get(self.lin2.weight), data[DataKey.AMD_SPECIES_I32], avg, num_neigh, (frag, inv_light),
             self_connection, fp.d_out,
         )

@@ -336,7 +336,7 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
     if unit_map.numel() != units_per_tile:
         raise ValueError(f"unit_map has {unit_map.numel()} units, expected {units_per_tile} (plan.fused_unit_map)")
     agg = torch.empty(N, d_mid, dtype=torch.float32, device=x.device)
-    with _timed(f"tp_scatter/d_mid={d_mid}"):
+    with _timed(f"tp_scatter/d_mid={d_mid}/d_in={x.shape[1]}"):
         rc = lib.matten_tp_fused(_ptr(x), d_in, _ptr(h2p), _ptr(w2p), w2p.shape[1], _ptr(sh_sorted),
                                  sh_sorted.shape[1], _ptr(rowptr), _ptr(src_sorted), N, _ptr(entries),
                                  _ptr(unit_map), entries.shape[0], units_per_tile, lds_floats_per_wave, d_mid,
@@ -347,7 +347,7 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
     return agg
 
 
-def tp_lin2(x, h2p, w2p, sh_sorted, rowptr, src_sorted, light_entries, rounds, slot_index, slots, chain, atab, species_i32,
+def tp_lin2(x, h2p, w2p, sh_sorted, rowptr, src_sorted, light_entries, rounds, slot_index, slots, items, atab, species_i32,
             avg_num_neighbors: float, num_neigh, a_split, add, d_out: int) -> torch.Tensor:
     """out[N, d_out] = add + lin2(neighbour sums of the light group entries)  (include/matten_hip.h matten_tp_lin2;
     tables from plan.plan_conv_fused).  a_split = (fragments, scale_inv per LIGHT entry)."""
@@ -371,11 +371,11 @@ def tp_lin2(x, h2p, w2p, sh_sorted, rowptr, src_sorted, light_entries, rounds, s
     if add is not None:
         add = _need_rows(add, torch.float32, "add")
     out = torch.empty(N, d_out, dtype=torch.float32, device=x.device)
-    with _timed(f"tp_lin2/d_out={d_out}"):
+    with _timed(f"tp_lin2/d_out={d_out}/d_in={x.shape[1]}"):
         rc = lib.matten_tp_lin2(_ptr(x), d_in, _ptr(h2p), _ptr(w2p), w2p.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
                                 _ptr(rowptr), _ptr(src_sorted), N, _ptr(light_entries), light_entries.shape[0],
-                                _ptr(rounds), rounds.shape[0], _ptr(slot_index), _ptr(slots), slots.shape[0],
-                                _ptr(chain), chain.shape[0], _ptr(atab), atab.shape[1], atab.shape[0], _ptr(species_i32),
+                                _ptr(rounds), rounds.shape[0], _ptr(slot_index), _ptr(slots), slots.shape[0], _ptr(items),
+                                items.shape[0], _ptr(atab), atab.shape[1], atab.shape[0], _ptr(species_i32),
                                 float(avg_num_neighbors or 0.0), _ptr(num_neigh), _ptr(frag), _ptr(scale_inv), _ptr(add),
                                 add.stride(0) if add is not None else d_out, d_out, _ptr(out), _stream())
     _lib.check(rc, "matten_tp_lin2")

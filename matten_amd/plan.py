@@ -598,6 +598,51 @@ class ConvFusedPlan:
     d_out: int
     light_ids: np.ndarray = None   # int64: index of each light / heavy entry in UVUPlan.group_entries
     heavy_ids: np.ndarray = None
+    # the same slots / chains flattened for the kernel: one ITEM per (slot, chain element), a wave's items of a round
+    # contiguous and slot-major; 4 packed words per item (see pack_lin2_items)
+    items: np.ndarray = None       # int32 [n_items, 4]
+    item_index: np.ndarray = None  # int32 [n_rounds, 4, 2] (first item, count) of (round, wave)
+    slot_recs: np.ndarray = None   # int32 [n_slots, 8]: kernel form of `slots` (merge_lin2_items)
+    slot_items: np.ndarray = None  # int32 [n_slot_items, 4]
+
+
+def merge_lin2_items(slot_index: np.ndarray, slots: np.ndarray, chain: np.ndarray, irreps_out_mul_of_off: Dict[int, int]):
+    """Kernel form of the slots: slot record {d3, n_pairs, out_off, pair_base, magic, first item, item count, 0} and
+    items {t_off, a_off, n_chunks (<= 4), a_stride}: consecutive chain elements that are the channel chunks of one
+    path in consecutive waves (LDS offsets LIN2_T_WAVE_FLOATS apart, weight blocks mul_out * 8 apart) become one item."""
+    recs, items = [], []
+    for (cb, cl, d3, n_pairs, out_off, pair_base, magic, _) in slots.tolist():
+        astr = irreps_out_mul_of_off[out_off] * 8
+        first = len(items)
+        ci = 0
+        while ci < cl:
+            t0, a0 = chain[cb + ci].tolist()
+            n = 1
+            while (ci + n < cl and n < 4 and chain[cb + ci + n][0] == t0 + n * LIN2_T_WAVE_FLOATS
+                   and chain[cb + ci + n][1] == a0 + n * astr):
+                n += 1
+            items.append((t0, a0, n, astr))
+            ci += n
+        recs.append((d3, n_pairs, out_off, pair_base, magic, first, len(items) - first, 0))
+    return (np.array(recs, dtype=np.int32).reshape(-1, 8), np.array(items, dtype=np.int32).reshape(-1, 4))
+
+
+def pack_lin2_items(slot_index: np.ndarray, slots: np.ndarray, chain: np.ndarray):
+    """item = {t_off | d3 << 16 | last_of_slot << 20,  a_off,  magic | pair_base << 17,  n_pairs | out_off << 16}"""
+    items, index = [], np.zeros(slot_index.shape, dtype=np.int32)
+    for r in range(slot_index.shape[0]):
+        for w in range(4):
+            b, cnt = slot_index[r, w]
+            first = len(items)
+            for (cb, cl, d3, n_pairs, out_off, pair_base, magic, _) in slots[b:b + cnt].tolist():
+                assert d3 < 16 and magic < (1 << 17) and pair_base < (1 << 14) and n_pairs < 65536 and out_off < 32768
+                for ci in range(cl):
+                    t_off, a_off = chain[cb + ci].tolist()
+                    assert t_off < 65536
+                    items.append((t_off | (d3 << 16) | (int(ci == cl - 1) << 20), a_off, magic | (pair_base << 17),
+                                  n_pairs | (out_off << 16)))
+            index[r, w] = (first, len(items) - first)
+    return np.array(items, dtype=np.int64).astype(np.int32).reshape(-1, 4), index
 
 
 def _div_magic(d: int) -> int:
@@ -656,7 +701,10 @@ def plan_conv_fused(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[ConvFu
     light_ids = [e for e in range(len(ent))
                  if int(ent[e][3]) == 3 and int(ent[e][0]) // TP_KIND_STRIDE <= LIN2_FUSE_LMAX
                  and 64 * t_offsets(e)[1] <= LIN2_T_WAVE_FLOATS]
-    if not light_ids or os.environ.get("MATTEN_CONV_FUSED", "1") == "0":
+    # Opt-in (MATTEN_CONV_FUSED=1): measured on MI355X the lin2 stage costs more than the agg round trip it removes
+    # (5.58 vs 5.38 ms per 1000-crystal forward) -- lin2's weights are per species, i.e. per NODE
+    # in a crystal-ordered batch: 27 KB of weights to apply per node against 12 KB of agg saved.
+    if not light_ids or os.environ.get("MATTEN_CONV_FUSED", "0") != "1":
         return None
     light_set = set(light_ids)
     # a path is handled where its entries are: all chunks of one (input block, l2 group) share lanes-per-node by construction
@@ -678,27 +726,32 @@ def plan_conv_fused(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[ConvFu
     a_base: List[np.ndarray] = []
     a_stride: List[np.ndarray] = []
     a_scale: List[np.ndarray] = []
-    a_off_of: Dict[Tuple[int, int, int], int] = {}
+    a_off_of: Dict[Tuple[int, int], int] = {}
     a_numel = 0
 
     def a_block(pi: int, u0: int, mul_c: int, io: int) -> int:
+        """float offset of the [mul_out][8] weight block of channels u0..u0+7 of path pi into output irrep io.  The
+        blocks of all 8-channel chunks of a path are allocated together, consecutive (stride mul_out * 8), so that the
+        kernel walks the chunks of one path with a constant stride."""
         nonlocal a_numel
-        key = (pi, u0, io)
-        if key in a_off_of:
-            return a_off_of[key]
+        key = (pi, io)
         pth = uvu.paths[pi]
-        ib, ub = blk_of_slot[pth.slot], uoff_of_slot[pth.slot] + u0
         mo = irreps_out[io].mul
-        v = np.arange(mo)[:, None]
-        u = np.arange(8)[None, :]
-        base = flat_of[(ib, io)] + (ub + u) * S * mo + v          # W[u_full, s=0, v]; + s * mo per species
-        base = np.where(u < mul_c, base, -1)
-        a_base.append(base.reshape(-1).astype(np.int64))
-        a_stride.append(np.full(mo * 8, mo, dtype=np.int64))
-        a_scale.append(np.full(mo * 8, fan[io] ** -0.5, dtype=np.float32))
-        a_off_of[key] = a_numel
-        a_numel += mo * 8
-        return a_off_of[key]
+        if key not in a_off_of:
+            a_off_of[key] = a_numel
+            ib = blk_of_slot[pth.slot]
+            for c0 in range(0, pth.mul, 8):
+                ub = uoff_of_slot[pth.slot] + c0
+                v = np.arange(mo)[:, None]
+                u = np.arange(8)[None, :]
+                base = flat_of[(ib, io)] + (ub + u) * S * mo + v          # W[u_full, s=0, v]; + s * mo per species
+                base = np.where(c0 + u < pth.mul, base, -1)
+                a_base.append(base.reshape(-1).astype(np.int64))
+                a_stride.append(np.full(mo * 8, mo, dtype=np.int64))
+                a_scale.append(np.full(mo * 8, fan[io] ** -0.5, dtype=np.float32))
+                a_numel += mo * 8
+        assert u0 % 8 == 0
+        return a_off_of[key] + (u0 // 8) * mo * 8
 
     slots: List[Tuple[int, ...]] = []
     chain: List[Tuple[int, int]] = []
@@ -777,7 +830,13 @@ def plan_conv_fused(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[ConvFu
     for row, e in zip(light_entries, light_ids):   # reserved[c] = accumulator offset of coupling c in the wave's LDS region
         for c, o in t_offsets(e)[0].items():
             row[8 + c] = o
+    slots_np = np.array(slots, dtype=np.int32).reshape(-1, 8)
+    chain_np = np.array(chain, dtype=np.int32).reshape(-1, 2)
+    items, item_index = pack_lin2_items(slot_index, slots_np, chain_np)
+    slot_recs, slot_items = merge_lin2_items(slot_index, slots_np, chain_np,
+                                             {o_offs[io]: irreps_out[io].mul for io in range(len(irreps_out))})
     return ConvFusedPlan(
+        items=items, item_index=item_index, slot_recs=slot_recs, slot_items=slot_items,
         light_entries=light_entries, rounds=rounds, slot_index=slot_index,
         slots=np.array(slots, dtype=np.int32).reshape(-1, 8), chain=np.array(chain, dtype=np.int32).reshape(-1, 2),
         a_numel=a_numel, a_base=np.concatenate(a_base), a_stride=np.concatenate(a_stride), a_scale=np.concatenate(a_scale),

@@ -669,10 +669,10 @@ def test_conv_fused_kernel_matches_two_kernel_path(monkeypatch):
         graphs = synthetic.fcc64_graphs(2) + ([lone] if avg else [lone_pair])
         ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": avg}
         hp = dict(PAPER, average_num_neighbors="auto" if avg else None)
+        monkeypatch.setenv("MATTEN_CONV_FUSED", "1")   # opt-in variant (plan.plan_conv_fused)
         ref, fused = build_pair(hp, ds, randomize_bn=True)
-        monkeypatch.setenv("MATTEN_CONV_FUSED", "0")
-        _, plain = build_pair(hp, ds, randomize_bn=True)
         monkeypatch.delenv("MATTEN_CONV_FUSED")
+        _, plain = build_pair(hp, ds, randomize_bn=True)
         convs = [m for m in fused.backbone.modules() if type(m).__name__ == "PointConv"]
         assert all(m.fused_plan is not None for m in convs) and len(convs) == 4
         assert all(m.fused_plan is None for m in plain.backbone.modules() if type(m).__name__ == "PointConv")

@@ -440,7 +440,8 @@ def _emulate_conv_fused(uvu, cf, lin2_w, S, agg, species, add):
                                 T[w * TW + 64 * row[8 + c] + (j * d3 + k) * 8 + u] = val
             for w in range(4):
                 b, cnt = cf.slot_index[r, w]
-                for (cb, cl, d3, n_pairs, out_off, pair_base, magic, _) in cf.slots[b:b + cnt]:
+                # the kernel's form of the slots: merged items {t_off, a_off, n_chunks, a_stride}
+                for (d3, n_pairs, out_off, pair_base, magic, ib, ni, _) in cf.slot_recs[b:b + cnt]:
                     for j, n in enumerate(nodes):
                         for q in range(8):
                             idx = pair_base + q
@@ -449,9 +450,11 @@ def _emulate_conv_fused(uvu, cf, lin2_w, S, agg, species, add):
                             v = (idx * magic) >> 16
                             k = idx - v * d3
                             acc = 0.0
-                            for (t_off, a_off) in cf.chain[cb:cb + cl]:
-                                for u in range(8):
-                                    acc += atab[species[n], a_off + v * 8 + u] * T[t_off + (j * d3 + k) * 8 + u]
+                            for (t_off, a_off, nch, astr) in cf.slot_items[ib:ib + ni]:
+                                for c in range(nch):
+                                    for u in range(8):
+                                        acc += (atab[species[n], a_off + c * astr + v * 8 + u]
+                                                * T[t_off + c * TW + (j * d3 + k) * 8 + u])
                             tile[j, out_off + idx] += acc
         for j, n in enumerate(nodes):
             out[n] = tile[j]
@@ -491,7 +494,11 @@ def test_conv_fused_plan_reproduces_lin2(case):
     }
     i1, ish, tgt, S = cases[case]
     uvu = mplan.plan_uvu(i1, ish, tgt)
-    cf = mplan.plan_conv_fused(uvu, S, tgt)
+    os.environ["MATTEN_CONV_FUSED"] = "1"
+    try:
+        cf = mplan.plan_conv_fused(uvu, S, tgt)
+    finally:
+        del os.environ["MATTEN_CONV_FUSED"]
     assert cf is not None
     lin2 = mplan.plan_fctp(uvu.irreps_mid.simplify(), S, tgt)
     rng = np.random.default_rng(11)
