@@ -177,6 +177,11 @@ int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t 
 int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                          const float* w0p, int nb_pad, const float* w1p, int hidden, uint16_t* h2s,
                          matten_stream_t stream);
+/* the same for n_layers <= 8 radial MLPs over one edge list in ONE launch (every conv layer of a model reads the same
+ * edge lengths; the Bessel basis is evaluated once): w0p / w1p / h2s are HOST arrays of n_layers device pointers */
+int matten_radial_hidden_multi(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
+                               const float* const* w0p, int nb_pad, const float* const* w1p, int hidden,
+                               uint16_t* const* h2s, int n_layers, matten_stream_t stream);
 int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
                     const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
                     int64_t n_nodes, const int32_t* group_entries, const int32_t* unit_map, int64_t n_entries,

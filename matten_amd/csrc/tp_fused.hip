@@ -934,7 +934,133 @@ __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __rest
     }
 }
 
+// All conv layers' hidden radial features in ONE launch: the edge lengths and the Bessel basis are the same for every
+// layer (reference nn/embedding.py:185-203 computes the embedding once per batch), only the MLP weights differ; one
+// launch instead of one per layer removes three launch + drain phases of a latency-bound kernel and evaluates the basis once.
+constexpr int RH_MAX_LAYERS = 8;
+struct RadialLayers {
+    const float* w0p[RH_MAX_LAYERS];
+    const float* w1p[RH_MAX_LAYERS];
+    _Float16* h2s[RH_MAX_LAYERS];
+    int n_layers;
+};
+
+template <int KS0>
+__global__ __launch_bounds__(256) void radial_hidden_multi_kernel(const float4* __restrict__ geom, int64_t E, int n_basis,
+                                                                  float r_start, float r_end, RadialLayers L) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * (NT * 16);
+    if (e0 >= E) return;
+    const float inv_c = 1.0f / (r_end - r_start);
+    const float bes_pref = sqrtf(2.0f * inv_c) * sqrtf((float)n_basis);
+    float bes[NT][KS0];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int64_t e = e0 + nt * 16 + c;
+        const float len = geom[e < E ? e : E - 1].w;
+        const float xr = len - r_start;
+        const float t01 = xr * inv_c, inv_xr = __builtin_amdgcn_rcpf(xr);
+#pragma unroll
+        for (int kk = 0; kk < KS0; ++kk) {
+            const int k = 4 * kk + g;
+            float b = 0.0f;
+            if (k < n_basis && t01 > 0.0f && t01 < 1.0f)
+                b = bes_pref * __builtin_amdgcn_sinf(0.5f * (float)(k + 1) * t01) * inv_xr;
+            bes[nt][kk] = b;
+        }
+    }
+    for (int l = 0; l < L.n_layers; ++l) {
+        const float* __restrict__ w0p = L.w0p[l];
+        const float* __restrict__ w1p = L.w1p[l];
+        _Float16* __restrict__ h2s = L.h2s[l];
+        float a0[2][KS0], a1[2][8];
+#pragma unroll
+        for (int kk = 0; kk < KS0; ++kk) {
+            a0[0][kk] = w0p[(4 * kk + g) * HID + c];
+            a0[1][kk] = w0p[(4 * kk + g) * HID + 16 + c];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+            a1[0][kk] = w1p[k * HID + c];
+            a1[1][kk] = w1p[k * HID + 16 + c];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int64_t e = e0 + nt * 16 + c;
+            f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS0; ++kk) {
+                h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0][kk], bes[nt][kk], h0, 0, 0, 0);
+                h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1][kk], bes[nt][kk], h1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                h0[r] = silu(h0[r]);
+                h1[r] = silu(h1[r]);
+            }
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float b = kk < 4 ? h0[kk & 3] : h1[kk & 3];
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0][kk], b, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1][kk], b, o1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o0[r] = silu(o0[r]);
+                o1[r] = silu(o1[r]);
+            }
+            if (e < E) {
+                f16x8 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 h, ll;
+                    split_f16(o0[r], h, ll);
+                    hi[r] = h, lo[r] = ll;
+                    split_f16(o1[r], h, ll);
+                    hi[4 + r] = h, lo[4 + r] = ll;
+                }
+                f16x8* dst = reinterpret_cast<f16x8*>(h2s + e * (2 * HID) + g * 8);
+                dst[0] = hi;
+                dst[HID / 8] = lo;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int matten_radial_hidden_multi(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start,
+                                          float r_end, const float* const* w0p, int nb_pad, const float* const* w1p,
+                                          int hidden, uint16_t* const* h2s, int n_layers, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_edges < 0 || hidden != HID || (nb_pad & 3) || nb_pad < n_basis || nb_pad > 16 || n_layers < 1 ||
+        n_layers > RH_MAX_LAYERS)
+        return MATTEN_EINVAL;
+    if (n_edges == 0) return MATTEN_OK;
+    if (!geom_sorted || !w0p || !w1p || !h2s) return MATTEN_EINVAL;
+    RadialLayers L{};
+    L.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!w0p[l] || !w1p[l] || !h2s[l]) return MATTEN_EINVAL;
+        L.w0p[l] = w0p[l], L.w1p[l] = w1p[l], L.h2s[l] = (_Float16*)h2s[l];
+    }
+    unsigned grid = (unsigned)matten_cdiv(n_edges, 4 * NT * 16);
+#define LAUNCH(K) \
+    radial_hidden_multi_kernel<K><<<grid, 256, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis, r_start, r_end, L)
+    switch (nb_pad >> 2) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
 
 extern "C" int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                                     const float* w0p, int nb_pad, const float* w1p, int hidden, uint16_t* h2s,

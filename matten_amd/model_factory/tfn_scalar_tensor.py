@@ -81,7 +81,25 @@ def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any], pooli
             NodewiseReduce,
             {"field": OUT_FIELD_NAME, "out_field": OUT_FIELD_NAME, "reduce": hparams["reduce"]},
         )
-    return create_sequential_module(modules=layers)
+    backbone = create_sequential_module(modules=layers)
+    link_radial_mlps(backbone)
+    return backbone
+
+
+def link_radial_mlps(backbone) -> None:
+    """Every conv layer's radial MLP reads the same edge lengths (reference nn/conv.py:72 builds one FullyConnectedNet per
+    layer on the shared edge embedding): tell them about each other so the first one evaluates the hidden layers of all
+    in a single launch (nn.utils.RadialMLP.hidden).  Weak references: no parameter sharing, no state_dict change."""
+    from ..nn.utils import RadialMLP, link_radial_group
+
+    groups = {}
+    for m in backbone.modules():
+        if isinstance(m, RadialMLP):
+            groups.setdefault(tuple(m.hs[:3]), []).append(m)
+    for group in groups.values():
+        for i in range(0, len(group), 8):
+            if len(group[i:i + 8]) > 1:
+                link_radial_group(group[i:i + 8])
 
 
 class ScalarTensorModel(torch.nn.Module):

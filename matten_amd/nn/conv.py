@@ -116,7 +116,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         nb, r0, r1 = data[DataKey.AMD_RBF].tolist()
         avg = self.avg_num_neighbors if self.avg_num_neighbors is not None else 0.0
         num_neigh = None if self.avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
-        h2p, w2p = tp.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1)
+        h2p, w2p = tp.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, data)
         frag, scale_inv = tp._a_split.get(w2p)
         inv_light, inv_heavy = self._fused_split.get(frag, scale_inv)
         out = ops.tp_lin2(

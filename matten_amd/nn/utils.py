@@ -88,6 +88,25 @@ class _RadialLayer(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.randn(h_in, h_out))
 
 
+# radial MLPs that read the same edge lengths (one per conv layer of a model), by group token.  The modules only carry
+# the integer token (picklable, copyable); a copied / unpickled module is not in the registry and simply runs alone.
+_RADIAL_GROUPS: Dict[int, list] = {}
+
+
+def link_radial_group(mlps) -> None:
+    import weakref
+
+    token = max(_RADIAL_GROUPS, default=0) + 1
+    _RADIAL_GROUPS[token] = [weakref.ref(m) for m in mlps]
+    for m in mlps:
+        m._radial_group = token
+
+
+def radial_group_of(mlp) -> list:
+    members = [m for m in (r() for r in _RADIAL_GROUPS.get(getattr(mlp, "_radial_group", 0), ())) if m is not None]
+    return members if any(m is mlp for m in members) else [mlp]
+
+
 class RadialMLP(torch.nn.Module):
     """Bias-free MLP [n_basis, h, h, W]: x <- c*silu(x @ W/sqrt(h_in)) on hidden layers."""
 
@@ -139,11 +158,23 @@ class RadialMLP(torch.nn.Module):
                 x = torch.nn.functional.silu(x) * self.act_cst
         return x.contiguous()
 
-    def hidden(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float):
-        """(h2p[E,32], w2p): the two hidden layers evaluated, the last layer left to the fused TP kernel."""
+    def hidden(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float, data=None):
+        """(h2s[E,2,32], w2p): the two hidden layers evaluated, the last layer left to the fused TP kernel.
+        With `data` (the batch dict) and a sibling group (set by the model factory: every conv layer's radial MLP reads
+        the same edge lengths) the first call evaluates ALL siblings in one launch and parks the results in the dict."""
         if n_basis != self.hs[0]:
             raise ValueError(f"radial basis size {n_basis} != MLP input {self.hs[0]}")
         w0p, w1p, w2p = self._packed.get(self.layer0.weight, self.layer1.weight, self.layer2.weight)
+        group = radial_group_of(self)
+        if data is not None and len(group) > 1 and os.environ.get("MATTEN_RADIAL_MULTI", "1") != "0":
+            cache = data.get("_amd_h2s")
+            if cache is None or cache.get("geom") is not geom_sorted or id(self) not in cache:
+                packs = [m._packed.get(m.layer0.weight, m.layer1.weight, m.layer2.weight) for m in group]
+                outs = ops.radial_hidden_multi(geom_sorted, n_basis, r_start, r_end, [p[0] for p in packs],
+                                               [p[1] for p in packs])
+                cache = {"geom": geom_sorted, **{id(m): h for m, h in zip(group, outs)}}
+                data["_amd_h2s"] = cache
+            return cache.pop(id(self)), w2p   # popped: the 147 MB per layer are released after use
         return ops.radial_hidden(geom_sorted, n_basis, r_start, r_end, w0p, w1p), w2p
 
 
@@ -210,7 +241,7 @@ class UVUTensorProduct(torch.nn.Module):
             w_edge = self.weight_nn.forward_train(data["_amd_emb_sorted"])
             return _ag.TensorProductScatterFn.apply(node_feats, w_edge, self, data, avg, num_neigh)
         if self.impl == "fused":
-            h2p, w2p = self.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1)
+            h2p, w2p = self.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, data)
             return ops.tp_fused(
                 node_feats, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
                 self._tables.get("gentries", dev), self._tables.get("gumap", dev), len(self.plan.fused_unit_map),

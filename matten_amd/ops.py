@@ -284,6 +284,26 @@ def radial_hidden(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, 
     return h2p
 
 
+def radial_hidden_multi(geom_sorted, n_basis: int, r_start: float, r_end: float, w0ps, w1ps):
+    """h2s of several radial MLPs over the same edges in one launch -> list of [E,2,32] fp16"""
+    import ctypes
+
+    lib = _lib.load()
+    geom_sorted = _need(geom_sorted, torch.float32, "geom_sorted")
+    w0ps = [_need(w, torch.float32, "w0p") for w in w0ps]
+    w1ps = [_need(w, torch.float32, "w1p") for w in w1ps]
+    L, E = len(w0ps), geom_sorted.shape[0]
+    if not 1 <= L <= 8 or len(w1ps) != L or any(w.shape != w0ps[0].shape for w in w0ps):
+        raise ValueError("radial_hidden_multi: 1..8 layers with equal basis / hidden sizes")
+    out = [torch.empty(E, 2, 32, dtype=torch.float16, device=geom_sorted.device) for _ in range(L)]
+    arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+    with _timed("radial_hidden_multi"):
+        rc = lib.matten_radial_hidden_multi(_ptr(geom_sorted), E, n_basis, r_start, r_end, arr(w0ps), w0ps[0].shape[0],
+                                            arr(w1ps), w0ps[0].shape[1], arr(out), L, _stream())
+    _lib.check(rc, "matten_radial_hidden_multi")
+    return out
+
+
 def split_a_tiles(w2p: torch.Tensor, group_entries) -> Tuple[torch.Tensor, torch.Tensor]:
     """w2p [32, w_pad] -> (a_split [n_tiles, 64, 16] fp16, a_scale_inv [n_entries] fp32): the last radial layer as the
     MFMA A fragments matten_tp_fused consumes (layout: include/matten_hip.h), per entry scaled by the power of two
