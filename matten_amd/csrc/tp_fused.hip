@@ -412,7 +412,13 @@ struct StoreLds {
     }
 };
 
-template <int L1, int GI, int TT, class Epilogue>
+// the kinds with registers to spare for a second neighbour row in flight (two-slot chunks: 8 lanes per node)
+template <int L1, int GI>
+struct TwoDeepOk { static constexpr bool value = L1 == 0 || (L1 == 1 && GI == 0); };
+
+// TWO_DEEP is a template parameter, not a run-time flag: with both gather schedules in one instantiation the compiler
+// reconciled their register assignments with 50-90 v_mov per CHUNK (60 % of the l1 = 0 kind's vector instructions).
+template <int L1, int GI, int TT, bool TWO_DEEP, class Epilogue>
 __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry& ge, float* __restrict__ tile,
                                                  float* __restrict__ stage, int entry, int node, int lane, bool valid,
                                                  int beg, int deg_node, int maxdeg, const Epilogue& epi) {
@@ -494,8 +500,8 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     // clamped edge index.
     const int e_last = deg > 0 ? beg + deg - 1 : 0;
     // (compiled in only for the kinds with registers to spare: the second row buffer costs the heavy kinds spills)
-    constexpr bool TWO_DEEP_OK = L1 == 0 || (L1 == 1 && GI == 0);
-    const bool two_deep = TWO_DEEP_OK && CH == 2;
+    static_assert(!TWO_DEEP || TwoDeepOk<L1, GI>::value, "two rows in flight only for the light kinds");
+    constexpr bool two_deep = TWO_DEEP;   // the caller guarantees CH == 2 (8 lanes per node)
     float xn[G::D1], xb[G::D1];
     int src_nn, src_b = 0;
     {
@@ -603,7 +609,11 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 }
 
 #define MATTEN_GROUP_CASE_SHARED(L1, GI) \
-    case (L1 * matten::GROUP_KIND_STRIDE + GI): if (nodes_per_wave > 16) run_group_shared<L1, GI, 2>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); else run_group_shared<L1, GI, 1>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); break;
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): \
+        if (nodes_per_wave > 16) run_group_shared<L1, GI, 2, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
+        else if (TwoDeepOk<L1, GI>::value && nodes_per_wave == 8) run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
+        else run_group_shared<L1, GI, 1, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
+        break;
 
 #define MATTEN_GROUP_CASE(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, node, lane, valid, beg, deg, maxdeg); break;
@@ -714,7 +724,7 @@ struct Lin2Args {
 };
 
 #define MATTEN_LIN2_CASE(L1, GI) \
-    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI, 1>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreLds{tile}); break;
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreLds{tile}); break;
 
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_lin2_kernel(Args a, Lin2Args la,
                                                                                       const GroupEntry* __restrict__ entries) {
