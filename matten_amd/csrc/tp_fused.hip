@@ -54,6 +54,9 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     lo = fabsf(r) < F16_MIN_NORMAL ? (_Float16)0.0f : (_Float16)r;
 }
 
+#ifndef TPF_SETPRIO
+#define TPF_SETPRIO 3
+#endif
 constexpr int TILE_NODES = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int N_XCD = 8;
@@ -523,6 +526,9 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     __syncthreads();
     int buf = 0;
     for (int s0 = 0; s0 < maxdeg; s0 += CH, buf ^= 1) {
+        // the short serial head of a chunk (issue the stage loads, LDS -> MFMA -> LDS) runs at raised priority: it is a
+        // latency chain, and every cycle another wave's contraction delays it is added to this wave's chunk (-1 %)
+        __builtin_amdgcn_s_setprio(TPF_SETPRIO);
         ld.issue(s0 + CH);
         const float* sb = stage + buf * (16 * TT * STAGE_ROW);
 #pragma unroll
@@ -544,6 +550,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the weight tile is written
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_setprio(0);
 #ifndef MATTEN_ABLATE_NO_VALU
         auto contract = [&](int so, const float* __restrict__ x) {
             const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
