@@ -68,9 +68,17 @@ namespace {
 // write of an operand -> MFMA read) and mfma_drain() after the last MFMA of every straight-line group, before
 // anything else may read, copy or store an accumulator.
 __device__ __forceinline__ void mfma_16x16x4(sl_f32x4& acc, float a, float b) {
+#ifdef SL_ABL_NO_MFMA
+    asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[0]) : "v"(a + b));   // timing experiment (tools/sl_ab2.sh): operands stay alive
+#else
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#endif
 }
-__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15" ::: "memory"); }
+__device__ __forceinline__ void mfma_drain() {
+#ifndef SL_ABL_NO_MFMA
+    asm volatile("s_nop 15" ::: "memory");
+#endif
+}
 
 // steps (16 input channels each) per chunk: max(1, NB / d).  d is 2l+1 <= 9 (the host plan rejects anything else), so
 // the run-time value is a select chain: the integer division cost ~30 instructions and a VALU -> SALU round trip three
@@ -274,7 +282,25 @@ __device__ __forceinline__ void consume_d(const float* buf, sl_f32x4 (&acc)[NACC
 __device__ __forceinline__ void consume(const float (&regs)[4 * NB], float* buf, sl_f32x4 (&acc)[NACC],
                                         const float* __restrict__ ws, const LinSeg& L, const Cursor& cu, int g, int c,
                                         bool row_ok, float* __restrict__ orow) {
+#ifdef SL_ABL_LOADS_ONLY
+    {   // timing experiment (tools/sl_ab2.sh): the load stream + the cursor walk only (results are wrong)
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i) t += regs[i];
+        acc[0][0] += t;
+        if (cu.st >= 0 && cu.st + steps_per_chunk(L.d) >= ((L.mul_in + 15) >> 4) && acc[0][0] == 12345.678f) orow[0] = t;
+        return;
+    }
+#endif
     stage_chunk(regs, buf, g, c);
+#ifdef SL_ABL_STAGE_ONLY
+    {   // timing experiment: + the LDS staging writes
+        float t = buf[c * XS_RS + 4 * g];
+        acc[0][0] += t;
+        if (cu.st >= 0 && cu.st + steps_per_chunk(L.d) >= ((L.mul_in + 15) >> 4) && acc[0][0] == 12345.678f) orow[0] = t;
+        return;
+    }
+#endif
     switch (L.d) {
         case 1: consume_d<1>(buf, acc, ws, L, cu, g, c, row_ok, orow); break;
         case 3: consume_d<3>(buf, acc, ws, L, cu, g, c, row_ok, orow); break;
