@@ -269,10 +269,10 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                     cu_log2 = 3  # every chunk of a block the conv-fused kernel may take has 8 lanes per node
                 nodes_per_wave = max(1, 64 // (1 << cu_log2))
                 n_tiles16 = max(1, nodes_per_wave // 16)
-                # wave tile: [16 * n_tiles16 edge rows][weight columns + 4]; the unshared path (unit order "entry", A/B
-                # harness only) also parks the edge's 32 harmonics behind the weights
-                y_cols = 32 if os.environ.get("MATTEN_FUSED_UNIT_ORDER", "node") != "node" else 0
-                lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(combos)) // 16)) + y_cols + 4))
+                # wave tile: [16 * n_tiles16 edge rows][weight columns + 4 (+ 32: units off the shared path park the
+                # edge's harmonics behind the weights; sized for them so that any unit order is valid)].  Without the 32
+                # a block needs 35.8 instead of 52 KB of LDS, but four blocks per CU do not pay.
+                lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(combos)) // 16)) + 32 + 4))
                 n_mt = -(-(mul_c * len(combos)) // 16)  # 16-column MFMA tiles of the entry's weight block
                 row = [l1 * TP_KIND_STRIDE + gi, plist[0].x_off + u0 * d1, mul_c, cu_log2, 0, len(fused_cols),
                        fused_a_tiles, n_mt] + [0] * 24
