@@ -30,6 +30,13 @@ def create_sequential_module(
         except Exception as e:
             raise RuntimeError(f"Failed instantiate module `{cls_type.__name__}` with kwargs: `{kw}`") from e
         built[name] = prev
+        # anomaly detection behind every layer in debug mode (reference model_factory/utils.py:82-87)
+        from ..log import get_log_level
+
+        if get_log_level() == "DEBUG":
+            from ..nn.utils import DetectAnomaly
+
+            built[DetectAnomaly.__name__ + "_" + name] = DetectAnomaly(irreps_in=prev.irreps_out, name=name)
     return Sequential(built)
 
 

@@ -20,7 +20,7 @@ from torch import Tensor
 
 from .. import autograd as _ag
 from .. import ops, plan as _plan
-from ..data.irreps import DataKey
+from ..data.irreps import DataKey, ModuleIrreps
 from ..o3 import Irrep, Irreps
 from ._activation import act_const_table, normalize2mom_const
 from ._tables import DerivedWeight, DeviceTables
@@ -358,3 +358,25 @@ class NormalizationLayer(torch.nn.Module):
             raise NotImplementedError("normalization='instance' is outside the accelerated path")
         assert method in supported, f"Unsupported normalization {method}"
         self.n = _IrrepBatchNorm(irreps) if method == "batch" else None
+
+
+class DetectAnomaly(ModuleIrreps, torch.nn.Module):
+    """Checks every tensor of the data dict its predecessor produced for NaN / Inf (reference nn/utils.py:370-394);
+    inserted behind every layer by ``create_sequential_module`` when the log level is DEBUG."""
+
+    def __init__(self, irreps_in: Dict[str, Irreps], name: str):
+        super().__init__()
+        self.init_irreps(irreps_in=irreps_in)
+        self.name = name
+
+    def forward(self, data: DataKey.Type) -> DataKey.Type:
+        from ..utils import detect_nan_and_inf
+
+        for k, v in data.items():
+            if v is None:
+                continue
+            try:
+                detect_nan_and_inf(v)
+            except ValueError:
+                raise ValueError(f"Anomaly detected for {k} of {self.name}")
+        return data

@@ -308,6 +308,9 @@ def predict(
     config: Dict[str, Any] = None,
 ):
     """See the module docstring.  ``model`` / ``config`` let a caller reuse an already loaded model."""
+    from .log import set_logger
+
+    set_logger(logger_level)  # reference predict.py:194
     if is_atomic_tensor:  # reference predict.py:196-199
         is_elasticity_tensor = False
     single = not isinstance(structure, (list, tuple))

@@ -688,3 +688,26 @@ def test_conv_fused_kernel_matches_two_kernel_path(monkeypatch):
             # run twice: the accumulation order is fixed
             again = fused.backbone(collate(graphs, device=DEV))["my_model_output"]
             assert torch.equal(again, a["my_model_output"])
+
+
+def test_debug_mode_catches_nan_on_device():
+    """log level DEBUG: the DetectAnomaly layers (reference nn/utils.py:370-394) name the first layer whose output holds
+    a NaN; the same batch passes silently (NaN output) without them"""
+    from matten_amd import log
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _fcc(1)
+    log.set_logger("DEBUG", stderr=False)
+    try:
+        _, model = build_pair(dict(LMAX2, num_layers=1), ds, device=DEV)
+    finally:
+        log.set_logger("ERROR", stderr=False)
+    good = collate(graphs, device=DEV)
+    with torch.no_grad():
+        out = model(dict(good))[0]["elastic_tensor_full"]
+        assert torch.isfinite(out).all()
+        bad = dict(good)
+        bad["pos"] = good["pos"].clone()
+        bad["pos"][3, 1] = float("nan")
+        with pytest.raises(ValueError, match="Anomaly detected for pos of one_hot"):
+            model(bad)

@@ -522,3 +522,34 @@ def test_conv_fused_plan_reproduces_lin2(case):
     assert sorted(x for x in cf.rounds.reshape(-1) if x >= 0) == list(range(len(cf.light_entries)))
     assert (cf.chain[:, 0] >= 0).all() and (cf.chain[:, 0] < 4 * mplan.LIN2_T_WAVE_FLOATS).all()
     assert (cf.chain[:, 1] >= 0).all() and (cf.chain[:, 1] < cf.a_numel).all()
+
+
+def test_debug_log_level_inserts_anomaly_detectors():
+    """reference model_factory/utils.py:82-87: with the log level at DEBUG every layer is followed by a DetectAnomaly
+    module (same names: 'DetectAnomaly_<layer>'); parameters and state_dict keys are unchanged"""
+    from common import LMAX2
+    from matten_amd import log
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+    from matten_amd.nn.utils import DetectAnomaly
+    from matten_amd.utils import detect_nan_and_inf
+
+    ds = {"allowed_species": [13, 29], "average_num_neighbors": 18.0}
+    hp = dict(LMAX2, num_layers=1)
+    plain = ScalarTensorModel(backbone_hparams=hp, dataset_hparams=ds)
+    log.set_logger("DEBUG", stderr=False)
+    try:
+        dbg = ScalarTensorModel(backbone_hparams=hp, dataset_hparams=ds)
+    finally:
+        log.set_logger("ERROR", stderr=False)
+    names = [n for n, _ in dbg.backbone.named_children()]
+    assert names[:4] == ["one_hot", "DetectAnomaly_one_hot", "spharm_edges", "DetectAnomaly_spharm_edges"]
+    assert sum(isinstance(m, DetectAnomaly) for m in dbg.backbone.children()) == len(list(plain.backbone.children()))
+    assert list(dbg.state_dict().keys()) == list(plain.state_dict().keys())
+    # the detector itself (host tensors): NaN / Inf raise with the key and the layer name, non-float entries are skipped
+    det = DetectAnomaly(irreps_in=None, name="layer0_convnet")
+    ok = {"pos": torch.zeros(3, 3), "edge_index": torch.zeros(2, 4, dtype=torch.int64), "none": None, "pair": (1, 2)}
+    assert det(ok) is ok
+    with pytest.raises(ValueError, match="Anomaly detected for node_features of layer0_convnet"):
+        det(dict(ok, node_features=torch.tensor([1.0, float("nan")])))
+    with pytest.raises(ValueError, match="inf"):
+        detect_nan_and_inf(torch.tensor([float("inf")]), file="f", name="x")
