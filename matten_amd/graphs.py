@@ -1,0 +1,127 @@
+"""
+hipGraph capture of a whole optimisation step (forward, loss, backward, optimiser) for FIXED batch shapes.
+
+At the reference's training batch size (32 crystals, ~150 atoms, ~4.5 k edges: pretrained/20230627/config_final.yaml:3-6)
+a step is ~350 kernel launches for under 3 ms of kernel time: the host cannot issue them fast enough.  Captured once
+(``torch.cuda.CUDAGraph`` = hipStreamBeginCapture / hipGraphLaunch on ROCm), a step is one launch.  The kernels of
+``libmatten_hip.so`` take their stream as an argument and never synchronise, so they capture as they are.
+
+Constraints (checked): every tensor of the batch keeps its shape and dtype between steps (pad or bucket batches
+upstream), the optimiser is capturable (``torch.optim.Adam(..., capturable=True)``), and the one host synchronisation
+of the forward -- the species / edge_index range check of ``SpeciesEmbedding`` -- is done once, eagerly, before the
+capture and switched off inside it.
+"""
+from typing import Callable, Dict
+
+import torch
+
+
+# rocPRIM's radix sort (CSR build, species grouping) switches algorithm above 2^20 keys and that path does not survive
+# a capture on this ROCm (memory aperture violation at replay; eager is fine).  Capture pays for launch-bound batches
+# only -- at 10^6 edges the GPU is busy for milliseconds per step either way -- so larger batches are refused.
+MAX_CAPTURED_EDGES = 1_000_000
+
+
+def _check_capturable(batch) -> None:
+    n_edges = int(batch["edge_index"].shape[1])
+    n_nodes = int(batch["pos"].shape[0])
+    if max(n_edges, n_nodes) > MAX_CAPTURED_EDGES:
+        raise ValueError(f"{n_edges} edges / {n_nodes} nodes: hipGraph capture is for launch-bound batch sizes "
+                         f"(<= {MAX_CAPTURED_EDGES}); run larger batches eagerly")
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, loss_fn: Callable, batch: Dict[str, torch.Tensor], target: torch.Tensor,
+                 warmup: int = 3, task_name: str = "elastic_tensor_full"):
+        _check_capturable(batch)
+        self.model, self.optimizer, self.loss_fn, self.task_name = model, optimizer, loss_fn, task_name
+        dev = target.device
+        self._static = {k: v.clone() if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+        self._target = target.clone()
+        embeds = [m for m in model.modules() if hasattr(m, "check_species")]
+        # warm-up on a side stream (allocator pools, lazily built tables), with the range checks on
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._flags = [(m, m.check_species) for m in embeds]
+        for m in embeds:
+            m.check_species = False   # validated above; a host sync cannot be captured
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                self._loss = self._eager_step()
+        finally:
+            for m, f in self._flags:
+                m.check_species = f
+
+    def _eager_step(self):
+        preds, _ = self.model(dict(self._static), task_name=self.task_name)
+        loss = self.loss_fn(preds, self._target)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def step(self, batch: Dict[str, torch.Tensor], target: torch.Tensor) -> torch.Tensor:
+        """copy the batch into the captured buffers (shapes must match) and replay; returns the captured loss tensor"""
+        for k, v in batch.items():
+            if isinstance(v, torch.Tensor):
+                s = self._static[k]
+                if s.shape != v.shape or s.dtype != v.dtype:
+                    raise ValueError(f"batch['{k}'] is {tuple(v.shape)} {v.dtype}, the captured step takes "
+                                     f"{tuple(s.shape)} {s.dtype}: capture one GraphedTrainStep per batch shape")
+                if s.data_ptr() != v.data_ptr():
+                    s.copy_(v, non_blocking=True)
+        if target.data_ptr() != self._target.data_ptr():
+            self._target.copy_(target, non_blocking=True)
+        self.graph.replay()
+        return self._loss
+
+
+class GraphedForward:
+    """Inference forward of FIXED batch shapes as one hipGraph launch: ``out = g(batch)`` -> [B, 21] (irreps) or the
+    Cartesian tensors, whatever ``model(batch)`` returns for `task_name`.  Pays where the forward is launch-bound (small
+    batches: ~45 launches); at 1000 crystals per batch the GPU is busy either way."""
+
+    def __init__(self, model, batch: Dict[str, torch.Tensor], warmup: int = 3, task_name: str = "elastic_tensor_full"):
+        _check_capturable(batch)
+        self.model, self.task_name = model, task_name
+        dev = next(model.parameters()).device
+        self._static = {k: v.clone() if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
+        embeds = [m for m in model.modules() if hasattr(m, "check_species")]
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(1, warmup)):
+                model(dict(self._static), task_name=task_name)   # range checks on: validates the captured batch
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        flags = [(m, m.check_species) for m in embeds]
+        for m in embeds:
+            m.check_species = False
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self._out = model(dict(self._static), task_name=task_name)[0][task_name]
+        finally:
+            for m, f in flags:
+                m.check_species = f
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """NOTE: the species / edge_index range checks ran on the batch given at construction only; a replayed batch is
+        trusted (same shapes enforced)."""
+        for k, v in batch.items():
+            if isinstance(v, torch.Tensor):
+                s = self._static[k]
+                if s.shape != v.shape or s.dtype != v.dtype:
+                    raise ValueError(f"batch['{k}'] is {tuple(v.shape)} {v.dtype}, the captured forward takes "
+                                     f"{tuple(s.shape)} {s.dtype}: capture one GraphedForward per batch shape")
+                if s.data_ptr() != v.data_ptr():
+                    s.copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self._out

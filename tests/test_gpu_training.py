@@ -102,3 +102,58 @@ def test_eval_after_training_uses_running_stats(golden_dir):
         want = ref.decode(collate(graphs))
         got = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
     _close(got, want, 5e-4, "eval after train")
+
+
+def test_hipgraph_training_step_follows_the_eager_trajectory(golden_dir):
+    """matten_amd.graphs.GraphedTrainStep: forward + MSE + backward + Adam of config 4 captured once in a hipGraph and
+    replayed; after several steps on alternating batches of equal shape the parameters follow the eager run (the
+    backward's fp32 atomics make both runs reproducible only to rounding), a batch of another shape is refused."""
+    from matten_amd.data.graph import collate
+    from matten_amd.graphs import GraphedTrainStep
+
+    graphs, ds = _graphs(golden_dir, 8)
+    batches = [collate(graphs, device=DEV), collate(graphs[::-1], device=DEV)]   # same shapes, different order
+    targets = [torch.randn(len(graphs), 21, device=DEV, generator=torch.Generator(device=DEV).manual_seed(s)) for s in (1, 2)]
+
+    def make():
+        _, m = build_pair(LMAX2, ds, randomize_bn=True)
+        m.train()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-2, weight_decay=1e-5, fused=True, capturable=True)
+
+    def loss_fn(preds, t):
+        return torch.nn.functional.mse_loss(preds["elastic_tensor_full"], t)
+
+    warm = 2
+    eager, opt_e = make()
+    graphed, opt_g = make()
+    step = GraphedTrainStep(graphed, opt_g, loss_fn, batches[0], targets[0], warmup=warm)
+    n_pre = warm   # steps the constructor took on (batches[0], targets[0]): the warm-up ones (a capture records, it does not run)
+    for _ in range(n_pre):
+        loss = loss_fn(eager(dict(batches[0]))[0], targets[0])
+        opt_e.zero_grad(); loss.backward(); opt_e.step()
+    for i in range(6):
+        b, t = batches[i % 2], targets[i % 2]
+        le = loss_fn(eager(dict(b))[0], t)
+        opt_e.zero_grad(); le.backward(); opt_e.step()
+        lg = step.step(b, t)
+        _close(lg, le, 2e-3, f"loss at step {i}")
+    for (k, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
+        _close(pg, pe, 5e-3, f"param {k} after 6 replayed steps")
+    small = collate(graphs[:3], device=DEV)
+    with pytest.raises(ValueError, match="captured step takes"):
+        step.step(small, targets[0][:3])
+
+
+def test_hipgraph_forward_is_bit_identical_to_eager():
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import collate
+    from matten_amd.graphs import GraphedForward
+
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    _, model = build_pair(PAPER, ds, randomize_bn=True)
+    a, b = collate(synthetic.fcc64_graphs(4), device=DEV), collate(synthetic.fcc64_graphs(4, seed=99), device=DEV)
+    g = GraphedForward(model, a)
+    with torch.no_grad():
+        for batch in (a, b, a):
+            want = model(dict(batch))[0]["elastic_tensor_full"]
+            assert torch.equal(g(batch), want)
