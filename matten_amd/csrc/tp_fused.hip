@@ -57,6 +57,16 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_SETPRIO
 #define TPF_SETPRIO 3
 #endif
+// weight columns ([u][coupling]) an entry may have: the plan caps an entry at the largest power-of-two channel count whose
+// block fits (plan.py TP_MAX_COLS, checked at load through matten_tp_max_cols); its MFMA A operand stays in registers
+#ifndef TPF_MAX_COLS
+#define TPF_MAX_COLS 64
+#endif
+__host__ __device__ constexpr int cap_channels(int nc) {
+    int cap = 64;
+    while (cap > 1 && cap * nc > TPF_MAX_COLS) cap /= 2;
+    return cap;
+}
 constexpr int TILE_NODES = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int N_XCD = 8;
@@ -121,7 +131,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
     // A operand (the entry's weight columns, <= 64 by construction of the plan) stays in registers for the
     // whole CSR walk: av[mt][kk] = W2p[pi(kk,g)][w_base + 16*mt + c]
     // MTMAX: the plan caps an entry at the largest power-of-two channel count whose [u][c] block fits 64 columns
-    constexpr int CAPC = NC > 32 ? 1 : NC > 16 ? 2 : NC > 8 ? 4 : NC > 4 ? 8 : NC > 2 ? 16 : NC > 1 ? 32 : 64;
+    constexpr int CAPC = cap_channels(NC);
     constexpr int MTMAX = (CAPC * NC + 15) / 16;
     f16x8 ah[MTMAX], al[MTMAX];
     float a_scale_inv;
@@ -445,7 +455,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const int u = lane & (cu - 1);
     const int g = lane >> 4, c = lane & 15;
     const int xcol = ge.x_off + u * G::D1;
-    constexpr int CAPC = NC > 32 ? 1 : NC > 16 ? 2 : NC > 8 ? 4 : NC > 4 ? 8 : NC > 2 ? 16 : NC > 1 ? 32 : 64;
+    constexpr int CAPC = cap_channels(NC);
     constexpr int MTMAX = (CAPC * NC + 15) / 16;
     const int stride = MT * 16 + 4;              // floats per edge row of the wave's weight tile
     f16x8 ah[MTMAX], al[MTMAX];
@@ -1130,6 +1140,7 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
     return MATTEN_OK;
 }
 
+extern "C" int matten_tp_max_cols(void) { return TPF_MAX_COLS; }
 extern "C" int matten_tp_lin2_group_nodes(void) { return LIN2_NODES; }
 extern "C" int matten_tp_lin2_t_wave_floats(void) { return LIN2_T_WAVE_FLOATS; }
 

@@ -32,6 +32,7 @@ _GROUP_SCHEMES = {
 }
 TP_GROUPS = _GROUP_SCHEMES[os.environ.get("MATTEN_TP_GROUPS", "A")]
 TP_MAX_COMBOS = 12
+TP_MAX_COLS = int(os.environ.get("MATTEN_TP_MAX_COLS", "64"))  # == matten_tp_max_cols() of the library (-DTPF_MAX_COLS)
 TP_KIND_STRIDE = 8
 
 ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
@@ -258,7 +259,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
             # channels per entry: a power of two <= 64 whose [u][c] weight block stays <= 64 columns, so the
             # fused kernel keeps the whole A operand (4 MFMA tiles x 8 k-steps) in registers
             cap = 64
-            while cap > 1 and cap * len(combos) > 64:
+            while cap > 1 and cap * len(combos) > TP_MAX_COLS:
                 cap //= 2
             for u0 in range(0, mul, cap):
                 mul_c = min(cap, mul - u0)
