@@ -62,9 +62,12 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_MAX_COLS
 #define TPF_MAX_COLS 64
 #endif
-__host__ __device__ constexpr int cap_channels(int nc) {
+#ifndef TPF_MAX_COLS_L0
+#define TPF_MAX_COLS_L0 96   // scalar input blocks (l1 = 0): the lightest kind has registers for a wider entry (16 channels)
+#endif
+__host__ __device__ constexpr int cap_channels(int l1, int nc) {
     int cap = 64;
-    while (cap > 1 && cap * nc > TPF_MAX_COLS) cap /= 2;
+    while (cap > 1 && cap * nc > (l1 == 0 ? TPF_MAX_COLS_L0 : TPF_MAX_COLS)) cap /= 2;
     return cap;
 }
 constexpr int TILE_NODES = 64;
@@ -131,7 +134,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
     // A operand (the entry's weight columns, <= 64 by construction of the plan) stays in registers for the
     // whole CSR walk: av[mt][kk] = W2p[pi(kk,g)][w_base + 16*mt + c]
     // MTMAX: the plan caps an entry at the largest power-of-two channel count whose [u][c] block fits 64 columns
-    constexpr int CAPC = cap_channels(NC);
+    constexpr int CAPC = cap_channels(L1, NC);
     constexpr int MTMAX = (CAPC * NC + 15) / 16;
     f16x8 ah[MTMAX], al[MTMAX];
     float a_scale_inv;
@@ -455,7 +458,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const int u = lane & (cu - 1);
     const int g = lane >> 4, c = lane & 15;
     const int xcol = ge.x_off + u * G::D1;
-    constexpr int CAPC = cap_channels(NC);
+    constexpr int CAPC = cap_channels(L1, NC);
     constexpr int MTMAX = (CAPC * NC + 15) / 16;
     const int stride = MT * 16 + 4;              // floats per edge row of the wave's weight tile
     f16x8 ah[MTMAX], al[MTMAX];
@@ -552,6 +555,8 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                 if (MTMAX == 1 || MT == 1) mfma_tiles<1>(ah, al, bh, bl, trow);
                 else if (MTMAX == 2 || MT == 2) mfma_tiles<(MTMAX < 2 ? MTMAX : 2)>(ah, al, bh, bl, trow);
                 else if (MTMAX == 3 || MT == 3) mfma_tiles<(MTMAX < 3 ? MTMAX : 3)>(ah, al, bh, bl, trow);
+                else if (MTMAX == 4 || MT == 4) mfma_tiles<(MTMAX < 4 ? MTMAX : 4)>(ah, al, bh, bl, trow);
+                else if (MTMAX == 5 || MT == 5) mfma_tiles<(MTMAX < 5 ? MTMAX : 5)>(ah, al, bh, bl, trow);
                 else mfma_tiles<MTMAX>(ah, al, bh, bl, trow);
 #else
                 if ((float)bh[0] == 12345.f) tile[c] = (float)bl[0];
@@ -1141,6 +1146,7 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
 }
 
 extern "C" int matten_tp_max_cols(void) { return TPF_MAX_COLS; }
+extern "C" int matten_tp_max_cols_l0(void) { return TPF_MAX_COLS_L0; }
 extern "C" int matten_tp_lin2_group_nodes(void) { return LIN2_NODES; }
 extern "C" int matten_tp_lin2_t_wave_floats(void) { return LIN2_T_WAVE_FLOATS; }
 

@@ -33,6 +33,7 @@ _GROUP_SCHEMES = {
 TP_GROUPS = _GROUP_SCHEMES[os.environ.get("MATTEN_TP_GROUPS", "A")]
 TP_MAX_COMBOS = 12
 TP_MAX_COLS = int(os.environ.get("MATTEN_TP_MAX_COLS", "64"))  # == matten_tp_max_cols() of the library (-DTPF_MAX_COLS)
+TP_MAX_COLS_L0 = int(os.environ.get("MATTEN_TP_MAX_COLS_L0", "96"))  # scalar input blocks (see plan_uvu); -DTPF_MAX_COLS_L0
 TP_KIND_STRIDE = 8
 
 ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
@@ -248,6 +249,20 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
     by_block: Dict[int, List[UVUPath]] = {}
     for p in paths:
         by_block.setdefault(p.i_in1, []).append(p)
+    # Scalar (l1 = 0) input blocks are the lightest kind and gain from wider entries (more channels share one matrix
+    # product and one staged row: -7 % on a layer with two such blocks) -- but only when the wide entries fill whole
+    # workgroups of four; a half-empty workgroup of loader-only waves costs more (measured, tools/tp_cols_ab.sh).
+    def _l0_entries(max_cols):
+        n = 0
+        for plist in by_block.values():
+            if plist[0].l1 == 0:
+                nc = sum(len(range(abs(0 - l2), min(4, l2) + 1)) for lo, hi in TP_GROUPS[0] for l2 in range(lo, hi + 1))
+                cap = 64
+                while cap > 1 and cap * nc > max_cols:
+                    cap //= 2
+                n += -(-plist[0].mul // cap)
+        return n
+    wide_l0 = TP_MAX_COLS_L0 > TP_MAX_COLS and _l0_entries(TP_MAX_COLS_L0) % 4 == 0 and _l0_entries(TP_MAX_COLS_L0) > 0
     for i_in1, plist in by_block.items():
         l1, mul = plist[0].l1, plist[0].mul
         d1 = 2 * l1 + 1
@@ -259,7 +274,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
             # channels per entry: a power of two <= 64 whose [u][c] weight block stays <= 64 columns, so the
             # fused kernel keeps the whole A operand (4 MFMA tiles x 8 k-steps) in registers
             cap = 64
-            while cap > 1 and cap * len(combos) > TP_MAX_COLS:
+            while cap > 1 and cap * len(combos) > (TP_MAX_COLS_L0 if (l1 == 0 and wide_l0) else TP_MAX_COLS):
                 cap //= 2
             for u0 in range(0, mul, cap):
                 mul_c = min(cap, mul - u0)
