@@ -854,6 +854,12 @@ def plan_conv_fused(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[ConvFu
     items, item_index = pack_lin2_items(slot_index, slots_np, chain_np)
     slot_recs, slot_items = merge_lin2_items(slot_index, slots_np, chain_np,
                                              {o_offs[io]: irreps_out[io].mul for io in range(len(irreps_out))})
+    # LDS of matten_tp_lin2: four wave regions + stage + the 8-node output tile + the work lists; wider layers than a
+    # workgroup can hold take the two-kernel path
+    ld = (irreps_out.dim + 23) // 32 * 32 + 8
+    lds_bytes = 4 * (4 * LIN2_T_WAVE_FLOATS + 2 * 16 * 68 + LIN2_GROUP_NODES * ld + 8 * len(slot_recs) + 4 * len(slot_items))
+    if lds_bytes > 64 * 1024:
+        return None
     return ConvFusedPlan(
         items=items, item_index=item_index, slot_recs=slot_recs, slot_items=slot_items,
         light_entries=light_entries, rounds=rounds, slot_index=slot_index,
