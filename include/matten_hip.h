@@ -214,6 +214,7 @@ int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const flo
  * ------------------------------------------------------------------------------------------ */
 int matten_tp_max_cols(void);   /* weight columns (mul * couplings) a group entry of matten_tp_fused / matten_tp_lin2 may have */
 int matten_tp_max_cols_l0(void);   /* the same for entries of scalar (l1 = 0) input blocks */
+int matten_tp_max_cols_l1(void);   /* ... and of vector (l1 = 1) input blocks */
 int matten_tp_lin2_group_nodes(void);
 int matten_tp_lin2_t_wave_floats(void);
 int matten_tp_lin2(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,

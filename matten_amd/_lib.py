@@ -34,6 +34,7 @@ SIGNATURES = {
     "matten_radial_hidden": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, c_int, P, P]),
     "matten_tp_max_cols": (c_int, []),
     "matten_tp_max_cols_l0": (c_int, []),
+    "matten_tp_max_cols_l1": (c_int, []),
     "matten_tp_lin2_group_nodes": (c_int, []),
     "matten_tp_lin2_t_wave_floats": (c_int, []),
     "matten_tp_lin2": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, P, P, c_int64,

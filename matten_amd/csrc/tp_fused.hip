@@ -65,9 +65,12 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_MAX_COLS_L0
 #define TPF_MAX_COLS_L0 96   // scalar input blocks (l1 = 0): the lightest kind has registers for a wider entry (16 channels)
 #endif
+#ifndef TPF_MAX_COLS_L1
+#define TPF_MAX_COLS_L1 TPF_MAX_COLS   // vector (l1 = 1) input blocks (experiment: 112 = 16 channels x 7 couplings)
+#endif
 __host__ __device__ constexpr int cap_channels(int l1, int nc) {
     int cap = 64;
-    while (cap > 1 && cap * nc > (l1 == 0 ? TPF_MAX_COLS_L0 : TPF_MAX_COLS)) cap /= 2;
+    while (cap > 1 && cap * nc > (l1 == 0 ? TPF_MAX_COLS_L0 : l1 == 1 ? TPF_MAX_COLS_L1 : TPF_MAX_COLS)) cap /= 2;
     return cap;
 }
 constexpr int TILE_NODES = 64;
@@ -557,6 +560,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                 else if (MTMAX == 3 || MT == 3) mfma_tiles<(MTMAX < 3 ? MTMAX : 3)>(ah, al, bh, bl, trow);
                 else if (MTMAX == 4 || MT == 4) mfma_tiles<(MTMAX < 4 ? MTMAX : 4)>(ah, al, bh, bl, trow);
                 else if (MTMAX == 5 || MT == 5) mfma_tiles<(MTMAX < 5 ? MTMAX : 5)>(ah, al, bh, bl, trow);
+                else if (MTMAX == 6 || MT == 6) mfma_tiles<(MTMAX < 6 ? MTMAX : 6)>(ah, al, bh, bl, trow);
                 else mfma_tiles<MTMAX>(ah, al, bh, bl, trow);
 #else
                 if ((float)bh[0] == 12345.f) tile[c] = (float)bl[0];
@@ -1147,6 +1151,7 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
 
 extern "C" int matten_tp_max_cols(void) { return TPF_MAX_COLS; }
 extern "C" int matten_tp_max_cols_l0(void) { return TPF_MAX_COLS_L0; }
+extern "C" int matten_tp_max_cols_l1(void) { return TPF_MAX_COLS_L1; }
 extern "C" int matten_tp_lin2_group_nodes(void) { return LIN2_NODES; }
 extern "C" int matten_tp_lin2_t_wave_floats(void) { return LIN2_T_WAVE_FLOATS; }
 

@@ -340,8 +340,9 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
 
     if lib.matten_tp_tile_nodes() != TP_TILE_NODES:
         raise _lib.MattenHipError("plan.TP_TILE_NODES does not match the library's node tile")
-    from .plan import TP_MAX_COLS, TP_MAX_COLS_L0
-    if lib.matten_tp_max_cols() != TP_MAX_COLS or lib.matten_tp_max_cols_l0() != TP_MAX_COLS_L0:
+    from .plan import TP_MAX_COLS, TP_MAX_COLS_L0, TP_MAX_COLS_L1
+    if (lib.matten_tp_max_cols() != TP_MAX_COLS or lib.matten_tp_max_cols_l0() != TP_MAX_COLS_L0
+            or lib.matten_tp_max_cols_l1() != TP_MAX_COLS_L1):
         raise _lib.MattenHipError("plan.TP_MAX_COLS does not match the library's entry width (-DTPF_MAX_COLS)")
     x = _need_rows(x, torch.float32, "node_features")  # a column slice is fine: d_in below is the row stride
     h2p = _need(h2p, torch.float16, "h2s")

@@ -34,6 +34,7 @@ TP_GROUPS = _GROUP_SCHEMES[os.environ.get("MATTEN_TP_GROUPS", "A")]
 TP_MAX_COMBOS = 12
 TP_MAX_COLS = int(os.environ.get("MATTEN_TP_MAX_COLS", "64"))  # == matten_tp_max_cols() of the library (-DTPF_MAX_COLS)
 TP_MAX_COLS_L0 = int(os.environ.get("MATTEN_TP_MAX_COLS_L0", "96"))  # scalar input blocks (see plan_uvu); -DTPF_MAX_COLS_L0
+TP_MAX_COLS_L1 = int(os.environ.get("MATTEN_TP_MAX_COLS_L1", str(TP_MAX_COLS)))  # vector input blocks; -DTPF_MAX_COLS_L1
 TP_KIND_STRIDE = 8
 
 ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
@@ -249,20 +250,37 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
     by_block: Dict[int, List[UVUPath]] = {}
     for p in paths:
         by_block.setdefault(p.i_in1, []).append(p)
-    # Scalar (l1 = 0) input blocks are the lightest kind and gain from wider entries (more channels share one matrix
-    # product and one staged row: -7 % on a layer with two such blocks) -- but only when the wide entries fill whole
-    # workgroups of four; a half-empty workgroup of loader-only waves costs more (measured, tools/tp_cols_ab.sh).
-    def _l0_entries(max_cols):
-        n = 0
+    # Scalar and vector (l1 <= 1) input blocks are the light kinds and gain from wider entries -- 16 instead of 8
+    # channels share one matrix product, one staged row and one chunk's fixed costs (-6 % on the l1 = 0 kind) -- but
+    # only when the entries of every lanes-per-node class fill whole workgroups of four: a workgroup padded with
+    # loader-only waves costs more than the width gains (measured, tools/tp_cols_ab.sh).  Choose per layer.
+    def _cap(l1, n_combos, wide0, wide1):
+        limit = TP_MAX_COLS_L0 if (l1 == 0 and wide0) else TP_MAX_COLS_L1 if (l1 == 1 and wide1) else TP_MAX_COLS
+        cap = 64
+        while cap > 1 and cap * n_combos > limit:
+            cap //= 2
+        return cap
+
+    def _padding(wide0, wide1):
+        """loader-only waves per node tile for this choice"""
+        per_class: Dict[int, int] = {}
         for plist in by_block.values():
-            if plist[0].l1 == 0:
-                nc = sum(len(range(abs(0 - l2), min(4, l2) + 1)) for lo, hi in TP_GROUPS[0] for l2 in range(lo, hi + 1))
-                cap = 64
-                while cap > 1 and cap * nc > max_cols:
-                    cap //= 2
-                n += -(-plist[0].mul // cap)
-        return n
-    wide_l0 = TP_MAX_COLS_L0 > TP_MAX_COLS and _l0_entries(TP_MAX_COLS_L0) % 4 == 0 and _l0_entries(TP_MAX_COLS_L0) > 0
+            l1_, mul_ = plist[0].l1, plist[0].mul
+            for lo, hi in TP_GROUPS[l1_]:
+                combos_ = [(l2, l3) for l2 in range(lo, hi + 1) for l3 in range(abs(l1_ - l2), min(4, l1_ + l2) + 1)]
+                if not any(lo <= p_.l2 <= hi for p_ in plist):
+                    continue
+                cap_ = _cap(l1_, len(combos_), wide0, wide1)
+                for u0 in range(0, mul_, cap_):
+                    cu = max(1, (min(cap_, mul_ - u0) - 1).bit_length())
+                    per_class[cu] = per_class.get(cu, 0) + 1
+        return sum((-n) % 4 * (-(-TP_TILE_NODES // max(1, 64 >> cu))) for cu, n in per_class.items())
+
+    choices = [(w0, w1) for w0 in ((True, False) if TP_MAX_COLS_L0 > TP_MAX_COLS else (False,))
+               for w1 in ((True, False) if TP_MAX_COLS_L1 > TP_MAX_COLS else (False,))]
+    wide_l0, wide_l1 = min(choices, key=lambda c: (_padding(*c), -int(c[0]) - int(c[1])))
+    if _padding(wide_l0, wide_l1) > _padding(False, False):
+        wide_l0 = wide_l1 = False
     for i_in1, plist in by_block.items():
         l1, mul = plist[0].l1, plist[0].mul
         d1 = 2 * l1 + 1
@@ -273,9 +291,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                 continue
             # channels per entry: a power of two <= 64 whose [u][c] weight block stays <= 64 columns, so the
             # fused kernel keeps the whole A operand (4 MFMA tiles x 8 k-steps) in registers
-            cap = 64
-            while cap > 1 and cap * len(combos) > (TP_MAX_COLS_L0 if (l1 == 0 and wide_l0) else TP_MAX_COLS):
-                cap //= 2
+            cap = _cap(l1, len(combos), wide_l0, wide_l1)
             for u0 in range(0, mul, cap):
                 mul_c = min(cap, mul - u0)
                 # at least two lanes per node (a multiplicity-1 entry idles one of them): at most 32 nodes, i.e. two
