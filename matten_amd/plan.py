@@ -254,14 +254,14 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
     # channels share one matrix product, one staged row and one chunk's fixed costs (-6 % on the l1 = 0 kind) -- but
     # only when the entries of every lanes-per-node class fill whole workgroups of four: a workgroup padded with
     # loader-only waves costs more than the width gains (measured, tools/tp_cols_ab.sh).  Choose per layer.
-    def _cap(l1, n_combos, wide0, wide1):
-        limit = TP_MAX_COLS_L0 if (l1 == 0 and wide0) else TP_MAX_COLS_L1 if (l1 == 1 and wide1) else TP_MAX_COLS
+    def _cap(l1, n_combos, cols0, cols1):
+        limit = cols0 if l1 == 0 else cols1 if l1 == 1 else TP_MAX_COLS
         cap = 64
         while cap > 1 and cap * n_combos > limit:
             cap //= 2
         return cap
 
-    def _padding(wide0, wide1):
+    def _padding(cols0, cols1):
         """loader-only waves per node tile for this choice"""
         per_class: Dict[int, int] = {}
         for plist in by_block.values():
@@ -270,17 +270,19 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                 combos_ = [(l2, l3) for l2 in range(lo, hi + 1) for l3 in range(abs(l1_ - l2), min(4, l1_ + l2) + 1)]
                 if not any(lo <= p_.l2 <= hi for p_ in plist):
                     continue
-                cap_ = _cap(l1_, len(combos_), wide0, wide1)
+                cap_ = _cap(l1_, len(combos_), cols0, cols1)
                 for u0 in range(0, mul_, cap_):
                     cu = max(1, (min(cap_, mul_ - u0) - 1).bit_length())
                     per_class[cu] = per_class.get(cu, 0) + 1
         return sum((-n) % 4 * (-(-TP_TILE_NODES // max(1, 64 >> cu))) for cu, n in per_class.items())
 
-    choices = [(w0, w1) for w0 in ((True, False) if TP_MAX_COLS_L0 > TP_MAX_COLS else (False,))
-               for w1 in ((True, False) if TP_MAX_COLS_L1 > TP_MAX_COLS else (False,))]
-    wide_l0, wide_l1 = min(choices, key=lambda c: (_padding(*c), -int(c[0]) - int(c[1])))
-    if _padding(wide_l0, wide_l1) > _padding(False, False):
-        wide_l0 = wide_l1 = False
+    # fewest loader-only waves first, then the widest entries.  (Going NARROWER than the general width to fill the
+    # workgroups of a lone 16-channel scalar block -- four 4-channel entries in the first conv layer -- was measured
+    # too: 0.173 -> 0.185 ms; half-idle workgroups of 8-channel entries are still faster.)
+    cands0 = sorted({TP_MAX_COLS_L0, TP_MAX_COLS}, reverse=True)
+    cands1 = sorted({TP_MAX_COLS_L1, TP_MAX_COLS}, reverse=True)
+    cols_l0, cols_l1 = min(((c0, c1) for c0 in cands0 for c1 in cands1),
+                           key=lambda c: (_padding(*c), -c[0] - c[1]))
     for i_in1, plist in by_block.items():
         l1, mul = plist[0].l1, plist[0].mul
         d1 = 2 * l1 + 1
@@ -291,7 +293,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                 continue
             # channels per entry: a power of two <= 64 whose [u][c] weight block stays <= 64 columns, so the
             # fused kernel keeps the whole A operand (4 MFMA tiles x 8 k-steps) in registers
-            cap = _cap(l1, len(combos), wide_l0, wide_l1)
+            cap = _cap(l1, len(combos), cols_l0, cols_l1)
             for u0 in range(0, mul, cap):
                 mul_c = min(cap, mul - u0)
                 # at least two lanes per node (a multiplicity-1 entry idles one of them): at most 32 nodes, i.e. two
