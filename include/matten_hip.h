@@ -163,7 +163,10 @@ int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t 
  *   w2p[32, w_pad]: last layer weights pre-scaled (1/sqrt(32) * normalize2mom(silu)), columns in the
  *                   fused [entry][u][coupling] order of group_entries, w_pad >= w_cols + 16
  *   group_entries: as matten_tp_blocks, with mul * couplings <= 64 weight columns per entry
- *   unit_map[units_per_tile]: wave index inside a node tile -> entry << 8 | node group (of 64 >> cu_log2 nodes); any
+ *   unit_map[units_per_tile]: wave index inside a node tile -> flags | entry << 8 | node group (of 64 >> cu_log2 nodes);
+ *                   flags: bit 24 = the unit's workgroup (four consecutive units) shares an LDS stage: same node
+ *                   group and lanes per node -- or, with bit 26 (paired), units 0,1 on node group r and units 2,3 the
+ *                   same two entries on r + 1; bit 25 = loader-only unit (feeds the stage, contracts nothing).  Any
  *                   bijection is valid, the host orders it node group first (plan.fused_unit_map) so the waves of a
  *                   workgroup read the same hidden-feature / harmonics rows
  *   a_split / a_scale_inv (both or neither; NULL: the kernel splits w2p itself, ~400 instructions per wave):

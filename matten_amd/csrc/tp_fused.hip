@@ -32,6 +32,8 @@
 // h2s layout: [E, 2, 32] fp16 (128 B per edge): piece 0 = hi, piece 1 = lo; column g*8 + kk of a piece  <->  hidden
 // feature pi(kk,g) = 16 (kk>>2) + 4 g + (kk&3): exactly the registers lane group g of the hidden-layer kernel
 // holds, and the 8 K-slots lane group g feeds to the MFMA (A rows follow the same pi).
+#include <type_traits>
+
 #include "cg_gen.h"
 #include "common.h"
 #include "sh.h"
@@ -360,6 +362,78 @@ struct StageLoader {
     }
 };
 
+// PAIRED workgroups: a class of entries that leaves only TWO for a workgroup would idle half of its waves as
+// loader-only units.  Instead waves 0, 1 take the two entries on node group r and waves 2, 3 the same two entries on node
+// group r + 1; the stage then holds 32 rows (rows 0-15: the chunk of group r, 16-31: of group r + 1) and every thread
+// fetches one piece of each half.  The two halves' CSR segments are exchanged through LDS once per unit.
+constexpr int PAIR_INFO_INTS = 2 * 16 * 2 + 2;   // [group][node][beg, deg] + [group] max degree
+struct PairLoader {
+    const char* base;
+    const char* safe;
+    int64_t row_bytes;
+    float* st_w;
+    int beg_ld[2], deg_ld[2], so_ld;
+    int CH, maxdeg;
+    f32x4 pf[2];
+
+    __device__ __forceinline__ void init(const Args& a, float* stage, int* info, int cu_log2, int beg, int deg_node,
+                                         int my_maxdeg) {
+        const int npw = 64 >> cu_log2;                     // <= 16 here
+        const int ch_log2 = 4 - (6 - cu_log2);
+        CH = 1 << ch_log2;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if ((wave & 1) == 0 && (lane & ((1 << cu_log2) - 1)) == 0) {
+            info[((wave >> 1) * 16 + (lane >> cu_log2)) * 2] = beg;
+            info[((wave >> 1) * 16 + (lane >> cu_log2)) * 2 + 1] = deg_node;
+            if (lane == 0) info[2 * 16 * 2 + (wave >> 1)] = my_maxdeg;
+        }
+        __syncthreads();
+        maxdeg = max(info[2 * 16 * 2], info[2 * 16 * 2 + 1]);
+        const int piece = threadIdx.x & 15;
+        base = piece < 8 ? reinterpret_cast<const char*>(a.h2s) + piece * 16
+                         : reinterpret_cast<const char*>(a.sh) + (piece - 8) * 16;
+        row_bytes = piece < 8 ? (int64_t)(2 * HID * sizeof(_Float16)) : (int64_t)a.sh_stride * 4;
+        safe = reinterpret_cast<const char*>(a.w2p);
+        const int n = (int)(threadIdx.x >> 4);
+        st_w = stage + n * STAGE_ROW + piece * 4;
+        const int jn = (n >> ch_log2) & (npw - 1);
+        so_ld = n & (CH - 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            beg_ld[t] = info[(t * 16 + jn) * 2];
+            deg_ld[t] = info[(t * 16 + jn) * 2 + 1];
+            pf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ void issue(int s0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            pf[t] = *reinterpret_cast<const f32x4*>(
+                deg_ld[t] > 0 ? base + (int64_t)(beg_ld[t] + min(s0 + so_ld, deg_ld[t] - 1)) * row_bytes : safe);
+    }
+    __device__ __forceinline__ void publish(int buf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            *reinterpret_cast<f32x4*>(st_w + buf * (32 * STAGE_ROW) + 16 * t * STAGE_ROW) = pf[t];
+    }
+};
+
+// loader-only unit of a paired workgroup
+__device__ __forceinline__ void run_loader_only_paired(const Args& a, int cu_log2, float* __restrict__ stage, int beg,
+                                                       int deg_node, int maxdeg) {
+    PairLoader ld;
+    ld.init(a, stage, reinterpret_cast<int*>(stage + STAGE_TOTAL_FLOATS), cu_log2, beg, deg_node, maxdeg);
+    ld.issue(0);
+    ld.publish(0);
+    __syncthreads();
+    int buf = 0;
+    for (int s0 = 0; s0 < ld.maxdeg; s0 += ld.CH, buf ^= 1) {
+        ld.issue(s0 + ld.CH);
+        ld.publish(buf ^ 1);
+        __syncthreads();
+    }
+}
+
 // a unit that only feeds the stage (same barrier sequence as run_group_shared)
 template <int TT>
 __device__ __forceinline__ void run_loader_only_t(const Args& a, int cu_log2, float* __restrict__ stage, int beg,
@@ -437,10 +511,13 @@ struct TwoDeepOk { static constexpr bool value = L1 == 0 || (L1 == 1 && GI == 0)
 
 // TWO_DEEP is a template parameter, not a run-time flag: with both gather schedules in one instantiation the compiler
 // reconciled their register assignments with 50-90 v_mov per CHUNK (60 % of the l1 = 0 kind's vector instructions).
-template <int L1, int GI, int TT, bool TWO_DEEP, class Epilogue>
+template <int L1, int GI, int TT, bool TWO_DEEP, bool PAIRED, class Epilogue>
 __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry& ge, float* __restrict__ tile,
                                                  float* __restrict__ stage, int entry, int node, int lane, bool valid,
                                                  int beg, int deg_node, int maxdeg, const Epilogue& epi) {
+    static_assert(!PAIRED || TT == 1, "paired workgroups stage 2 x 16 rows");
+    const int row0 = PAIRED ? 16 * (int)(threadIdx.x >> 7) : 0;       // this wave's half of a paired stage
+    constexpr int STAGE_BUF = (PAIRED ? 32 : 16 * TT) * STAGE_ROW;    // floats per stage buffer
     const int deg = valid ? deg_node : 0;
     using G = matten::Group<L1, GI>;
     constexpr int NC = G::NC;
@@ -508,8 +585,13 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         }
     }
 
-    StageLoader<TT> ld;
-    ld.init(a, stage, cu_log2, beg, deg_node);
+    typename std::conditional<PAIRED, PairLoader, StageLoader<TT>>::type ld;
+    if constexpr (PAIRED) {
+        ld.init(a, stage, reinterpret_cast<int*>(stage + STAGE_TOTAL_FLOATS), cu_log2, beg, deg_node, maxdeg);
+        maxdeg = ld.maxdeg;   // both node groups walk the same number of chunks (one barrier sequence)
+    } else {
+        ld.init(a, stage, cu_log2, beg, deg_node);
+    }
     ld.issue(0);
 
     // Neighbour gather.  Two-slot chunks (8 nodes per wave: short steps) keep TWO rows in flight, one per slot of the
@@ -546,7 +628,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         // latency chain, and every cycle another wave's contraction delays it is added to this wave's chunk (-1 %)
         __builtin_amdgcn_s_setprio(TPF_SETPRIO);
         ld.issue(s0 + CH);
-        const float* sb = stage + buf * (16 * TT * STAGE_ROW);
+        const float* sb = stage + buf * STAGE_BUF + row0 * STAGE_ROW;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             {
@@ -636,9 +718,10 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 
 #define MATTEN_GROUP_CASE_SHARED(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): \
-        if (nodes_per_wave > 16) run_group_shared<L1, GI, 2, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
-        else if (TwoDeepOk<L1, GI>::value && nodes_per_wave == 8) run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
-        else run_group_shared<L1, GI, 1, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
+        if (paired) run_group_shared<L1, GI, 1, false, true>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
+        else if (nodes_per_wave > 16) run_group_shared<L1, GI, 2, false, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
+        else if (TwoDeepOk<L1, GI>::value && nodes_per_wave == 8) run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
+        else run_group_shared<L1, GI, 1, false, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
         break;
 
 #define MATTEN_GROUP_CASE(L1, GI) \
@@ -698,8 +781,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
 #endif
     if (shared_stage) {
         float* stage = lds + WAVES_PER_BLOCK * a.lds_per_wave;
+        const bool paired = (um >> 26) & 1;   // uniform over the workgroup: two entries x two node groups (PairLoader)
         if ((um >> 25) & 1) {  // loader-only unit: fills the workgroup up to four waves
-            run_loader_only(a, cu_log2, stage, beg, deg, maxdeg);
+            if (paired) run_loader_only_paired(a, cu_log2, stage, beg, deg, maxdeg);
+            else run_loader_only(a, cu_log2, stage, beg, deg, maxdeg);
             return;
         }
         switch (ge.kind) {
@@ -750,7 +835,7 @@ struct Lin2Args {
 };
 
 #define MATTEN_LIN2_CASE(L1, GI) \
-    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreLds{tile}); break;
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value, false>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreLds{tile}); break;
 
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_lin2_kernel(Args a, Lin2Args la,
                                                                                       const GroupEntry* __restrict__ entries) {
@@ -1134,7 +1219,7 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
     if (!x || !h2s || !w2p || !sh_sorted || !rowptr || !src_sorted || !group_entries || !unit_map || !agg)
         return MATTEN_EINVAL;
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
-    const size_t lds = sizeof(float) * ((size_t)lds_floats_per_wave * WAVES_PER_BLOCK + STAGE_TOTAL_FLOATS);
+    const size_t lds = sizeof(float) * ((size_t)lds_floats_per_wave * WAVES_PER_BLOCK + STAGE_TOTAL_FLOATS + PAIR_INFO_INTS);
     if (lds > 64 * 1024) return MATTEN_EINVAL;
     if ((a_split == nullptr) != (a_scale_inv == nullptr)) return MATTEN_EINVAL;
     Args a{x, (const _Float16*)h2s, w2p, (const _Float16*)a_split, a_scale_inv, sh_sorted, rowptr, src_sorted, num_neigh, agg, (int)d_in, (int)w_pad, (int)sh_stride,

@@ -47,22 +47,20 @@ LIN2_GROUP_NODES = 8
 
 FUSED_UNIT_SHARED = 1 << 24       # the unit's workgroup stages hidden features / harmonics once for its four waves
 FUSED_UNIT_LOADER_ONLY = 1 << 25  # padding unit of a shared workgroup: feeds the stage, contracts nothing
+FUSED_UNIT_PAIRED = 1 << 26       # shared workgroup of TWO entries on TWO consecutive node groups (waves 0,1 | 2,3)
 
 
-def fused_unit_map(group_entries, order: Optional[str] = None) -> np.ndarray:
-    """Wave (unit) index inside a node tile -> packed (flags | entry << 8 | node group) for matten_tp_fused.
-
-    'node' order (default): runs of consecutive entries with the same lanes-per-node are sorted by kind, cut into
-    workgroups of at most four entries and walked node group first, so the four waves of a workgroup (units 4b..4b+3)
-    contract different entries of the SAME destination nodes and fetch each hidden-feature / harmonics row once per
-    workgroup through a double-buffered LDS stage (FUSED_UNIT_SHARED, see tp_fused.hip).  Workgroups with fewer than
-    four entries are filled with FUSED_UNIT_LOADER_ONLY units.  Entries with one lane per node (64 nodes per wave)
-    and the 'entry' order (MATTEN_FUSED_UNIT_ORDER=entry, A/B harness) use the unshared path, entry-major."""
+def fused_workgroups(group_entries, order: Optional[str] = None):
+    """How matten_tp_fused's entries are cut into workgroups: -> list of (cu_log2, entry ids, mode).
+    Entries with equal lanes per node, sorted by kind (stable: kind-homogeneous workgroups where possible), are taken
+    four at a time: mode "shared" (the four waves = four entries on ONE node group, hidden features / harmonics staged
+    once per workgroup; fewer than four entries are padded with loader-only waves).  What is left over when the class
+    has at most 16 nodes per wave goes, two entries at a time, into mode "paired": waves 0, 1 = the two entries on node
+    group r, waves 2, 3 = the same entries on node group r + 1 (a lone entry leaves one loader-only wave per node
+    group instead of three).  "plain": no sharing (one lane per node, or the 'entry' order of the A/B harness)."""
     order = order or os.environ.get("MATTEN_FUSED_UNIT_ORDER", "node")
     ent = np.asarray(group_entries).reshape(-1, 32)
-    assert len(ent) < 65536
-    shared_units: List[int] = []
-    plain_units: List[int] = []
+    out = []
     i = 0
     while i < len(ent):
         j = i
@@ -70,20 +68,50 @@ def fused_unit_map(group_entries, order: Optional[str] = None) -> np.ndarray:
             j += 1
         cu_log2 = int(ent[i][3])
         npw = max(1, 64 >> cu_log2)
-        groups = -(-TP_TILE_NODES // npw)
-        assert groups < 256
-        run = sorted(range(i, j), key=lambda e: int(ent[e][0]))  # stable: kind-homogeneous workgroups where possible
-        if order == "node" and cu_log2 >= 1:
+        run = sorted(range(i, j), key=lambda e: int(ent[e][0]))
+        if order != "node" or cu_log2 < 1:
+            out.append((cu_log2, run, "plain"))
+        elif npw <= 16 and os.environ.get("MATTEN_FUSED_PAIRED", "1") != "0":
+            n4 = len(run) // 4 * 4
+            for k in range(0, n4, 4):
+                out.append((cu_log2, run[k:k + 4], "shared"))
+            rest = run[n4:]
+            if len(rest) == 3:
+                out.append((cu_log2, rest, "shared"))
+            elif rest:
+                out.append((cu_log2, rest, "paired"))
+        else:
             nblk = -(-len(run) // 4)
             cuts = [round(k * len(run) / nblk) for k in range(nblk + 1)]
-            for r in range(groups):
-                for k in range(nblk):
-                    blk = run[cuts[k]:cuts[k + 1]]
-                    shared_units += [FUSED_UNIT_SHARED | (e << 8) | r for e in blk]
-                    shared_units += [FUSED_UNIT_SHARED | FUSED_UNIT_LOADER_ONLY | (blk[-1] << 8) | r] * (4 - len(blk))
-        else:
-            plain_units += [(e << 8) | r for e in run for r in range(groups)]
+            for k in range(nblk):
+                out.append((cu_log2, run[cuts[k]:cuts[k + 1]], "shared"))
         i = j
+    return out
+
+
+def fused_unit_map(group_entries, order: Optional[str] = None) -> np.ndarray:
+    """Wave (unit) index inside a node tile -> packed (flags | entry << 8 | node group) for matten_tp_fused; four
+    consecutive units are one workgroup (fused_workgroups).  Shared / paired workgroups come first, node group major."""
+    ent = np.asarray(group_entries).reshape(-1, 32)
+    assert len(ent) < 65536
+    shared_units: List[int] = []
+    plain_units: List[int] = []
+    for cu_log2, blk, mode in fused_workgroups(ent, order):
+        groups = -(-TP_TILE_NODES // max(1, 64 >> cu_log2))
+        assert groups < 256
+        if mode == "shared":
+            for r in range(groups):
+                shared_units += [FUSED_UNIT_SHARED | (e << 8) | r for e in blk]
+                shared_units += [FUSED_UNIT_SHARED | FUSED_UNIT_LOADER_ONLY | (blk[-1] << 8) | r] * (4 - len(blk))
+        elif mode == "paired":
+            assert groups % 2 == 0 and 1 <= len(blk) <= 2
+            flags = FUSED_UNIT_SHARED | FUSED_UNIT_PAIRED
+            for r in range(0, groups, 2):
+                for rr in (r, r + 1):
+                    shared_units += [flags | (e << 8) | rr for e in blk]
+                    shared_units += [flags | FUSED_UNIT_LOADER_ONLY | (blk[-1] << 8) | rr] * (2 - len(blk))
+        else:
+            plain_units += [(e << 8) | r for e in blk for r in range(groups)]
     return np.array(shared_units + plain_units, dtype=np.int64).astype(np.int32)
 
 
@@ -274,7 +302,15 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                 for u0 in range(0, mul_, cap_):
                     cu = max(1, (min(cap_, mul_ - u0) - 1).bit_length())
                     per_class[cu] = per_class.get(cu, 0) + 1
-        return sum((-n) % 4 * (-(-TP_TILE_NODES // max(1, 64 >> cu))) for cu, n in per_class.items())
+        idle = 0
+        for cu, n in per_class.items():
+            npw_ = max(1, 64 >> cu)
+            groups_ = -(-TP_TILE_NODES // npw_)
+            if npw_ <= 16:      # leftovers of two pair up over two node groups (fused_workgroups)
+                idle += {0: 0, 1: 1, 2: 0, 3: 1}[n % 4] * groups_
+            else:
+                idle += (-n) % 4 * groups_
+        return idle
 
     # fewest loader-only waves first, then the widest entries.  (Going NARROWER than the general width to fill the
     # workgroups of a lone 16-channel scalar block -- four 4-channel entries in the first conv layer -- was measured

@@ -319,7 +319,8 @@ def test_dataset_json_reader_matches_oracle_reader(golden_dir):
 
 def test_fused_unit_map_covers_every_entry_and_node_group_once():
     """plan.fused_unit_map: every (entry, node group) appears exactly once as a working unit; shared workgroups
-    (four consecutive units) are homogeneous in node group and lanes-per-node and padded with loader-only units."""
+    (four consecutive units) are homogeneous in node group and lanes-per-node and padded with loader-only units;
+    paired workgroups hold two entries on two consecutive node groups."""
     from matten_amd import plan as mp
     from matten_amd.o3 import Irreps
 
@@ -339,7 +340,14 @@ def test_fused_unit_map_covers_every_entry_and_node_group_once():
             assert n_shared % 4 == 0 and all(shared[:n_shared]) and not any(shared[n_shared:])
             for b in range(0, n_shared, 4):
                 blk = [int(v) for v in m[b:b + 4]]
-                assert len({v & 255 for v in blk}) == 1
+                if blk[0] & mp.FUSED_UNIT_PAIRED:   # two entries x two consecutive node groups: waves 0,1 | 2,3
+                    assert all(v & mp.FUSED_UNIT_PAIRED for v in blk)
+                    r = blk[0] & 255
+                    assert [v & 255 for v in blk] == [r, r, r + 1, r + 1] and r % 2 == 0
+                    assert (blk[0] >> 8 & 0xFFFF) == (blk[2] >> 8 & 0xFFFF) and (blk[1] >> 8 & 0xFFFF) == (blk[3] >> 8 & 0xFFFF)
+                    assert max(1, 64 >> int(p.group_entries[blk[0] >> 8 & 0xFFFF][3])) <= 16
+                else:
+                    assert len({v & 255 for v in blk}) == 1
                 assert len({int(p.group_entries[v >> 8 & 0xFFFF][3]) for v in blk}) == 1
                 assert int(p.group_entries[blk[0] >> 8 & 0xFFFF][3]) >= 1
                 assert not blk[0] & mp.FUSED_UNIT_LOADER_ONLY
