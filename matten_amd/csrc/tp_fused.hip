@@ -68,8 +68,8 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #define TPF_MAX_COLS_L0 96   // scalar input blocks (l1 = 0): the lightest kind has registers for a wider entry (16 channels)
 #endif
 #ifndef TPF_MAX_COLS_L1
-#define TPF_MAX_COLS_L1 TPF_MAX_COLS   // vector (l1 = 1) input blocks (experiment: 112 = 16 channels x 7 couplings)
-#endif
+#define TPF_MAX_COLS_L1 TPF_MAX_COLS   // vector (l1 = 1) input blocks; 7 couplings with l2 <= 2 (112 columns for 16 channels:
+#endif                                 // measured, spills), 5 with l2 = 3, 4 (80 columns)
 __host__ __device__ constexpr int cap_channels(int l1, int nc) {
     int cap = 64;
     while (cap > 1 && cap * nc > (l1 == 0 ? TPF_MAX_COLS_L0 : l1 == 1 ? TPF_MAX_COLS_L1 : TPF_MAX_COLS)) cap /= 2;

@@ -61,14 +61,12 @@ def fused_workgroups(group_entries, order: Optional[str] = None):
     order = order or os.environ.get("MATTEN_FUSED_UNIT_ORDER", "node")
     ent = np.asarray(group_entries).reshape(-1, 32)
     out = []
-    i = 0
-    while i < len(ent):
-        j = i
-        while j < len(ent) and ent[j][3] == ent[i][3]:
-            j += 1
-        cu_log2 = int(ent[i][3])
+    classes: Dict[int, List[int]] = {}
+    for e in range(len(ent)):                      # classes by lanes per node, in order of first appearance
+        classes.setdefault(int(ent[e][3]), []).append(e)
+    for cu_log2, members in classes.items():
         npw = max(1, 64 >> cu_log2)
-        run = sorted(range(i, j), key=lambda e: int(ent[e][0]))
+        run = sorted(members, key=lambda e: int(ent[e][0]))
         if order != "node" or cu_log2 < 1:
             out.append((cu_log2, run, "plain"))
         elif npw <= 16 and os.environ.get("MATTEN_FUSED_PAIRED", "1") != "0":
@@ -85,7 +83,6 @@ def fused_workgroups(group_entries, order: Optional[str] = None):
             cuts = [round(k * len(run) / nblk) for k in range(nblk + 1)]
             for k in range(nblk):
                 out.append((cu_log2, run[cuts[k]:cuts[k + 1]], "shared"))
-        i = j
     return out
 
 
