@@ -79,7 +79,8 @@ int matten_species_embed(const int64_t* atomic_numbers, int64_t n_nodes, const i
  * Sorted-order outputs (consumed by the kernels below; e = sorted position, o = perm[e]):
  *   geom_sorted[E,4] = (vx, vy, vz, |v|)
  *   sh_sorted[E, sh_stride]   real SH of v/|v| in the first (lmax+1)^2 columns, l-major, m=-l..l,
- *                             'component' normalised; sh_stride >= (lmax+1)^2 (32 keeps rows on 128-B lines)
+ *                             'component' normalised; sh_stride >= (lmax+1)^2 (32 keeps rows on 128-B lines);
+ *                             the remaining columns of every row are written as zeros (no pre-clearing needed)
  * Optional original-order outputs for the backbone's data dict (NULL to skip):
  *   edge_vectors[E,3], edge_lengths[E], edge_attrs[E,(lmax+1)^2], edge_embedding[E,nb]
  * cell is [B,3,3] (rows = lattice vectors) or NULL; n_cells==1 uses cell 0 for every edge.

@@ -38,8 +38,20 @@ __global__ void edge_geom_kernel(const float* __restrict__ pos, const int64_t* _
 
     float y[SH];
     matten::real_sh<LMAX>(vx, vy, vz, len, y);
+    // the whole padded row, zeros included: the caller hands over uninitialised memory
+    if (sh_stride == 32) {  // one 128-byte line per edge as eight 16-byte stores
+        float4* row = reinterpret_cast<float4*>(sh_sorted + e * 32);
 #pragma unroll
-    for (int k = 0; k < SH; ++k) sh_sorted[e * sh_stride + k] = y[k];
+        for (int q = 0; q < 8; ++q)
+            row[q] = make_float4(4 * q < SH ? y[4 * q < SH ? 4 * q : 0] : 0.0f,
+                                 4 * q + 1 < SH ? y[4 * q + 1 < SH ? 4 * q + 1 : 0] : 0.0f,
+                                 4 * q + 2 < SH ? y[4 * q + 2 < SH ? 4 * q + 2 : 0] : 0.0f,
+                                 4 * q + 3 < SH ? y[4 * q + 3 < SH ? 4 * q + 3 : 0] : 0.0f);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SH; ++k) sh_sorted[e * sh_stride + k] = y[k];
+        for (int k = SH; k < sh_stride; ++k) sh_sorted[e * sh_stride + k] = 0.0f;
+    }
 
     if (edge_vectors) {
         edge_vectors[3 * o + 0] = vx;

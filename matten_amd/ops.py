@@ -161,7 +161,8 @@ def edge_geom(pos, edge_index, edge_cell_shift, cell, batch, perm, lmax: int, n_
     sh_dim = (lmax + 1) ** 2
     geom = torch.empty(E, 4, dtype=torch.float32, device=dev)
     # rows padded to 32 floats: one 128-byte line per edge, and the fused TP kernel may read any l2 <= 4
-    sh = torch.zeros(E, SH_STRIDE, dtype=torch.float32, device=dev)
+    # (the kernel writes the padding columns as zeros itself)
+    sh = torch.empty(E, SH_STRIDE, dtype=torch.float32, device=dev)
     out = {"geom_sorted": geom, "sh_sorted": sh}
     ev = torch.empty(E, 3, dtype=torch.float32, device=dev) if want_vectors else None
     el = torch.empty(E, dtype=torch.float32, device=dev) if want_lengths else None
