@@ -47,8 +47,11 @@ int matten_abi_version(void);
  *   src_sorted[E]: edge_index[0][perm[e]]
  * workspace: matten_csr_workspace_bytes(E, N) bytes.
  * Out-of-range node ids set err_flag bit 0.
+ * Sparse graphs (E <= 64 N) are built by counting (in-degree atomics, scan, rank of the edge ids inside every
+ * segment: no device-wide sort), dense ones by a stable radix sort; the result is the same.
  * ------------------------------------------------------------------------------------------ */
 size_t matten_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
+int matten_csr_counting_max_avg_degree(void);   /* E <= this * N: counting build (no device-wide sort) */
 int matten_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, int32_t* perm,
                      int32_t* rowptr, int32_t* src_sorted, void* workspace, size_t workspace_bytes,
                      int32_t* err_flag, matten_stream_t stream);
@@ -56,7 +59,9 @@ int matten_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes
 /* Grouping of n items by an integer key in [0, n_keys): order[n] = item positions stably sorted by key,
  * seg[n_keys+1] = first sorted position of each key.  This is the species grouping the species-indexed linears
  * (FullyConnectedTensorProduct with a one-hot operand, nn/conv.py:59-86) walk instead of evaluating densely over
- * the one-hot.  workspace: matten_csr_workspace_bytes(n, n_keys) bytes.  A key out of range sets err_flag bit 0. */
+ * the one-hot.  workspace: matten_group_workspace_bytes(n, n_keys) bytes.  A key out of range sets err_flag bit 0.
+ * (n_keys <= 256: per-run histograms + scan + ballot ranks; more keys: stable radix sort.) */
+size_t matten_group_workspace_bytes(int64_t n, int64_t n_keys);
 int matten_group_by_key(const int64_t* key, int64_t n, int64_t n_keys, int32_t* order, int32_t* seg,
                         void* workspace, size_t workspace_bytes, int32_t* err_flag, matten_stream_t stream);
 

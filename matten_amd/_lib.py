@@ -21,6 +21,8 @@ P = c_void_p
 SIGNATURES = {
     "matten_abi_version": (c_int, []),
     "matten_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "matten_group_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "matten_csr_counting_max_avg_degree": (c_int, []),
     "matten_csr_build": (c_int, [P, c_int64, c_int64, P, P, P, P, c_size_t, P, P]),
     "matten_group_by_key": (c_int, [P, c_int64, c_int64, P, P, P, c_size_t, P, P]),
     "matten_species_embed": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_int64, P, P, P, P, P, P]),

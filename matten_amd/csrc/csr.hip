@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
 
@@ -44,6 +45,59 @@ __global__ void csr_src_kernel(const int64_t* __restrict__ edge_index, const int
     src_sorted[e] = (int32_t)s;
 }
 
+// ---- counting build (sparse graphs: a few dozen edges per node) -----------------------------------------------------
+// The radix sort spends ~135 us in 14 launches on the 1.15 M edges of 1000 fcc-64 crystals.  With short segments the
+// same stable order comes cheaper: count the in-degrees, scan them into rowptr, drop every edge into its node's segment
+// in arrival order (the counting atomic's return value: any order), then rank the ids INSIDE each segment (16 lanes per node, degree^2 / 16
+// comparisons) -- sorted by (dst, edge id), i.e. exactly the stable sort's permutation.
+// (a kernel, not hipMemsetAsync: a memset node captured into a hipGraph was not re-executed on replay on ROCm 7.2 --
+// the counters then kept the previous replay's totals and the placement wrote past its segment)
+__global__ void zero_i32_kernel(int32_t* __restrict__ p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+__global__ void csr_count_kernel(const int64_t* __restrict__ edge_index, int64_t E, int64_t N,
+                                 int32_t* __restrict__ deg, int32_t* __restrict__ slot, int32_t* err_flag) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t s = edge_index[e];
+    int64_t d = edge_index[E + e];
+    if (s < 0 || s >= N || d < 0 || d >= N) {
+        atomicOr(err_flag, 1);
+        d = d < 0 ? 0 : (d >= N ? N - 1 : d);
+    }
+    slot[e] = atomicAdd(&deg[d], 1);   // arrival order inside the segment (any order: ranked below)
+}
+
+__global__ void csr_place_kernel(const int64_t* __restrict__ edge_index, int64_t E, int64_t N,
+                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ slot,
+                                 int32_t* __restrict__ ids) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t d = edge_index[E + e];
+    d = d < 0 ? 0 : (d >= N ? N - 1 : d);
+    ids[rowptr[d] + slot[e]] = (int32_t)e;
+}
+
+__global__ void csr_rank_kernel(const int64_t* __restrict__ edge_index, const int32_t* __restrict__ rowptr,
+                                const int32_t* __restrict__ ids, int64_t E, int64_t N, int32_t* __restrict__ perm,
+                                int32_t* __restrict__ src_sorted) {
+    const int64_t node = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (node >= N) return;
+    const int sub = threadIdx.x & 15;
+    const int beg = rowptr[node], d = rowptr[node + 1] - beg;
+    for (int i = sub; i < d; i += 16) {
+        const int id = ids[beg + i];
+        int rank = 0;
+        for (int j = 0; j < d; ++j) rank += ids[beg + j] < id;
+        perm[beg + rank] = id;
+        int64_t s = edge_index[id];
+        s = s < 0 ? 0 : (s >= N ? N - 1 : s);
+        src_sorted[beg + rank] = (int32_t)s;
+    }
+}
+
 // keys of a plain grouping (matten_group_by_key): value = position, key clamped into [0, n_keys)
 __global__ void group_keys_kernel(const int64_t* __restrict__ key, int64_t n, int64_t n_keys,
                                   int32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* err_flag) {
@@ -56,6 +110,61 @@ __global__ void group_keys_kernel(const int64_t* __restrict__ key, int64_t n, in
     }
     keys[i] = (int32_t)k;
     vals[i] = (int32_t)i;
+}
+
+// ---- grouping by a small key (species): counting form ----------------------------------------------------------------
+// cnt[k][w] = items with key k in the w-th run of 64 items; an exclusive scan of the key-major table is the stable
+// position of (k, w); inside a run the rank among equal keys comes from wave ballots.  3 launches + a scan instead
+// of the radix sort's 9.
+constexpr int GROUP_COUNTING_MAX_KEYS = 256;
+constexpr int GROUP_WAVES = 4;
+
+__device__ __forceinline__ int group_key_of(const int64_t* __restrict__ key, int64_t i, int64_t n, int64_t n_keys,
+                                            int32_t* err_flag) {
+    if (i >= n) return -1;
+    int64_t k = key[i];
+    if (k < 0 || k >= n_keys) {
+        atomicOr(err_flag, 1);
+        k = k < 0 ? 0 : n_keys - 1;
+    }
+    return (int)k;
+}
+
+__global__ __launch_bounds__(GROUP_WAVES * 64) void group_hist_kernel(const int64_t* __restrict__ key, int64_t n,
+                                                                      int64_t n_keys, int64_t n_runs,
+                                                                      int32_t* __restrict__ cnt, int32_t* err_flag) {
+    __shared__ int h[GROUP_WAVES][GROUP_COUNTING_MAX_KEYS];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t run = (int64_t)blockIdx.x * GROUP_WAVES + wv;
+    for (int kk = lane; kk < n_keys; kk += 64) h[wv][kk] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int k = group_key_of(key, run * 64 + lane, n, n_keys, err_flag);
+    if (k >= 0) atomicAdd(&h[wv][k], 1);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (run < n_runs)
+        for (int kk = lane; kk < n_keys; kk += 64) cnt[(int64_t)kk * n_runs + run] = h[wv][kk];
+}
+
+__global__ __launch_bounds__(GROUP_WAVES * 64) void group_place_kernel(const int64_t* __restrict__ key, int64_t n,
+                                                                       int64_t n_keys, int64_t n_runs,
+                                                                       const int32_t* __restrict__ offs,
+                                                                       int32_t* __restrict__ order,
+                                                                       int32_t* __restrict__ seg, int32_t* err_flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t run = i >> 6;
+    if (i <= n_keys) seg[i] = i < n_keys ? offs[i * n_runs] : (int32_t)n;
+    const int k = group_key_of(key, i, n, n_keys, err_flag);
+    unsigned long long todo = __ballot(k >= 0);
+    int rank = 0;
+    while (todo) {   // one round per distinct key of the run
+        const int kf = __shfl(k, __ffsll((long long)todo) - 1);
+        const unsigned long long m = __ballot(k == kf);
+        if (k == kf) rank = __popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+    if (k >= 0) order[offs[(int64_t)k * n_runs + run] + rank] = (int32_t)i;
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -74,8 +183,32 @@ extern "C" size_t matten_csr_workspace_bytes(int64_t E, int64_t N) {
     int32_t* p = nullptr;
     // size query only (no launch)
     (void)rocprim::radix_sort_pairs(nullptr, tmp, p, p, p, p, (size_t)(E > 0 ? E : 1), 0, key_bits(N), 0, false);
-    return 3 * align256((size_t)(E > 0 ? E : 1) * sizeof(int32_t)) + align256(tmp) + 256;
+    size_t scan_tmp = 0;
+    (void)rocprim::exclusive_scan(nullptr, scan_tmp, p, p, 0, (size_t)(N + 1), rocprim::plus<int32_t>());
+    // radix path: 3 edge-sized arrays + its temporaries; counting path: 2 edge-sized arrays + N+1 counters + scan temporaries
+    return 3 * align256((size_t)(E > 0 ? E : 1) * sizeof(int32_t)) + align256(tmp) + align256((size_t)(N + 1) * sizeof(int32_t)) +
+           align256(scan_tmp) + 256;
 }
+
+// workspace of matten_group_by_key(n items, n_keys): the sort's, or the counting form's two [n_keys][ceil(n / 64)] tables
+extern "C" size_t matten_group_workspace_bytes(int64_t n, int64_t n_keys) {
+    if (n < 0 || n_keys <= 0) return 0;
+    size_t need = matten_csr_workspace_bytes(n, n_keys);
+    if (n_keys <= GROUP_COUNTING_MAX_KEYS) {
+        const size_t table = (size_t)n_keys * (size_t)((n + 63) / 64 + 1);
+        size_t scan_tmp = 0;
+        int32_t* p = nullptr;
+        (void)rocprim::exclusive_scan(nullptr, scan_tmp, p, p, 0, table, rocprim::plus<int32_t>());
+        const size_t counting = 2 * align256(table * sizeof(int32_t)) + align256(scan_tmp) + 256;
+        if (counting > need) need = counting;
+    }
+    return need;
+}
+
+// average in-degree up to which the counting build is used (the ranking step is quadratic in a node's degree)
+constexpr int64_t CSR_COUNTING_MAX_AVG_DEGREE = 64;
+
+extern "C" int matten_csr_counting_max_avg_degree(void) { return (int)CSR_COUNTING_MAX_AVG_DEGREE; }
 
 extern "C" int matten_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* perm, int32_t* rowptr,
                                 int32_t* src_sorted, void* workspace, size_t workspace_bytes, int32_t* err_flag,
@@ -84,7 +217,8 @@ extern "C" int matten_csr_build(const int64_t* edge_index, int64_t E, int64_t N,
     if (E < 0 || N < 0 || N >= ((int64_t)1 << 31) || E >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
     if (!rowptr || !err_flag) return MATTEN_EINVAL;
     if (E == 0) {
-        if (hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * sizeof(int32_t), stream) != hipSuccess) return MATTEN_ELAUNCH;
+        zero_i32_kernel<<<(unsigned)matten_cdiv(N + 1, 256), 256, 0, stream>>>(rowptr, N + 1);
+        MATTEN_LAUNCH_CHECK();
         return MATTEN_OK;
     }
     if (!edge_index || !perm || !src_sorted || !workspace) return MATTEN_EINVAL;
@@ -100,6 +234,27 @@ extern "C" int matten_csr_build(const int64_t* edge_index, int64_t E, int64_t N,
     size_t tmp_bytes = workspace_bytes - 3 * seg;
 
     const int T = 256;
+    if (N > 0 && E <= CSR_COUNTING_MAX_AVG_DEGREE * N) {
+        int32_t* ids = (int32_t*)ws;
+        int32_t* slot = (int32_t*)(ws + seg);
+        int32_t* deg = (int32_t*)(ws + 2 * seg);
+        const size_t deg_bytes = align256((size_t)(N + 1) * sizeof(int32_t));
+        void* scan_tmp = ws + 2 * seg + deg_bytes;
+        size_t scan_bytes = workspace_bytes - 2 * seg - deg_bytes;
+        zero_i32_kernel<<<(unsigned)matten_cdiv(N + 1, T), T, 0, stream>>>(deg, N + 1);
+        MATTEN_LAUNCH_CHECK();
+        csr_count_kernel<<<(unsigned)matten_cdiv(E, T), T, 0, stream>>>(edge_index, E, N, deg, slot, err_flag);
+        MATTEN_LAUNCH_CHECK();
+        if (rocprim::exclusive_scan(scan_tmp, scan_bytes, deg, rowptr, 0, (size_t)(N + 1), rocprim::plus<int32_t>(),
+                                    stream) != hipSuccess)
+            return MATTEN_ELAUNCH;
+        csr_place_kernel<<<(unsigned)matten_cdiv(E, T), T, 0, stream>>>(edge_index, E, N, rowptr, slot, ids);
+        MATTEN_LAUNCH_CHECK();
+        csr_rank_kernel<<<(unsigned)matten_cdiv(N * 16, T), T, 0, stream>>>(edge_index, rowptr, ids, E, N, perm,
+                                                                           src_sorted);
+        MATTEN_LAUNCH_CHECK();
+        return MATTEN_OK;
+    }
     csr_keys_kernel<<<(unsigned)matten_cdiv(E, T), T, 0, stream>>>(edge_index, E, N, keys_in, vals_in, err_flag);
     MATTEN_LAUNCH_CHECK();
     if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, perm, (size_t)E, 0, key_bits(N), stream,
@@ -121,12 +276,34 @@ extern "C" int matten_group_by_key(const int64_t* key, int64_t n, int64_t n_keys
     if (n < 0 || n_keys <= 0 || n_keys >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
     if (!seg || !err_flag) return MATTEN_EINVAL;
     if (n == 0) {
-        if (hipMemsetAsync(seg, 0, (size_t)(n_keys + 1) * sizeof(int32_t), stream) != hipSuccess) return MATTEN_ELAUNCH;
+        zero_i32_kernel<<<(unsigned)matten_cdiv(n_keys + 1, 256), 256, 0, stream>>>(seg, n_keys + 1);
+        MATTEN_LAUNCH_CHECK();
         return MATTEN_OK;
     }
     if (!key || !order || !workspace) return MATTEN_EINVAL;
-    if (workspace_bytes < matten_csr_workspace_bytes(n, n_keys)) return MATTEN_ENOMEM;
+    if (workspace_bytes < matten_group_workspace_bytes(n, n_keys)) return MATTEN_ENOMEM;
     char* ws = (char*)workspace;
+    if (n_keys <= GROUP_COUNTING_MAX_KEYS) {
+        const int64_t n_runs = (n + 63) / 64;
+        const size_t table = (size_t)n_keys * (size_t)n_runs;
+        const size_t tb = align256((size_t)n_keys * (size_t)(n_runs + 1) * sizeof(int32_t));
+        int32_t* cnt = (int32_t*)ws;
+        int32_t* offs = (int32_t*)(ws + tb);
+        void* scan_tmp = ws + 2 * tb;
+        size_t scan_bytes = workspace_bytes - 2 * tb;
+        const int TB = GROUP_WAVES * 64;
+        group_hist_kernel<<<(unsigned)matten_cdiv(n_runs, GROUP_WAVES), TB, 0, stream>>>(key, n, n_keys, n_runs, cnt,
+                                                                                        err_flag);
+        MATTEN_LAUNCH_CHECK();
+        if (rocprim::exclusive_scan(scan_tmp, scan_bytes, cnt, offs, 0, table, rocprim::plus<int32_t>(), stream) !=
+            hipSuccess)
+            return MATTEN_ELAUNCH;
+        const int64_t threads = n > n_keys + 1 ? n : n_keys + 1;
+        group_place_kernel<<<(unsigned)matten_cdiv(threads, TB), TB, 0, stream>>>(key, n, n_keys, n_runs, offs, order,
+                                                                                 seg, err_flag);
+        MATTEN_LAUNCH_CHECK();
+        return MATTEN_OK;
+    }
     size_t sg = align256((size_t)n * sizeof(int32_t));
     int32_t* keys_in = (int32_t*)ws;
     int32_t* keys_out = (int32_t*)(ws + sg);

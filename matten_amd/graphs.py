@@ -16,18 +16,23 @@ from typing import Callable, Dict
 import torch
 
 
-# rocPRIM's radix sort (CSR build, species grouping) switches algorithm above 2^20 keys and that path does not survive
-# a capture on this ROCm (memory aperture violation at replay; eager is fine).  Capture pays for launch-bound batches
-# only -- at 10^6 edges the GPU is busy for milliseconds per step either way -- so larger batches are refused.
-MAX_CAPTURED_EDGES = 1_000_000
+# rocPRIM's radix sort switches algorithm above 2^20 keys and that path does not survive a capture on this ROCm (memory
+# aperture violation at replay; eager is fine -- most likely its hipMemsetAsync nodes: a memset captured by
+# matten_csr_build was not re-executed on replay either, and is a kernel now).  Sparse graphs (E <= 64 N, every
+# cutoff-radius graph of this domain) are built by counting without a device-wide sort and the species grouping never
+# sorts, so only DENSE graphs above that size are refused.
+MAX_CAPTURED_SORT_KEYS = 1_000_000
 
 
 def _check_capturable(batch) -> None:
+    from . import _lib
+
     n_edges = int(batch["edge_index"].shape[1])
     n_nodes = int(batch["pos"].shape[0])
-    if max(n_edges, n_nodes) > MAX_CAPTURED_EDGES:
-        raise ValueError(f"{n_edges} edges / {n_nodes} nodes: hipGraph capture is for launch-bound batch sizes "
-                         f"(<= {MAX_CAPTURED_EDGES}); run larger batches eagerly")
+    sorts = n_edges > _lib.load().matten_csr_counting_max_avg_degree() * n_nodes
+    if sorts and n_edges > MAX_CAPTURED_SORT_KEYS:
+        raise ValueError(f"{n_edges} edges on {n_nodes} nodes: a graph this dense is built with a radix sort, which "
+                         f"cannot be captured above {MAX_CAPTURED_SORT_KEYS} edges on this ROCm; run it eagerly")
 
 
 class GraphedTrainStep:

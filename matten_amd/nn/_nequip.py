@@ -25,11 +25,11 @@ def with_batch(data: DataKey.Type) -> DataKey.Type:
     return data
 
 
-def ensure_graph(data: DataKey.Type) -> DataKey.Type:
-    """Destination-sorted CSR of edge_index, built once per batch."""
+def ensure_graph(data: DataKey.Type, err=None) -> DataKey.Type:
+    """Destination-sorted CSR of edge_index, built once per batch (err: optional zeroed int32[1] for its range flag)."""
     if DataKey.AMD_ROWPTR not in data:
         n_nodes = data[DataKey.POSITIONS].shape[0]
-        perm, rowptr, src, err = ops.csr_build(data[DataKey.EDGE_INDEX], n_nodes)
+        perm, rowptr, src, err = ops.csr_build(data[DataKey.EDGE_INDEX], n_nodes, err=err)
         data[DataKey.AMD_PERM], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC] = perm, rowptr, src
         data["_amd_csr_err"] = err
     return data

@@ -110,29 +110,34 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
             Z, lut, provided = data[DataKey.ATOMIC_NUMBERS], a2i._Z_to_index, False
         else:
             raise ValueError("Nothing in `data` to encode. Need either species_index or atomic_numbers")
-        sidx, s32, feats, attrs, err = ops.species_embed(
-            Z, lut, lo, hi, S, self.linear.weight, self.linear.bias, want_attrs=self.materialize
+        # one flag vector for the three kernels that validate their input: [species, edge_index range, grouping]
+        flags_dev = torch.zeros(3, dtype=torch.int32, device=Z.device)
+        sidx, s32, feats, attrs, _ = ops.species_embed(
+            Z, lut, lo, hi, S, self.linear.weight, self.linear.bias, want_attrs=self.materialize, err=flags_dev[0:1]
         )
         # the destination-sorted CSR every conv layer walks is built here, so that its range check of edge_index
         # shares this module's one host sync (the reference would raise an IndexError in its first gather,
         # nn/_nequip.py:238; the kernels clamp, so a malformed batch must not get past this point)
-        csr_err = None
         if DataKey.EDGE_INDEX in data:
             from ._nequip import ensure_graph
 
-            csr_err = ensure_graph(data).get("_amd_csr_err")
+            built_here = DataKey.AMD_ROWPTR not in data
+            csr_err = ensure_graph(data, err=flags_dev[1:2]).get("_amd_csr_err")
+            if not built_here and csr_err is not None:   # built earlier by another module: it has its own flag word
+                flags_dev[1:2] = csr_err
+        # nodes grouped by species (stable): the species-indexed linears walk this order.  Enqueued before the host
+        # waits for the flags below, so that its launches are not paced by the host afterwards (an unknown species
+        # is grouped with species 0 by the kernel and never used: the check raises)
+        order, seg, _ = ops.group_by_key(sidx, S, err=flags_dev[2:3])
         if self.check_species:
-            flags = err if csr_err is None else torch.cat([err, csr_err])
-            flags = flags.tolist()
+            flags = flags_dev.tolist()
             if flags[0]:
                 a2i.raise_for_flags(flags[0], Z)
-            if len(flags) > 1 and flags[1] & 1:
+            if flags[1] & 1:
                 n_nodes = data[DataKey.POSITIONS].shape[0]
                 raise IndexError(f"edge_index holds node ids outside [0, {n_nodes}) (a malformed batch)")
         if not provided:
             data[DataKey.SPECIES_INDEX] = sidx
-        # nodes grouped by species (stable): the species-indexed linears walk this order
-        order, seg, _ = ops.group_by_key(sidx.clamp(min=0), S)
         data[DataKey.AMD_SPECIES] = (order, seg)
         data[DataKey.AMD_SPECIES_I32] = s32
         if attrs is not None:

@@ -84,7 +84,16 @@ def _need_rows(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     return _need(t, dtype, name)
 
 
-def csr_build(edge_index: torch.Tensor, n_nodes: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+def _err_flag(err, dev) -> torch.Tensor:
+    """a zeroed int32[1] flag word, or the caller's (one allocation + one memset for several kernels' flags)"""
+    if err is None:
+        return torch.zeros(1, dtype=torch.int32, device=dev)
+    if err.dtype != torch.int32 or err.numel() != 1 or err.device != dev:
+        raise ValueError("err must be an int32 tensor of one element on the inputs' device")
+    return err
+
+
+def csr_build(edge_index: torch.Tensor, n_nodes: int, err: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> (perm[E] i32, rowptr[N+1] i32, src_sorted[E] i32, err_flag[1] i32)"""
     lib = _lib.load()
     edge_index = _need(edge_index, torch.int64, "edge_index")
@@ -93,7 +102,7 @@ def csr_build(edge_index: torch.Tensor, n_nodes: int) -> Tuple[torch.Tensor, tor
     perm = torch.empty(E, dtype=torch.int32, device=dev)
     rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
     src = torch.empty(E, dtype=torch.int32, device=dev)
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    err = _err_flag(err, dev)
     nbytes = lib.matten_csr_workspace_bytes(E, n_nodes)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
     _lib.check(
@@ -104,7 +113,7 @@ def csr_build(edge_index: torch.Tensor, n_nodes: int) -> Tuple[torch.Tensor, tor
     return perm, rowptr, src, err
 
 
-def group_by_key(key: torch.Tensor, n_keys: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def group_by_key(key: torch.Tensor, n_keys: int, err: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> (order[n] i32: positions stably sorted by key, seg[n_keys+1] i32, err_flag[1] i32)"""
     lib = _lib.load()
     key = _need(key, torch.int64, "key")
@@ -112,8 +121,8 @@ def group_by_key(key: torch.Tensor, n_keys: int) -> Tuple[torch.Tensor, torch.Te
     dev = key.device
     order = torch.empty(n, dtype=torch.int32, device=dev)
     seg = torch.empty(n_keys + 1, dtype=torch.int32, device=dev)
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
-    nbytes = lib.matten_csr_workspace_bytes(n, n_keys)
+    err = _err_flag(err, dev)
+    nbytes = lib.matten_group_workspace_bytes(n, n_keys)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
     _lib.check(lib.matten_group_by_key(_ptr(key), n, n_keys, _ptr(order), _ptr(seg), _ptr(ws), nbytes, _ptr(err),
                                        _stream()), "matten_group_by_key")
@@ -121,7 +130,7 @@ def group_by_key(key: torch.Tensor, n_keys: int) -> Tuple[torch.Tensor, torch.Te
 
 
 def species_embed(atomic_numbers, z_to_index, min_z: int, max_z: int, n_species: int, weight, bias,
-                  want_attrs: bool = False):
+                  want_attrs: bool = False, err: torch.Tensor = None):
     """-> (species_index i64 [N], species_i32 [N], node_feats [N,dim], node_attrs [N,S] | None, err_flag)"""
     lib = _lib.load()
     Z = _need(atomic_numbers, torch.int64, "atomic_numbers")
@@ -134,7 +143,7 @@ def species_embed(atomic_numbers, z_to_index, min_z: int, max_z: int, n_species:
     s32 = torch.empty(N, dtype=torch.int32, device=dev)
     feats = torch.empty(N, dim, dtype=torch.float32, device=dev)
     attrs = torch.empty(N, n_species, dtype=torch.float32, device=dev) if want_attrs else None
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    err = _err_flag(err, dev)
     _lib.check(
         lib.matten_species_embed(_ptr(Z), N, _ptr(lut), min_z, max_z, n_species, _ptr(W), _ptr(b), dim, _ptr(sidx),
                                  _ptr(s32), _ptr(feats), _ptr(attrs), _ptr(err), _stream()),

@@ -53,6 +53,24 @@ def test_csr_is_stable_sort_by_dst():
     assert int(err.item()) == 0
 
 
+@pytest.mark.parametrize("n_nodes,n_edges", [(50, 600), (7, 2000), (1000, 300), (3, 1)])
+def test_csr_counting_and_radix_builds_agree_with_a_stable_sort(n_nodes, n_edges):
+    """sparse graphs (<= 64 edges per node on average) take the counting build, dense ones the radix sort: the same
+    stable order either way; isolated nodes, a hub node and repeated edges included"""
+    from matten_amd import ops
+
+    g = torch.Generator().manual_seed(n_nodes * 7 + n_edges)
+    ei = torch.randint(0, n_nodes, (2, n_edges), generator=g)
+    ei[1, : n_edges // 3] = 0                                   # a hub: a third of the edges end in node 0
+    perm, rowptr, src, err = ops.csr_build(ei.to(DEV), n_nodes)
+    want_perm = torch.sort(ei[1], stable=True).indices
+    assert torch.equal(perm.cpu().long(), want_perm)
+    assert torch.equal(src.cpu().long(), ei[0][want_perm])
+    assert torch.equal(rowptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long),
+                                                       torch.bincount(ei[1], minlength=n_nodes).cumsum(0)]))
+    assert int(err.item()) == 0
+
+
 def test_csr_empty_and_bad_index():
     from matten_amd import ops
 
@@ -76,6 +94,14 @@ def test_group_by_key_is_a_stable_sort():
     assert int(err.item()) & 1
     _, seg, _ = ops.group_by_key(torch.zeros(0, dtype=torch.int64, device=DEV), 4)
     assert seg.cpu().tolist() == [0] * 5
+    # both forms (<= 256 keys: counting; more: radix sort), ragged sizes, more keys than items, empty keys
+    for n, n_keys in ((1, 3), (63, 100), (64, 2), (65, 256), (4097, 86), (5000, 300), (70000, 10)):
+        key = torch.randint(0, n_keys, (n,), generator=g)
+        key[key == 1] = 0                                   # key 1 stays empty
+        order, seg, err = ops.group_by_key(key.to(DEV), n_keys)
+        assert torch.equal(order.cpu().long(), torch.sort(key, stable=True).indices), (n, n_keys)
+        assert seg.cpu().tolist() == [0] + torch.cumsum(torch.bincount(key, minlength=n_keys), 0).tolist()
+        assert int(err.item()) == 0
 
 
 def test_malformed_edge_index_raises_like_the_reference():

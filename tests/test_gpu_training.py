@@ -157,3 +157,26 @@ def test_hipgraph_forward_is_bit_identical_to_eager():
         for batch in (a, b, a):
             want = model(dict(batch))[0]["elastic_tensor_full"]
             assert torch.equal(g(batch), want)
+
+
+def test_hipgraph_forward_above_a_million_edges():
+    """1000 fcc-64 crystals = 1.15 M edges: more keys than rocPRIM's radix sort survives in a capture on this ROCm
+    (DESIGN.md section 8).  The CSR of a sparse graph is built by counting, without that sort, so the capture works;
+    a DENSE graph of that size is refused up front."""
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import collate
+    from matten_amd.graphs import GraphedForward, _check_capturable
+
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    _, model = build_pair(dict(LMAX2, num_layers=1), ds, randomize_bn=True)
+    graphs = synthetic.fcc64_graphs(64)
+    a = collate([graphs[i % 64] for i in range(1000)], device=DEV)
+    b = collate([graphs[(i * 7 + 3) % 64] for i in range(1000)], device=DEV)
+    assert a["edge_index"].shape[1] > 2**20
+    g = GraphedForward(model, a)
+    with torch.no_grad():
+        for batch in (a, b, a):
+            assert torch.equal(g(batch), model(dict(batch))[0]["elastic_tensor_full"])
+    dense = {"edge_index": torch.zeros(2, 2_000_000, dtype=torch.int64), "pos": torch.zeros(1000, 3)}
+    with pytest.raises(ValueError, match="radix sort"):
+        _check_capturable(dense)
