@@ -89,10 +89,12 @@ int matten_species_embed(const int64_t* atomic_numbers, int64_t n_nodes, const i
  * Optional original-order outputs for the backbone's data dict (NULL to skip):
  *   edge_vectors[E,3], edge_lengths[E], edge_attrs[E,(lmax+1)^2], edge_embedding[E,nb]
  * cell is [B,3,3] (rows = lattice vectors) or NULL; n_cells==1 uses cell 0 for every edge.
+ * Node ids outside [0, n_nodes) and crystal ids outside [0, n_cells) are clamped (memory safety only: matten_csr_build
+ * flags such a batch, and the host may read that flag after this kernel was enqueued).
  * ------------------------------------------------------------------------------------------ */
 int matten_edge_geom(const float* pos, const int64_t* edge_index, const float* edge_cell_shift,
                      const float* cell, int64_t n_cells, const int64_t* batch, const int32_t* perm,
-                     int64_t n_edges, int lmax, int n_basis, float r_start, float r_end,
+                     int64_t n_edges, int64_t n_nodes, int lmax, int n_basis, float r_start, float r_end,
                      float* geom_sorted, float* sh_sorted, int sh_stride, float* edge_vectors, float* edge_lengths,
                      float* edge_attrs, float* edge_embedding, matten_stream_t stream);
 

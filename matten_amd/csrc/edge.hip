@@ -12,7 +12,7 @@ template <int LMAX>
 __global__ void edge_geom_kernel(const float* __restrict__ pos, const int64_t* __restrict__ edge_index,
                                  const float* __restrict__ shift, const float* __restrict__ cell, int64_t n_cells,
                                  const int64_t* __restrict__ batch, const int32_t* __restrict__ perm, int64_t E,
-                                 int n_basis, float r_start, float r_end, float4* __restrict__ geom_sorted,
+                                 int64_t N, int n_basis, float r_start, float r_end, float4* __restrict__ geom_sorted,
                                  float* __restrict__ sh_sorted, int sh_stride, float* __restrict__ edge_vectors,
                                  float* __restrict__ edge_lengths, float* __restrict__ edge_attrs,
                                  float* __restrict__ edge_embedding) {
@@ -22,11 +22,17 @@ __global__ void edge_geom_kernel(const float* __restrict__ pos, const int64_t* _
     int64_t o = perm ? (int64_t)perm[e] : e;
     int64_t i = edge_index[o];      // centre ("source")
     int64_t j = edge_index[E + o];  // neighbour ("target")
+    // ids outside the batch are flagged by matten_csr_build; here they only must not fault (the host may read the flag
+    // after this kernel has run)
+    i = i < 0 ? 0 : (i >= N ? N - 1 : i);
+    j = j < 0 ? 0 : (j >= N ? N - 1 : j);
     float vx = pos[3 * j + 0] - pos[3 * i + 0];
     float vy = pos[3 * j + 1] - pos[3 * i + 1];
     float vz = pos[3 * j + 2] - pos[3 * i + 2];
     if (cell) {
-        const float* c = cell + 9 * ((n_cells > 1 && batch) ? batch[i] : 0);
+        int64_t b = (n_cells > 1 && batch) ? batch[i] : 0;
+        b = b < 0 ? 0 : (b >= n_cells ? n_cells - 1 : b);
+        const float* c = cell + 9 * b;
         float s0 = shift[3 * o + 0], s1 = shift[3 * o + 1], s2 = shift[3 * o + 2];
         // einsum("ni,nij->nj"): rows of the cell are the lattice vectors
         vx += s0 * c[0] + s1 * c[3] + s2 * c[6];
@@ -118,11 +124,11 @@ extern "C" int matten_species_embed(const int64_t* atomic_numbers, int64_t n_nod
 
 extern "C" int matten_edge_geom(const float* pos, const int64_t* edge_index, const float* edge_cell_shift,
                                 const float* cell, int64_t n_cells, const int64_t* batch, const int32_t* perm,
-                                int64_t n_edges, int lmax, int n_basis, float r_start, float r_end,
+                                int64_t n_edges, int64_t n_nodes, int lmax, int n_basis, float r_start, float r_end,
                                 float* geom_sorted, float* sh_sorted, int sh_stride, float* edge_vectors, float* edge_lengths,
                                 float* edge_attrs, float* edge_embedding, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (n_edges < 0 || lmax < 0 || lmax > 4 || n_basis < 0 || sh_stride < (lmax + 1) * (lmax + 1)) return MATTEN_EINVAL;
+    if (n_edges < 0 || n_nodes < 0 || (n_edges > 0 && n_nodes == 0) || lmax < 0 || lmax > 4 || n_basis < 0 || sh_stride < (lmax + 1) * (lmax + 1)) return MATTEN_EINVAL;
     if (n_edges == 0) return MATTEN_OK;
     if (!pos || !edge_index || !geom_sorted || !sh_sorted) return MATTEN_EINVAL;
     if (cell && !edge_cell_shift) return MATTEN_EINVAL;
@@ -130,7 +136,7 @@ extern "C" int matten_edge_geom(const float* pos, const int64_t* edge_index, con
     unsigned grid = (unsigned)matten_cdiv(n_edges, T);
 #define LAUNCH(L)                                                                                              \
     edge_geom_kernel<L><<<grid, T, 0, stream>>>(pos, edge_index, edge_cell_shift, cell, n_cells, batch, perm,  \
-                                                n_edges, n_basis, r_start, r_end, (float4*)geom_sorted,        \
+                                                n_edges, n_nodes, n_basis, r_start, r_end, (float4*)geom_sorted, \
                                                 sh_sorted, sh_stride, edge_vectors, edge_lengths, edge_attrs, edge_embedding)
     switch (lmax) {
         case 0: LAUNCH(0); break;

@@ -179,7 +179,7 @@ def edge_geom(pos, edge_index, edge_cell_shift, cell, batch, perm, lmax: int, n_
     ee = torch.empty(E, n_basis, dtype=torch.float32, device=dev) if want_embedding else None
     _lib.check(
         lib.matten_edge_geom(_ptr(pos), _ptr(edge_index), _ptr(edge_cell_shift), _ptr(cell), n_cells, _ptr(batch),
-                             _ptr(perm), E, lmax, n_basis, r_start, r_end, _ptr(geom), _ptr(sh), SH_STRIDE, _ptr(ev),
+                             _ptr(perm), E, pos.shape[0], lmax, n_basis, r_start, r_end, _ptr(geom), _ptr(sh), SH_STRIDE, _ptr(ev),
                              _ptr(el),
                              _ptr(ea), _ptr(ee), _stream()),
         "matten_edge_geom",
