@@ -28,7 +28,7 @@ def run_fused(entries_np, label):
     ust = torch.from_numpy(mplan.fused_unit_map(entries_np)).to(dev)
     upt = ust.numel()
     asp = ops.split_a_tiles(w2p, entries_np) if os.environ.get('NO_ASPLIT') is None else None
-    f = lambda: ops.tp_fused(x, h2p, w2p, geo["sh_sorted"], rowptr, src, ent, ust, upt, p.fused_lds_floats_per_wave, p.d_mid, 18.0, a_split=asp)
+    f = lambda: ops.tp_fused(x, h2p, w2p, geo["sh_sorted"], rowptr, src, ent, ust, upt, int(os.environ.get('LDS_PER_WAVE', p.fused_lds_floats_per_wave)), p.d_mid, 18.0, a_split=asp)
     for _ in range(2): f()
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(5): f()
