@@ -23,7 +23,11 @@ struct __attribute__((packed, aligned(4))) f4u {  // 16 bytes at 4-byte alignmen
 };
 constexpr int ROWS = 16;
 constexpr int WAVES = 4;
-constexpr int TPB = 2;  // 16-row tiles per workgroup: the weight fill and the species look-up are paid once for 32 rows
+#ifndef SLR_TPB
+#define SLR_TPB 2
+#endif
+constexpr int TPB = SLR_TPB;  // 16-row tiles per workgroup: the weight fill and the species look-up are paid once for 32 rows
+                              // (2 and 4 measure the same, 3 and 6 are 20 % slower: tools/slr_tpb_ab.sh)
 
 // accumulate-in-place MFMA through inline asm with explicit wait states, see species_linear.hip
 __device__ __forceinline__ void mfma_16x16x4(f32x4& acc, float a, float b) {
@@ -151,6 +155,35 @@ __global__ __launch_bounds__(WAVES * 64, 3) void species_linear_rows_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     // ---- rows and weights to LDS ----
+    // Row copy, software-pipelined over the workgroup's tiles: the loads of tile t + 1 are issued before tile t's
+    // items are multiplied and land in registers meanwhile (16 per thread for rows of up to 256 floats; wider rows
+    // take further sweeps at copy time), so only the first tile's HBM latency is exposed.
+    constexpr int RW = ROWS / WAVES;
+    float pre[RW][4];
+    auto fetch = [&](int lo_t, int col0, float (&v)[RW][4]) {
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = wave * RW + rr;
+            const bool in = lo_t + r < hi;
+            const int nd = in ? (order ? order[lo_t + r] : lo_t + r) : 0;
+            const float* xr = x + (int64_t)nd * d_in;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = col0 + 64 * q;
+                v[rr][q] = (in && col < d_in) ? xr[col] : 0.0f;
+            }
+        }
+    };
+    auto put = [&](int col0, const float (&v)[RW][4]) {
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = col0 + 64 * q;
+                if (col < xs_stride) xs[(wave * RW + rr) * xs_stride + col] = v[rr][q];
+            }
+    };
+    fetch(lo, lane, pre);   // the first tile's rows travel while the weights are copied
     // Every thread issues its loads in batches before it stores (the loops have run-time bounds: left to itself the
     // compiler waits for each load, and a workgroup spent ~25 us copying 40 KB).
     const float* wsp = wp + (int64_t)s * w_stride;
@@ -192,35 +225,13 @@ __global__ __launch_bounds__(WAVES * 64, 3) void species_linear_rows_kernel(
     const int g = lane >> 4, c = lane & 15;
     for (int tile = 0; tile < TPB && lo < hi; ++tile, lo += ROWS) {
         if (tile) __syncthreads();  // everyone is done with the previous tile's rows
-        {
-            constexpr int RW = ROWS / WAVES;
-            const float* xr[RW];
-            bool in[RW];
-#pragma unroll
-            for (int rr = 0; rr < RW; ++rr) {
-                const int r = wave * RW + rr;
-                in[rr] = lo + r < hi;
-                const int nd = in[rr] ? (order ? order[lo + r] : lo + r) : 0;
-                xr[rr] = x + (int64_t)nd * d_in;
-            }
-            for (int col0 = lane; col0 < xs_stride; col0 += 4 * 64) {
-                float v[RW][4];
-#pragma unroll
-                for (int rr = 0; rr < RW; ++rr)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int col = col0 + 64 * q;
-                        v[rr][q] = (in[rr] && col < d_in) ? xr[rr][col] : 0.0f;
-                    }
-#pragma unroll
-                for (int rr = 0; rr < RW; ++rr)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int col = col0 + 64 * q;
-                        if (col < xs_stride) xs[(wave * RW + rr) * xs_stride + col] = v[rr][q];
-                    }
-            }
+        put(lane, pre);
+        for (int col0 = lane + 4 * 64; col0 < xs_stride; col0 += 4 * 64) {
+            float v[RW][4];
+            fetch(lo, col0, v);
+            put(col0, v);
         }
+        if (tile + 1 < TPB && lo + ROWS < hi) fetch(lo + ROWS, lane, pre);   // in flight during this tile's items
         __syncthreads();
         const bool row_ok = lo + c < hi;
         const int node = row_ok ? (order ? order[lo + c] : lo + c) : 0;
