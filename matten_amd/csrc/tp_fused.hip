@@ -674,19 +674,22 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             G::apply(mask, x, y, w, acc);
         };
         if (two_deep) {
-            if (s0 < deg) contract(0, xn);
-            {
-                const float* xp = a.x + (int64_t)src_nn * a.d_in + xcol;
+            for (int so = 0; so < CH; so += 2) {   // CH is 2, 4 or 8 here: slot pairs, one row buffer per parity
+                const int s = s0 + so;
+                if (s < deg) contract(so, xn);
+                {
+                    const float* xp = a.x + (int64_t)src_nn * a.d_in + xcol;
 #pragma unroll
-                for (int i = 0; i < G::D1; ++i) xn[i] = xp[i];
-                src_nn = a.src_sorted[min(beg + s0 + 4, e_last)];
-            }
-            if (s0 + 1 < deg) contract(1, xb);
-            {
-                const float* xp = a.x + (int64_t)src_b * a.d_in + xcol;
+                    for (int i = 0; i < G::D1; ++i) xn[i] = xp[i];
+                    src_nn = a.src_sorted[min(beg + s + 4, e_last)];
+                }
+                if (s + 1 < deg) contract(so + 1, xb);
+                {
+                    const float* xp = a.x + (int64_t)src_b * a.d_in + xcol;
 #pragma unroll
-                for (int i = 0; i < G::D1; ++i) xb[i] = xp[i];
-                src_b = a.src_sorted[min(beg + s0 + 5, e_last)];
+                    for (int i = 0; i < G::D1; ++i) xb[i] = xp[i];
+                    src_b = a.src_sorted[min(beg + s + 5, e_last)];
+                }
             }
         } else {
             for (int so = 0; so < CH; ++so) {
@@ -720,7 +723,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     case (L1 * matten::GROUP_KIND_STRIDE + GI): \
         if (paired) run_group_shared<L1, GI, 1, false, true>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
         else if (nodes_per_wave > 16) run_group_shared<L1, GI, 2, false, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
-        else if (TwoDeepOk<L1, GI>::value && nodes_per_wave == 8) run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
+        else if (TwoDeepOk<L1, GI>::value && nodes_per_wave <= 8 && nodes_per_wave >= TPF_TWO_DEEP_MIN_NPW) run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
         else run_group_shared<L1, GI, 1, false, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
         break;
 
@@ -729,6 +732,9 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 
 #ifndef TPF_MIN_BLOCKS
 #define TPF_MIN_BLOCKS 3
+#endif
+#ifndef TPF_TWO_DEEP_MIN_NPW
+#define TPF_TWO_DEEP_MIN_NPW 2   // two neighbour rows in flight for 8, 4 and 2 nodes per wave (2, 4, 8 slots per chunk)
 #endif
 // experiment switches (tools/fused_kind_ablate.sh): compile the kernel for a subset of the group kinds only
 #if defined(TPF_ONLY_LIGHT)
