@@ -18,85 +18,66 @@ __device__ __forceinline__ float apply_act(int code, float v) {
     }
 }
 
-// Gate + (eval) BatchNorm.  A workgroup owns GB_ROWS rows and first folds the per-column constants into LDS once --
-// source column, gate column, activation codes and the BatchNorm affine as (scale, shift) -- so the per-element work is
-// two loads, the activations and one fma; consecutive lanes write consecutive output columns.
-constexpr int GB_ROWS = 32;
-constexpr int GB_MAXD = 1024;  // output columns held in LDS (wider layers take the plain path below)
-
-__global__ __launch_bounds__(256) void gate_bn_kernel(const float* __restrict__ x, int d_in, const int4* __restrict__ meta,
-                                                      int d_out, const float* __restrict__ act_cst,
-                                                      const float* __restrict__ running_mean,
-                                                      const float* __restrict__ running_var,
-                                                      const float* __restrict__ bn_weight,
-                                                      const float* __restrict__ bn_bias, float eps, int64_t n_rows,
-                                                      float* __restrict__ out) {
-    __shared__ int s_src[GB_MAXD], s_gate[GB_MAXD], s_act[GB_MAXD];
-    __shared__ float s_scale[GB_MAXD], s_shift[GB_MAXD];
-    for (int o = threadIdx.x; o < d_out; o += blockDim.x) {
-        const int4 m = meta[o];
-        s_src[o] = m.x;
-        s_gate[o] = m.y;
-        s_act[o] = m.z;
-        float scale = 1.0f, shift = 0.0f;
-        if (bn_weight) {
-            const int bn_idx = m.w & 0xffff, mean_idx = (m.w >> 16) & 0xffff;
-            scale = bn_weight[bn_idx] / sqrtf(running_var[bn_idx] + eps);
-            if (mean_idx != 0xffff) shift = bn_bias[mean_idx] - running_mean[mean_idx] * scale;  // (v - mu) s + b
-        }
-        s_scale[o] = scale;
-        s_shift[o] = shift;
+// Gate + (eval) BatchNorm.  A thread owns output column o -- its source / gate column, activation codes and the
+// BatchNorm affine folded to (scale, shift) live in registers -- and walks the workgroup's GB_ROWS rows GB_UNROLL at a
+// time, all loads of a batch issued before the first activation.  Consecutive threads, consecutive columns: coalesced
+// like the earlier row-per-wave form (a wave walked a row with the column tables in LDS: 46 us per launch), without
+// its five LDS reads per element and with 2 x GB_UNROLL loads in flight per thread: 32 us (4.3 TB/s).  16 or 32 rows
+// per workgroup measure the same, 64 rows or an unroll of 16 are 25 % slower (tools/gb_ab.sh).
+#ifndef GB_R
+#define GB_R 16
+#endif
+#ifndef GB_U
+#define GB_U 8
+#endif
+constexpr int GB_ROWS = GB_R, GB_UNROLL = GB_U;
+__global__ __launch_bounds__(256) void gate_bn_kernel(const float* __restrict__ x, int d_in,
+                                                           const int4* __restrict__ meta, int d_out,
+                                                           const float* __restrict__ act_cst,
+                                                           const float* __restrict__ running_mean,
+                                                           const float* __restrict__ running_var,
+                                                           const float* __restrict__ bn_weight,
+                                                           const float* __restrict__ bn_bias, float eps, int64_t n_rows,
+                                                           float* __restrict__ out) {
+    const int o = blockIdx.y * blockDim.x + threadIdx.x;
+    if (o >= d_out) return;
+    const int4 m = meta[o];
+    const int act = m.z & 0xff, gact = (m.z >> 8) & 0xff;
+    const float ca = act ? act_cst[act] : 1.0f, cg = gact ? act_cst[gact] : 1.0f;
+    float scale = 1.0f, shift = 0.0f;
+    if (bn_weight) {
+        const int bn_idx = m.w & 0xffff, mean_idx = (m.w >> 16) & 0xffff;
+        scale = bn_weight[bn_idx] / sqrtf(running_var[bn_idx] + eps);
+        if (mean_idx != 0xffff) shift = bn_bias[mean_idx] - running_mean[mean_idx] * scale;
     }
-    __syncthreads();
+    const int gcol = m.y < 0 ? m.x : m.y;   // scalars read their own column twice (no branch around a load)
     const int64_t row0 = (int64_t)blockIdx.x * GB_ROWS;
     const int rows = (int)min((int64_t)GB_ROWS, n_rows - row0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < rows; r += 4) {  // a wave walks one row: consecutive lanes, consecutive columns, no division
-        const float* xr = x + (row0 + r) * d_in;
-        float* orow = out + (row0 + r) * d_out;
-        for (int o = lane; o < d_out; o += 64) {
-            float v = xr[s_src[o]];
-            const int act = s_act[o] & 0xff, gact = (s_act[o] >> 8) & 0xff;
-            if (s_gate[o] < 0) {
-                if (act) v = apply_act(act, v) * act_cst[act];
-            } else {
-                float gte = xr[s_gate[o]];
-                if (gact) gte = apply_act(gact, gte) * act_cst[gact];
-                v = v * gte;
+    for (int r0 = 0; r0 < rows; r0 += GB_UNROLL) {
+        float a[GB_UNROLL], b[GB_UNROLL];
+#pragma unroll
+        for (int i = 0; i < GB_UNROLL; ++i) {
+            const int64_t r = row0 + min(r0 + i, rows - 1);
+            a[i] = x[r * d_in + m.x];
+            b[i] = x[r * d_in + gcol];
+        }
+#pragma unroll
+        for (int i = 0; i < GB_UNROLL; ++i) {
+            if (r0 + i < rows) {
+                float v = a[i];
+                if (m.y < 0) {
+                    if (act) v = apply_act(act, v) * ca;
+                } else {
+                    float gte = b[i];
+                    if (gact) gte = apply_act(gact, gte) * cg;
+                    v = v * gte;
+                }
+                out[(row0 + r0 + i) * d_out + o] = bn_weight ? fmaf(v, scale, shift) : v;
             }
-            orow[o] = bn_weight ? fmaf(v, s_scale[o], s_shift[o]) : v;
         }
     }
 }
 
-__global__ void gate_bn_wide_kernel(const float* __restrict__ x, int d_in, const int4* __restrict__ meta, int d_out,
-                                    const float* __restrict__ act_cst, const float* __restrict__ running_mean,
-                                    const float* __restrict__ running_var, const float* __restrict__ bn_weight,
-                                    const float* __restrict__ bn_bias, float eps, int64_t n_rows,
-                                    float* __restrict__ out) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_rows * d_out) return;
-    int64_t n = idx / d_out;
-    int o = (int)(idx - n * d_out);
-    int4 m = meta[o];
-    const float* xr = x + n * d_in;
-    float v = xr[m.x];
-    int act = m.z & 0xff, gact = (m.z >> 8) & 0xff;
-    if (m.y < 0) {
-        if (act) v = apply_act(act, v) * act_cst[act];
-    } else {
-        float gte = xr[m.y];
-        if (gact) gte = apply_act(gact, gte) * act_cst[gact];
-        v = v * gte;
-    }
-    if (bn_weight) {
-        int bn_idx = m.w & 0xffff, mean_idx = (m.w >> 16) & 0xffff;
-        float scale = bn_weight[bn_idx] / sqrtf(running_var[bn_idx] + eps);
-        if (mean_idx != 0xffff) v = (v - running_mean[mean_idx]) * scale + bn_bias[mean_idx];
-        else v = v * scale;
-    }
-    out[idx] = v;
-}
 
 __global__ void segment_reduce_kernel(const float* __restrict__ x, int dim, const int64_t* __restrict__ ptr,
                                       int64_t n_seg, int mean, float* __restrict__ out) {
@@ -135,15 +116,10 @@ extern "C" int matten_gate_bn(const float* x, int64_t d_in, const int32_t* meta,
     if (n_rows == 0) return MATTEN_OK;
     if (!x || !meta || !act_cst || !out) return MATTEN_EINVAL;
     if (bn_weight && (!running_var || !running_mean || !bn_bias)) return MATTEN_EINVAL;
-    const int T = 256;
-    if (d_out <= GB_MAXD)
-        gate_bn_kernel<<<(unsigned)matten_cdiv(n_rows, GB_ROWS), T, 0, stream>>>(
-            x, (int)d_in, (const int4*)meta, (int)d_out, act_cst, running_mean, running_var, bn_weight, bn_bias, eps,
-            n_rows, out);
-    else
-        gate_bn_wide_kernel<<<(unsigned)matten_cdiv(n_rows * d_out, T), T, 0, stream>>>(
-            x, (int)d_in, (const int4*)meta, (int)d_out, act_cst, running_mean, running_var, bn_weight, bn_bias, eps,
-            n_rows, out);
+    const int TC = (int)(d_out >= 256 ? 256 : 64 * matten_cdiv(d_out, 64));   // whole waves, at most one of them part idle
+    dim3 grid((unsigned)matten_cdiv(n_rows, GB_ROWS), (unsigned)matten_cdiv(d_out, TC));
+    gate_bn_kernel<<<grid, TC, 0, stream>>>(x, (int)d_in, (const int4*)meta, (int)d_out, act_cst, running_mean, running_var,
+                                            bn_weight, bn_bias, eps, n_rows, out);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }
