@@ -86,8 +86,18 @@ __global__ void segment_reduce_kernel(const float* __restrict__ x, int dim, cons
     int64_t b = idx / dim;
     int c = (int)(idx - b * dim);
     int64_t beg = ptr[b], end = ptr[b + 1];
+    // same left-to-right sum as before, the loads of eight rows issued together (the dependent adds then run on
+    // values that are already there: 22 -> ~8 us for 1000 crystals of 64 atoms)
     float s = 0.0f;
-    for (int64_t n = beg; n < end; ++n) s += x[n * dim + c];
+    int64_t n = beg;
+    for (; n + 8 <= end; n += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = x[(n + i) * dim + c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; n < end; ++n) s += x[n * dim + c];
     if (mean) {
         float cnt = (float)(end - beg);
         s = s / (cnt < 1.0f ? 1.0f : cnt);
