@@ -8,8 +8,10 @@
 
 namespace {
 
+constexpr int SH_TILE_RS = 36;   // floats per staged harmonics row (32 + 4: 16-byte aligned, rows spread over the banks)
+
 template <int LMAX>
-__global__ void edge_geom_kernel(const float* __restrict__ pos, const int64_t* __restrict__ edge_index,
+__global__ __launch_bounds__(256) void edge_geom_kernel(const float* __restrict__ pos, const int64_t* __restrict__ edge_index,
                                  const float* __restrict__ shift, const float* __restrict__ cell, int64_t n_cells,
                                  const int64_t* __restrict__ batch, const int32_t* __restrict__ perm, int64_t E,
                                  int64_t N, int n_basis, float r_start, float r_end, float4* __restrict__ geom_sorted,
@@ -17,8 +19,13 @@ __global__ void edge_geom_kernel(const float* __restrict__ pos, const int64_t* _
                                  float* __restrict__ edge_lengths, float* __restrict__ edge_attrs,
                                  float* __restrict__ edge_embedding) {
     constexpr int SH = (LMAX + 1) * (LMAX + 1);
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
+    __shared__ __attribute__((aligned(16))) float sh_tile[4 * 64 * SH_TILE_RS];
+    const int64_t e_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e_raw - (threadIdx.x & 63) >= E) return;   // whole waves past the end
+    // lanes past the end of the last wave stay: the harmonics rows are stored by the wave together.  They recompute
+    // the last edge and write nothing of their own.
+    const bool live = e_raw < E;
+    const int64_t e = live ? e_raw : E - 1;
     int64_t o = perm ? (int64_t)perm[e] : e;
     int64_t i = edge_index[o];      // centre ("source")
     int64_t j = edge_index[E + o];  // neighbour ("target")
@@ -40,24 +47,40 @@ __global__ void edge_geom_kernel(const float* __restrict__ pos, const int64_t* _
         vz += s0 * c[2] + s1 * c[5] + s2 * c[8];
     }
     float len = sqrtf(vx * vx + vy * vy + vz * vz);
-    geom_sorted[e] = make_float4(vx, vy, vz, len);
+    if (live) geom_sorted[e] = make_float4(vx, vy, vz, len);
 
     float y[SH];
     matten::real_sh<LMAX>(vx, vy, vz, len, y);
     // the whole padded row, zeros included: the caller hands over uninitialised memory
-    if (sh_stride == 32) {  // one 128-byte line per edge as eight 16-byte stores
-        float4* row = reinterpret_cast<float4*>(sh_sorted + e * 32);
+    if (sh_stride == 32) {
+        // one 128-byte line per edge.  Written through a wave-private LDS tile so that a store instruction covers 1 KB
+        // of consecutive memory (8 whole lines) instead of one 16-byte piece of 64 different lines.
+        float* tile = sh_tile + (threadIdx.x >> 6) * (64 * SH_TILE_RS);
+        const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            row[q] = make_float4(4 * q < SH ? y[4 * q < SH ? 4 * q : 0] : 0.0f,
-                                 4 * q + 1 < SH ? y[4 * q + 1 < SH ? 4 * q + 1 : 0] : 0.0f,
-                                 4 * q + 2 < SH ? y[4 * q + 2 < SH ? 4 * q + 2 : 0] : 0.0f,
-                                 4 * q + 3 < SH ? y[4 * q + 3 < SH ? 4 * q + 3 : 0] : 0.0f);
-    } else {
+            *reinterpret_cast<float4*>(tile + lane * SH_TILE_RS + 4 * q) =
+                make_float4(4 * q < SH ? y[4 * q < SH ? 4 * q : 0] : 0.0f,
+                            4 * q + 1 < SH ? y[4 * q + 1 < SH ? 4 * q + 1 : 0] : 0.0f,
+                            4 * q + 2 < SH ? y[4 * q + 2 < SH ? 4 * q + 2 : 0] : 0.0f,
+                            4 * q + 3 < SH ? y[4 * q + 3 < SH ? 4 * q + 3 : 0] : 0.0f);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int64_t e0 = e_raw - lane;                // first edge of this wave
+        const int64_t n_here = E - e0 < 64 ? E - e0 : 64;
+        float4* dst = reinterpret_cast<float4*>(sh_sorted + e0 * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = i * 64 + lane;                // 16-byte piece f of the wave's 8 KB: row f / 8, piece f % 8
+            if ((f >> 3) < n_here)
+                dst[f] = *reinterpret_cast<const float4*>(tile + (f >> 3) * SH_TILE_RS + 4 * (f & 7));
+        }
+    } else if (live) {
 #pragma unroll
         for (int k = 0; k < SH; ++k) sh_sorted[e * sh_stride + k] = y[k];
         for (int k = SH; k < sh_stride; ++k) sh_sorted[e * sh_stride + k] = 0.0f;
     }
+    if (!live) return;
 
     if (edge_vectors) {
         edge_vectors[3 * o + 0] = vx;
