@@ -39,8 +39,10 @@ B_ALG_PER_EDGE_TP = 4816.0  # mean algorithmic bytes per edge-TP, 2-kernel archi
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 10 + 50 forwards = 0.3 s of device time (the first few forwards after the seconds of host-side model
+    # construction run at ramping clocks: 3 warm-up steps measured 1.5 % below the steady state)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--crystals", type=int, default=1000, help="crystals per rank per step (one batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="crystals in the CPU-oracle sample batch")

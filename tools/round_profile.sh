@@ -5,10 +5,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.log 2>&1
 f=$(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$f" $R/gpurun_out/${TAG}_kernel_stats.csv
-python3 $R/bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $R/gpurun_out/${TAG}_bench.json
+python3 $R/bench.py 2>/dev/null | tail -1 > $R/gpurun_out/${TAG}_bench.json
 bash $R/tools/collect_traffic.sh $TAG
 head -8 $R/gpurun_out/${TAG}_kernel_stats.csv
 cat $R/gpurun_out/${TAG}_bench.json | cut -c1-600
