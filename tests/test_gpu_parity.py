@@ -71,6 +71,33 @@ def test_csr_counting_and_radix_builds_agree_with_a_stable_sort(n_nodes, n_edges
     assert int(err.item()) == 0
 
 
+def test_csr_properties_at_full_size():
+    """BASELINE configs[2] size (1000 fcc-64 crystals, 1.15 M edges): the CSR is a permutation, sorted by destination,
+    stable inside a destination, and rowptr / src_sorted agree with it (size-independent properties, checked on device)"""
+    from matten_amd import ops
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import collate
+
+    graphs = synthetic.fcc64_graphs(64)
+    b = collate([graphs[i % 64] for i in range(1000)], device=DEV)
+    ei, N = b["edge_index"], b["pos"].shape[0]
+    E = ei.shape[1]
+    assert E == 1152 * 1000
+    perm, rowptr, src, err = ops.csr_build(ei, N)
+    p = perm.long()
+    assert int(err.item()) == 0
+    assert torch.equal(torch.sort(p).values, torch.arange(E, device=DEV))            # a permutation
+    dst = ei[1][p]
+    assert bool((dst[1:] >= dst[:-1]).all())                                          # sorted by destination
+    same = dst[1:] == dst[:-1]
+    assert bool((p[1:][same] > p[:-1][same]).all())                                   # stable inside a destination
+    assert torch.equal(rowptr.long(), torch.cat([torch.zeros(1, dtype=torch.long, device=DEV),
+                                                 torch.bincount(ei[1], minlength=N).cumsum(0)]))
+    assert torch.equal(src.long(), ei[0][p])
+    again = ops.csr_build(ei, N)
+    assert all(torch.equal(x, y) for x, y in zip((perm, rowptr, src), again[:3]))     # atomics inside, same result
+
+
 def test_csr_empty_and_bad_index():
     from matten_amd import ops
 
