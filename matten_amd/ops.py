@@ -577,7 +577,8 @@ def segment_reduce_bwd(dy, ptr, n_rows: int, mean: bool) -> torch.Tensor:
 def neighbor_list(pos64, cell64, ptr, reach, pair_ptr, r_cut: float, max_atoms: int, n_pairs: int):
     """Periodic neighbour list of a batch of crystals, canonical (i, j, Sx, Sy, Sz) order.
     pair_ptr[B+1] = running sum of n_b^2 (ordered pairs numbered crystal by crystal, i-major), n_pairs = pair_ptr[B].
-    -> (edge_index [2,E] i64 (global ids), edge_cell_shift [E,3] f32, pair_offsets [n_pairs+1] i64)"""
+    -> (edge_index [2,E] i64 (global ids), edge_cell_shift [E,3] f32, pair_offsets [n_pairs+1] i64,
+        smallest edge count of a crystal: an int, read back together with the edge count)"""
     lib = _lib.load()
     pos64 = _need(pos64, torch.float64, "pos")
     cell64 = _need(cell64, torch.float64, "cell")
@@ -595,7 +596,13 @@ def neighbor_list(pos64, cell64, ptr, reach, pair_ptr, r_cut: float, max_atoms: 
         )
     offsets = torch.zeros(n_pairs + 1, dtype=torch.int64, device=dev)
     torch.cumsum(counts, 0, dtype=torch.int64, out=offsets[1:])
-    E = int(offsets[-1]) if n_pairs else 0  # the one host sync of graph construction: the edge count sizes the outputs
+    # the one host sync of graph construction: the edge count sizes the outputs; the smallest edge count of a crystal
+    # (0: the caller has to find and report the edgeless ones) rides on the same read-back
+    if n_pairs:
+        per_crystal = offsets[pair_ptr[1:]] - offsets[pair_ptr[:-1]]
+        E, min_edges = torch.stack([offsets[-1], per_crystal.min()]).tolist()
+    else:
+        E, min_edges = 0, 0
     edge_index = torch.empty(2, E, dtype=torch.int64, device=dev)
     shifts = torch.empty(E, 3, dtype=torch.float32, device=dev)
     with _timed("neighbor_fill"):
@@ -604,4 +611,4 @@ def neighbor_list(pos64, cell64, ptr, reach, pair_ptr, r_cut: float, max_atoms: 
                                      int(max_atoms), _ptr(offsets), E, _ptr(edge_index), _ptr(shifts), _stream()),
             "matten_neighbor_fill",
         )
-    return edge_index, shifts, offsets
+    return edge_index, shifts, offsets, int(min_edges)
