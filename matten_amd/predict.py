@@ -198,7 +198,10 @@ def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
                 p = preds[tensor_target_name]
                 if p.dim() == 2:  # irreps -> Cartesian on the GPU
                     p = converter.to_cartesian(p)
-                out[torch.as_tensor(ids, device=device)] = p
+                if len(ids) and ids[-1] - ids[0] + 1 == len(ids):
+                    out[int(ids[0]) : int(ids[-1]) + 1] = p     # a plain range: no index upload (a blocking copy
+                else:                                            # queued behind the forward would stall the host here)
+                    out[torch.as_tensor(ids, device=device)] = p
             nxt = build(chunks[k + 1]) if k + 1 < len(chunks) else None  # overlaps the forward just enqueued
     return out.cpu().numpy(), sorted(edgeless)
 
