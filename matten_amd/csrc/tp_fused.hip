@@ -511,7 +511,9 @@ struct TwoDeepOk { static constexpr bool value = L1 == 0 || (L1 == 1 && GI == 0)
 
 // TWO_DEEP is a template parameter, not a run-time flag: with both gather schedules in one instantiation the compiler
 // reconciled their register assignments with 50-90 v_mov per CHUNK (60 % of the l1 = 0 kind's vector instructions).
-template <int L1, int GI, int TT, bool TWO_DEEP, bool PAIRED, class Epilogue>
+// CMASK != 0: the entry's coupling mask as a compile-time constant (HotMask below); the couplings of a step then form
+// one basic block instead of NC uniformly-branched ones
+template <int L1, int GI, int TT, bool TWO_DEEP, bool PAIRED, unsigned CMASK, class Epilogue>
 __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry& ge, float* __restrict__ tile,
                                                  float* __restrict__ stage, int entry, int node, int lane, bool valid,
                                                  int beg, int deg_node, int maxdeg, const Epilogue& epi) {
@@ -671,7 +673,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             }
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
-            G::apply(mask, x, y, w, acc);
+            G::apply(CMASK ? CMASK : mask, x, y, w, acc);
         };
         if (two_deep) {
             for (int so = 0; so < CH; so += 2) {   // CH is 2, 4 or 8 here: slot pairs, one row buffer per parity
@@ -719,12 +721,27 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     epi.template store<G>(a, ge, acc, a_scale_inv, node, j, u, valid);
 }
 
+// Coupling masks worth a specialisation: only the scalar-block kind (all five couplings, or l2 <= 3 when the target has
+// no 4o) -- for every other kind the extra instantiations cost the rest of the kernel more than they gain (DESIGN.md
+// section 8: the register allocation of this one function is shared by all kinds).
+template <int L1, int GI> struct HotMask { static constexpr unsigned M0 = 0, M1 = 0; };
+#ifndef TPF_NO_HOT_MASKS
+template <> struct HotMask<0, 0> { static constexpr unsigned M0 = 0x1f, M1 = 0xf; };
+#endif
+#define MATTEN_RGS_ARGS a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}
+#define MATTEN_RGS(L1, GI, TT, TD, P) \
+    do { \
+        using HM = HotMask<L1, GI>; \
+        if (HM::M0 && ge.mask == HM::M0) run_group_shared<L1, GI, TT, TD, P, HM::M0>(MATTEN_RGS_ARGS); \
+        else if (HM::M1 && ge.mask == HM::M1) run_group_shared<L1, GI, TT, TD, P, HM::M1>(MATTEN_RGS_ARGS); \
+        else run_group_shared<L1, GI, TT, TD, P, 0u>(MATTEN_RGS_ARGS); \
+    } while (0)
 #define MATTEN_GROUP_CASE_SHARED(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): \
-        if (paired) run_group_shared<L1, GI, 1, false, true>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
-        else if (nodes_per_wave > 16) run_group_shared<L1, GI, 2, false, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
-        else if (TwoDeepOk<L1, GI>::value && nodes_per_wave <= 8 && nodes_per_wave >= TPF_TWO_DEEP_MIN_NPW) run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
-        else run_group_shared<L1, GI, 1, false, false>(a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}); \
+        if (paired) MATTEN_RGS(L1, GI, 1, false, true); \
+        else if (nodes_per_wave > 16) MATTEN_RGS(L1, GI, 2, false, false); \
+        else if (TwoDeepOk<L1, GI>::value && nodes_per_wave <= 8 && nodes_per_wave >= TPF_TWO_DEEP_MIN_NPW) MATTEN_RGS(L1, GI, 1, (TwoDeepOk<L1, GI>::value), false); \
+        else MATTEN_RGS(L1, GI, 1, false, false); \
         break;
 
 #define MATTEN_GROUP_CASE(L1, GI) \
@@ -841,7 +858,7 @@ struct Lin2Args {
 };
 
 #define MATTEN_LIN2_CASE(L1, GI) \
-    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value, false>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreLds{tile}); break;
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group_shared<L1, GI, 1, TwoDeepOk<L1, GI>::value, false, 0u>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreLds{tile}); break;
 
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_lin2_kernel(Args a, Lin2Args la,
                                                                                       const GroupEntry* __restrict__ entries) {
