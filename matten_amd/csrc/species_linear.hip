@@ -62,8 +62,14 @@ namespace {
 // upper half was stale for a few shapes (d = 1 blocks with an addend; tools/sl_check.py finds them).  The hardware
 // was ruled out -- overlapping vDst/SrcA/SrcB/SrcC, dependent chains and MFMA -> VALU reads are all interlocked
 // on gfx950, only MFMA -> VMEM-store needs 8 wait states and clang leaves 10 (tools/ubench/mfma_overlap.hip,
-// mfma_latency.hip) -- and the miscompile was not root-caused.  The tied form below leaves the register allocator
-// nothing to move; it passes the full sweep (tests/test_gpu_parity.py::test_species_linear_shape_sweep).
+// mfma_latency.hip).  Root cause (found in round 2 when a variant of this kernel reproduced it deterministically: the
+// last matrix instructions of a step lost for some accumulators): SimplifyCFG sinks the accumulator updates of
+// different template paths into one store through a PHI of POINTERS, which keeps those accumulators in scratch memory
+// (load - MFMA - scratch_store).  With the builtin the compiler pads the MFMA -> store hazard itself but shuffles
+// tuples; with inline asm its hazard recogniser is blind and the scratch store reads a result that is not there yet.
+// The file is therefore built with -mllvm -simplifycfg-sink-common=false (Makefile): every accumulator stays in
+// registers.  The tied form below leaves the register allocator nothing to move; it passes the full sweep
+// (tests/test_gpu_parity.py::test_species_linear_shape_sweep, tools/sl_fuzz.py).
 // The hazard recogniser does not look inside inline asm, hence the explicit wait states: s_nop 1 in front (VALU
 // write of an operand -> MFMA read) and mfma_drain() after the last MFMA of every straight-line group, before
 // anything else may read, copy or store an accumulator.
