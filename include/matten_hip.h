@@ -304,13 +304,17 @@ int matten_dense_rows(const float* x, int64_t n_in, const float* q, int64_t n_ou
 /* adjoint of matten_tp_paths / matten_tp_scatter (w_edge in the reference column order):
  *   dw[e,q]              = norm * sum_ijk C_ijk x[src,x_base+i] Y[e,y_off+j] G[dst,out_base+k]
  *   dx[src, x_base + i] += norm * w[e,q] * sum_jk C_ijk Y[e,y_off+j] G[dst,out_base+k]     (dx zero-initialised)
- *   col_meta[n_cols,4] int32 {x_base, out_base, nnz_begin, nnz_count | y_off<<16}; nnz_ijk[nnz,4] uint8 {i,j,k,0};
- *   nnz_c[nnz] = sqrt(2 l3+1) C_ijk */
+ *   col_meta[n_cols,4] int32 {x_base, out_base, nnz_begin, nnz_count | y_off<<16}; nnz_ijk[nnz,4] uint8 {i,j,k,0}
+ *   (i-major per coupling); nnz_c[nnz] = sqrt(2 l3+1) C_ijk
+ *   in_ptr[n_in+1] / in_cols[n_cols] (both or neither): the weight columns grouped by the input channel (x_base) they
+ *   read.  With them a thread owns (edge, input channel) and adds its paths' contributions to dx in registers: one
+ *   atomic per (edge, channel, component) instead of one per path; without, one thread per (edge, column). */
 int matten_tp_backward(const float* x, int64_t d_in, const float* w_edge, int64_t w_ld, const float* sh_sorted,
                        int64_t sh_stride, const int32_t* src_sorted, const int32_t* dst_sorted,
                        const int32_t* col_meta, int64_t n_cols, const uint8_t* nnz_ijk, const float* nnz_c,
                        const float* g_agg, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
-                       int64_t n_edges, float* dx, float* dw, int64_t dw_ld, matten_stream_t stream);
+                       int64_t n_edges, float* dx, float* dw, int64_t dw_ld, const int32_t* in_ptr,
+                       const int32_t* in_cols, int64_t n_in, matten_stream_t stream);
 
 /* adjoint of matten_species_linear w.r.t. the packed weights (the adjoint w.r.t. x is matten_species_linear
  * itself with the transposed segment table and transposed packed weights):

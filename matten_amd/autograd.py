@@ -10,6 +10,8 @@ the design rules reserve libraries for: the radial MLP (three bias-free GEMMs ov
 """
 from typing import Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -85,7 +87,9 @@ class TensorProductScatterFn(torch.autograd.Function):
         sh, src, dst = ctx.graph
         dx, dw = ops.tp_backward(x, w_edge, sh, src, dst, mod._tables.get("bw_col_meta", dev),
                                  mod._tables.get("bw_nnz_ijk", dev), mod._tables.get("bw_nnz_c", dev), g.contiguous(),
-                                 ctx.avg, ctx.num_neigh)
+                                 ctx.avg, ctx.num_neigh,
+                                 in_groups=None if os.environ.get("MATTEN_TP_BWD_GROUPED", "1") == "0" else
+                                 (mod._tables.get("bw_in_ptr", dev), mod._tables.get("bw_in_cols", dev)))
         return dx, dw, None, None, None, None
 
 

@@ -37,26 +37,91 @@ __global__ void tp_backward_kernel(const float* __restrict__ x, int d_in, const 
     const float* yp = sh + e * sh_stride + y_off;
     const float* gp = g_agg + (int64_t)dst * d_mid + m.y;
     const float wv = w_edge[e * w_ld + q];
-    float dwv = 0.0f;
-    float dxi[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) dxi[i] = 0.0f;
+    float* dxp = dx + (int64_t)src * d_in + m.x;
+    const float s = wv * norm;
+    // The non-zeros of a coupling are stored i-major (plan.py: np.nonzero order), so the terms of one input component
+    // are consecutive: sum them in a scalar and flush per component -- one x load and one atomic per component, no
+    // per-term scatter into a register array (that was nine compare / select pairs per term).
+    float dwv = 0.0f, acc = 0.0f;
+    int cur = cnt > 0 ? (int)nnz_ijk[m.z].x : 0;
     for (int t = 0; t < cnt; ++t) {
         const uchar4 ijk = nnz_ijk[m.z + t];
         const float c = nnz_c[m.z + t];
-        const float yg = c * yp[ijk.y] * gp[ijk.z];
-        dwv = fmaf(yg, xp[ijk.x], dwv);
-        // static-index scatter into the per-lane array
-#pragma unroll
-        for (int i = 0; i < 9; ++i)
-            if (i == ijk.x) dxi[i] += yg;
+        if ((int)ijk.x != cur) {
+            dwv = fmaf(acc, xp[cur], dwv);
+            if (acc != 0.0f) atomicAdd(dxp + cur, s * acc);
+            cur = ijk.x;
+            acc = 0.0f;
+        }
+        acc = fmaf(c * yp[ijk.y], gp[ijk.z], acc);
+    }
+    if (cnt > 0) {
+        dwv = fmaf(acc, xp[cur], dwv);
+        if (acc != 0.0f) atomicAdd(dxp + cur, s * acc);
     }
     dw[e * dw_ld + q] = dwv * norm;
-    float* dxp = dx + (int64_t)src * d_in + m.x;
-    const float s = wv * norm;
+}
+
+// The same adjoint with the weight columns grouped by the INPUT channel they read (in_ptr / in_cols: columns of channel
+// c are in_cols[in_ptr[c] .. in_ptr[c+1])): a thread owns (edge, input channel), walks that channel's 5-9 paths and adds
+// their contributions to dx in registers, so the gather adjoint costs one atomic per (edge, channel, component)
+// instead of one per (edge, path, channel, component).  The atomics were most of the per-column kernel's time
+// (~120 M of them per layer at 290 k edges).
+__global__ void tp_backward_grouped_kernel(const float* __restrict__ x, int d_in, const float* __restrict__ w_edge, int w_ld,
+                                           const float* __restrict__ sh, int sh_stride,
+                                           const int32_t* __restrict__ src_sorted, const int32_t* __restrict__ dst_sorted,
+                                           const int4* __restrict__ col_meta, const int32_t* __restrict__ in_ptr,
+                                           const int32_t* __restrict__ in_cols, int n_in,
+                                           const uchar4* __restrict__ nnz_ijk, const float* __restrict__ nnz_c,
+                                           const float* __restrict__ g_agg, int d_mid, float avg_nn,
+                                           const float* __restrict__ num_neigh, int64_t E, float* __restrict__ dx,
+                                           float* __restrict__ dw, int dw_ld) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * n_in) return;
+    const int64_t e = idx / n_in;
+    const int ch = (int)(idx - e * n_in);
+    const int src = src_sorted[e], dst = dst_sorted[e];
+    const float norm = 1.0f / sqrtf(avg_nn > 0.0f ? avg_nn : num_neigh[dst]);
+    const float* yrow = sh + e * sh_stride;
+    const float* grow = g_agg + (int64_t)dst * d_mid;
+    float dxi[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
-        if (dxi[i] != 0.0f) atomicAdd(dxp + i, s * dxi[i]);
+    for (int i = 0; i < 9; ++i) dxi[i] = 0.0f;
+    const int c0 = in_ptr[ch], c1 = in_ptr[ch + 1];
+    int x_base = 0;
+    for (int cc = c0; cc < c1; ++cc) {
+        const int q = in_cols[cc];
+        const int4 m = col_meta[q];
+        const int cnt = m.w & 0xffff;
+        x_base = m.x;
+        const float* xp = x + (int64_t)src * d_in + m.x;
+        const float* yp = yrow + (m.w >> 16);
+        const float* gp = grow + m.y;
+        const float wv = w_edge[e * w_ld + q];
+        float dwv = 0.0f, acc = 0.0f;
+        int cur = cnt > 0 ? (int)nnz_ijk[m.z].x : 0;
+        for (int t = 0; t <= cnt; ++t) {   // one extra round flushes the last component
+            const bool more = t < cnt;
+            const uchar4 ijk = more ? nnz_ijk[m.z + t] : uchar4{255, 0, 0, 0};
+            if ((int)ijk.x != cur) {
+                dwv = fmaf(acc, xp[cur], dwv);
+                const float contrib = wv * acc;
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    if (i == cur) dxi[i] += contrib;
+                cur = ijk.x;
+                acc = 0.0f;
+            }
+            if (more) acc = fmaf(nnz_c[m.z + t] * yp[ijk.y], gp[ijk.z], acc);
+        }
+        dw[e * dw_ld + q] = dwv * norm;
+    }
+    if (c1 > c0) {
+        float* dxp = dx + (int64_t)src * d_in + x_base;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -276,6 +341,7 @@ extern "C" int matten_tp_backward(const float* x, int64_t d_in, const float* w_e
                                   const int32_t* col_meta, int64_t n_cols, const uint8_t* nnz_ijk, const float* nnz_c,
                                   const float* g_agg, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
                                   int64_t n_edges, float* dx /*zero-initialised [N,d_in]*/, float* dw, int64_t dw_ld,
+                                  const int32_t* in_ptr, const int32_t* in_cols, int64_t n_in,
                                   matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || d_in <= 0 || n_cols <= 0 || d_mid <= 0 || w_ld < n_cols || dw_ld < n_cols) return MATTEN_EINVAL;
@@ -284,6 +350,16 @@ extern "C" int matten_tp_backward(const float* x, int64_t d_in, const float* w_e
         return MATTEN_EINVAL;
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
     const int T = 256;
+    if ((in_ptr == nullptr) != (in_cols == nullptr) || (in_ptr && n_in <= 0)) return MATTEN_EINVAL;
+    if (in_ptr) {
+        if (matten_cdiv(n_edges * n_in, T) >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+        tp_backward_grouped_kernel<<<(unsigned)matten_cdiv(n_edges * n_in, T), T, 0, stream>>>(
+            x, (int)d_in, w_edge, (int)w_ld, sh_sorted, (int)sh_stride, src_sorted, dst_sorted, (const int4*)col_meta,
+            in_ptr, in_cols, (int)n_in, (const uchar4*)nnz_ijk, nnz_c, g_agg, (int)d_mid, avg_num_neighbors, num_neigh,
+            n_edges, dx, dw, (int)dw_ld);
+        MATTEN_LAUNCH_CHECK();
+        return MATTEN_OK;
+    }
     tp_backward_kernel<<<(unsigned)matten_cdiv(n_edges * n_cols, T), T, 0, stream>>>(
         x, (int)d_in, w_edge, (int)w_ld, sh_sorted, (int)sh_stride, src_sorted, dst_sorted, (const int4*)col_meta,
         (int)n_cols, (const uchar4*)nnz_ijk, nnz_c, g_agg, (int)d_mid, avg_num_neighbors, num_neigh, n_edges, dx, dw,

@@ -214,6 +214,7 @@ class UVUTensorProduct(torch.nn.Module):
             entries=self.plan.path_entries, unit_start=self.plan.unit_start,
             gentries=self.plan.group_entries, gstart=self.plan.group_unit_start, gumap=self.plan.fused_unit_map,
             bw_col_meta=self.plan.bw_col_meta, bw_nnz_ijk=self.plan.bw_nnz_ijk, bw_nnz_c=self.plan.bw_nnz_c,
+            bw_in_ptr=self.plan.bw_in_ptr, bw_in_cols=self.plan.bw_in_cols,
         )
 
         self._a_split = DerivedWeight(self._split_last_layer)

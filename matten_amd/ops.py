@@ -490,8 +490,9 @@ def dense_rows(x, q) -> torch.Tensor:
 # adjoint operators (training step)
 # ---------------------------------------------------------------------------------------------------
 def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk, nnz_c, g_agg,
-                avg_num_neighbors: float, num_neigh=None):
-    """-> (dx [N,d_in], dw [E,W]) for agg = tp(x, w_edge) with w_edge in the reference column order."""
+                avg_num_neighbors: float, num_neigh=None, in_groups=None):
+    """-> (dx [N,d_in], dw [E,W]) for agg = tp(x, w_edge) with w_edge in the reference column order.
+    in_groups: optional (in_ptr [n_in+1] i32, in_cols [W] i32) = the columns grouped by input channel (plan.bw_in_*)."""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
     w_edge = _need(w_edge, torch.float32, "w_edge")
@@ -507,7 +508,9 @@ def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk,
         lib.matten_tp_backward(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
                                _ptr(src_sorted), _ptr(dst_sorted), _ptr(col_meta), W, _ptr(nnz_ijk), _ptr(nnz_c),
                                _ptr(g_agg), g_agg.shape[1], float(avg_num_neighbors or 0.0), _ptr(num_neigh), E,
-                               _ptr(dx), _ptr(dw), W, _stream()),
+                               _ptr(dx), _ptr(dw), W, _ptr(in_groups[0]) if in_groups else None,
+                               _ptr(in_groups[1]) if in_groups else None,
+                               in_groups[0].shape[0] - 1 if in_groups else 0, _stream()),
         "matten_tp_backward",
     )
     return dx, dw

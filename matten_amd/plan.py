@@ -176,6 +176,8 @@ class UVUPlan:
     bw_col_meta: np.ndarray = None    # int32 [W, 4] {x_base, out_base, nnz_begin, nnz_count | y_off << 16}
     bw_nnz_ijk: np.ndarray = None     # uint8 [nnz, 4]
     bw_nnz_c: np.ndarray = None       # f32 [nnz]
+    bw_in_ptr: np.ndarray = None      # int32 [n_in+1] / bw_in_cols int32 [W]: weight columns grouped by input channel
+    bw_in_cols: np.ndarray = None
 
 
 def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
@@ -376,7 +378,13 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
         for u in range(p.mul):
             col_meta[p.w_off + u] = (p.x_off + u * d1, p.out_off + u * d3, b0, cnt | (sh_offs[p.l2] << 16))
+    # weight columns grouped by the input channel they read (stable: reference column order inside a group)
+    in_order = np.argsort(col_meta[:, 0], kind="stable")
+    xb_sorted = col_meta[in_order, 0]
+    starts = np.nonzero(np.concatenate([[True], xb_sorted[1:] != xb_sorted[:-1]]))[0]
+    bw_in_ptr = np.concatenate([starts, [len(in_order)]]).astype(np.int32)
     return UVUPlan(
+        bw_in_ptr=bw_in_ptr, bw_in_cols=in_order.astype(np.int32),
         bw_col_meta=col_meta.astype(np.int32), bw_nnz_ijk=np.array(nnz_ijk, dtype=np.uint8).reshape(-1, 4),
         bw_nnz_c=np.array(nnz_c, dtype=np.float32),
         irreps_in1=irreps_in1, irreps_sh=irreps_sh, irreps_mid=irreps_mid, irreps_out=irreps_mid.simplify(),
