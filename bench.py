@@ -3,7 +3,10 @@
 bench.py -- headline benchmark of the MI355X message-passing hot path.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  N > 1 (or --force-dist / MATTEN_FORCE_DIST=1 with N = 1): when not already running as a rank of torch.distributed.run
+  (RANK / WORLD_SIZE in the environment: how the driver starts it), the process -- which has not touched the GPU --
+  starts `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a CHILD and exits with
+  its code; the ranks (one per GPU) use RCCL (torch.distributed backend "nccl").
 
 A "step" is one full backbone + out_layer forward (a1-a13 of SURVEY.md section 8) over one batch of
 synthetic 64-atom fcc crystals already resident in HBM (BASELINE.json configs[2]: 1000 crystals,
@@ -16,19 +19,22 @@ Printed by rank 0: one JSON line with the driver contract fields plus
   "roofline"     -- the dominant kernel (tp_fused_kernel, mean over its launches) against the HBM roofline
   "cpu_baseline" -- the CPU oracle (a restatement of the reference's e3nn path, NOT e3nn itself;
                     e3nn cannot be installed on either box) timed on a bounded sample, rank 0, N=1
+  "extras"       -- short driver-timed runs of the other single-GPU configurations (N = 1 only; --no-extras skips):
+                    configs[1] n100 forward, configs[3] training step (batch 32, eager and hipGraph) with the roofline
+                    of its dominant kernel, predict() end to end at batch_size 200 / 1000
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+# torch / numpy are imported inside run_rank(): the launcher path below must stay free of anything GPU
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3e12  # flop/s, dense fp32 MFMA (same guide)
@@ -46,18 +52,262 @@ def parse():
     ap.add_argument("--crystals", type=int, default=1000, help="crystals per rank per step (one batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="crystals in the CPU-oracle sample batch")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] / predict() extras")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the RCCL path (init, barrier, all_gather) even with one rank (same as MATTEN_FORCE_DIST=1)")
     return ap.parse_args()
 
 
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """Start the N ranks as a child `torch.distributed.run` (this process has initialised nothing on the GPU and never
+    replaces itself: a child process, not an exec) and hand its exit code back."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    if args.force_dist:
+        env["MATTEN_FORCE_DIST"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def _pmc_traffic(kernel: str, field: str = "hbm_bytes_mean_launch"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC run (profiles/hbm_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes, gfx950 x2 correction on FETCH_SIZE), or None.
-    'hbm_bytes_mean_launch' averages over the kernel's launches of a forward, 'hbm_bytes_per_launch' is the largest."""
+    """(HBM bytes per launch of `kernel`, where that number comes from) from the committed rocprofv3 PMC run
+    (profiles/hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, gfx950 x2 correction on
+    FETCH_SIZE), or (None, None).  'hbm_bytes_mean_launch' averages over the kernel's launches of a forward,
+    'hbm_bytes_per_launch' is the largest."""
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            return float(json.load(f)["kernels"][kernel][field])
+            d = json.load(f)
+        return float(d["kernels"][kernel][field]), (f"profiles/hbm_traffic.json (tag {d.get('tag', '?')}"
+                                                    f"{', commit ' + d['commit'] if d.get('commit') else ''}): a separate "
+                                                    "rocprofv3 --pmc run of bench.py --steps 2, not this run")
     except Exception:
-        return None
+        return None, None
+
+
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def _time_cpu(fn, warmup: int = 3, n: int = 10, budget_s: float = 12.0):
+    """SURVEY 8d protocol: 3 warm-up + median of 10 timed forwards; a time budget bounds slow configurations (at least
+    3 timed forwards are taken).  -> (median seconds, forwards timed, last result)"""
+    t_start = time.perf_counter()
+    res = None
+    for i in range(warmup):
+        res = fn()
+        if time.perf_counter() - t_start > budget_s / 2 and i >= 0:
+            break
+    times = []
+    while len(times) < n and (len(times) < 3 or time.perf_counter() - t_start < budget_s):
+        t1 = time.perf_counter()
+        res = fn()
+        times.append(time.perf_counter() - t1)
+    times.sort()
+    return times[len(times) // 2], len(times), res
+
+
+def cpu_baseline(args, model, graphs, ds, gpu_out, n_layers):
+    """The CPU oracle (kind "port": the builder's restatement of the reference's e3nn path -- e3nn itself cannot be
+    installed on either box) on bounded samples of configs 1-3, eval mode, no_grad, fp32, same weights as the GPU model
+    for the headline configuration."""
+    from __graft_entry__ import PAPER_HPARAMS
+    from matten_amd.data.graph import average_num_neighbors, collate, crystal_graph
+    from matten_amd.data.io import structures_from_json
+    from oracle.matten_ref.model import ScalarTensorOracle
+
+    # The oracle's per-path einsums are small: beyond ~16 threads it gets slower, not faster
+    # (256 host threads on the MI355X box: >100x slower), so the baseline uses at most 16.
+    nthreads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(nthreads)
+    ref = ScalarTensorOracle(dict(PAPER_HPARAMS), ds).eval()
+    ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=False)
+    sample = collate(graphs[: args.cpu_sample])
+    e_sample = int(sample["edge_index"].shape[1])
+    with torch.no_grad():
+        med, n_timed, want = _time_cpu(lambda: ref.decode(dict(sample)))
+    err = (gpu_out[: args.cpu_sample].cpu() - want).abs().max().item()
+    base = {
+        "value": e_sample * n_layers / med,
+        "unit": "edge-TP/s",
+        "cores": nthreads,
+        "cpu_model": _cpu_model(),
+        "host_cores_available": os.cpu_count(),
+        "kind": "port",
+        "sample": f"configs[2]: {args.cpu_sample} fcc-64 crystals ({e_sample} edges) per forward, median of {n_timed} "
+                  f"forwards after 3 warm-up; pure-PyTorch fp32 restatement of the e3nn path (not e3nn)",
+        "crystals_per_sec": args.cpu_sample / med,
+        "max_abs_diff_vs_gpu": err,
+    }
+    # configs[0] (Si diamond, the reference's README example) and configs[1] (the reference's n100 example set)
+    others = {}
+    a = 5.46
+    si = crystal_graph(np.array([[0.0, 0, 0], [a / 4, a / 4, a / 4]]),
+                       np.array([[0, a / 2, a / 2], [a / 2, 0, a / 2], [a / 2, a / 2, 0]]), np.array([14, 14]), 5.0)
+    n100 = structures_from_json(os.path.join(ROOT, "tests", "golden", "example_crystal_elasticity_tensor_n100.json"))
+    g100 = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in n100]
+    for name, gs in (("configs[0] Si diamond", [si]), ("configs[1] n100", g100)):
+        species = sorted({int(z) for g in gs for z in g["atomic_numbers"].tolist()})
+        torch.manual_seed(35)
+        r = ScalarTensorOracle(dict(PAPER_HPARAMS), {"allowed_species": species,
+                                                     "average_num_neighbors": average_num_neighbors(gs)}).eval()
+        b = collate(gs)
+        with torch.no_grad():
+            m, k, _ = _time_cpu(lambda: r.decode(dict(b)), budget_s=10.0)
+        e = int(b["edge_index"].shape[1])
+        others[name] = {"crystals": len(gs), "atoms": int(b["pos"].shape[0]), "edges": e, "ms_per_forward": 1e3 * m,
+                        "edge_TP_per_sec": e * n_layers / m, "crystals_per_sec": len(gs) / m, "forwards_timed": k}
+    base["other_configs"] = others
+    return base
+
+
+def extras(dev):
+    """Short timed runs of the remaining single-GPU configurations of BASELINE.json (random-init weights, synthetic or
+    repo-held inputs; the Zenodo training set and the checkpoint are not available): see the module docstring."""
+    from __graft_entry__ import PAPER_HPARAMS
+    from matten_amd import ops
+    from matten_amd import predict as P
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import average_num_neighbors, batch_graphs_gpu, collate, crystal_graph
+    from matten_amd.data.io import structures_from_json
+    from matten_amd.graphs import GraphedForward, GraphedTrainStep
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+
+    ex = {}
+    n100 = structures_from_json(os.path.join(ROOT, "tests", "golden", "example_crystal_elasticity_tensor_n100.json"))
+    species = sorted({int(z) for s in n100 for z in s["atomic_numbers"]})
+    n_layers = PAPER_HPARAMS["num_layers"] + 1
+
+    def timed(fn, warm, n):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, r
+
+    # ---- configs[1]: the reference's n100 example set as ONE batch, paper hparams, 73 species ----
+    torch.manual_seed(35)
+    ds = {"allowed_species": species, "average_num_neighbors": 30.4017}
+    model = ScalarTensorModel(backbone_hparams=dict(PAPER_HPARAMS), dataset_hparams=ds).to(dev).eval()
+    batch = batch_graphs_gpu([(s["cart_coords"], s["lattice"], s["atomic_numbers"]) for s in n100], 5.0, dev)
+    E = int(batch["edge_index"].shape[1])
+    with torch.no_grad():
+        t_eager, _ = timed(lambda: model(dict(batch))[0]["elastic_tensor_full"], 5, 50)
+        g = GraphedForward(model, batch)
+        t_graph, _ = timed(lambda: g(batch), 5, 50)
+    ex["configs[1]_n100_forward"] = {
+        "crystals": len(n100), "atoms": int(batch["pos"].shape[0]), "edges": E, "species": len(species), "dtype": "f32",
+        "ms_per_forward_eager": 1e3 * t_eager, "ms_per_forward_hipgraph": 1e3 * t_graph,
+        "edge_TP_per_sec_hipgraph": E * n_layers / t_graph, "crystals_per_sec_hipgraph": len(n100) / t_graph,
+        "note": "launch-bound at this size (~45 launches): the hipGraph replay is the rate to quote",
+    }
+    del model, g
+
+    # ---- configs[3]: one optimisation step, lmax = 2, 3 gated blocks, batch 32, BatchNorm batch statistics, MSE in
+    # irreps space, Adam; synthetic-Zenodo-like = the n100 set's size distribution (SURVEY 8d config 4) ----
+    lmax2 = dict(PAPER_HPARAMS, irreps_edge_sh="0e + 1o + 2e", conv_layer_irreps="32x0o+32x0e+16x1o+16x1e+4x2o+4x2e")
+    graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in n100]
+    ds4 = {"allowed_species": species, "average_num_neighbors": average_num_neighbors(graphs)}
+    BS = 32
+    tb = collate(graphs[:BS], device=dev)
+    target = torch.randn(BS, 21, device=dev)
+
+    def make():
+        torch.manual_seed(3)
+        m = ScalarTensorModel(backbone_hparams=dict(lmax2), dataset_hparams=ds4).to(dev).train()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-2, weight_decay=1e-5, fused=True, capturable=True)
+
+    def loss_fn(preds, t):
+        return torch.nn.functional.mse_loss(preds["elastic_tensor_full"], t)
+
+    m_e, opt_e = make()
+
+    def eager_step():
+        loss = loss_fn(m_e(dict(tb))[0], target)
+        opt_e.zero_grad()
+        loss.backward()
+        opt_e.step()
+        return loss
+
+    t_e, _ = timed(eager_step, 5, 20)
+    ops.enable_event_timing(True)
+    for _ in range(5):
+        eager_step()
+    torch.cuda.synchronize()
+    ev = {k: sum(v) / len(v) for k, v in ops.event_timings_ms().items()}
+    ops.enable_event_timing(False)
+    m_g, opt_g = make()
+    gs = GraphedTrainStep(m_g, opt_g, loss_fn, tb, target, warmup=3)
+    t_g, _ = timed(lambda: gs.step(tb, target), 5, 30)
+    Et, Nt = int(tb["edge_index"].shape[1]), int(tb["pos"].shape[0])
+    rec = {
+        "crystals": BS, "atoms": Nt, "edges": Et, "dtype": "f32 (the reference's dtype; bf16 storage: see 'bf16')",
+        "ms_per_step_eager": 1e3 * t_e, "ms_per_step_hipgraph": 1e3 * t_g, "crystals_per_sec_hipgraph": BS / t_g,
+        "data": "synthetic-Zenodo-like (first 32 crystals of the reference's n100 example, random targets)",
+        "note": "with l <= 2 features the 4e output has no path: 9 of the 21 components are identically 0 (SURVEY 8d)",
+        "kernel_ms_per_launch_eager": {k: v for k, v in ev.items() if k.startswith(("tp_backward", "tp_scatter", "tp_train"))},
+    }
+    # roofline of the step's dominant kernel, the tensor-product adjoint: contract bytes per (edge, layer) of the
+    # two-kernel architecture = ids 8 + vector 12 + w read 4W + dw written 4W + (x and dx rows: 2 d_in, grad rows: d_mid) / deg
+    convs = [m for m in m_e.backbone.modules() if type(m).__name__ == "PointConv"]
+    deg = Et / Nt
+    bw = []
+    for c in convs:
+        p = c.tp.plan
+        k = next((k for k in ev if k.startswith("tp_backward") and k.endswith(f"d_mid={p.d_mid}/d_in={p.d_in}")), None)
+        if k:
+            bw.append(((8.0 + 12.0 + 8.0 * p.weight_numel + 4.0 * (2 * p.d_in + p.d_mid) / deg) * Et, ev[k]))
+    if bw:
+        bytes_mean = sum(b for b, _ in bw) / len(bw)
+        ms_mean = sum(t for _, t in bw) / len(bw)
+        rec["roofline"] = {"kernel": "tp_backward (adjoint of the uvu tensor product + scatter; mean over the conv layers)",
+                           "bound": "hbm", "achieved": bytes_mean / (ms_mean * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                           "unit": "GB/s", "frac": bytes_mean / (ms_mean * 1e-3) / HBM_PEAK, "traffic": None,
+                           "algorithmic_bytes_per_launch": bytes_mean, "avg_launch_ms": ms_mean,
+                           "note": "4.5 k edges per launch: far below the size that fills 256 CUs (launch-bound regime)"}
+    ex["configs[3]_training_step_batch32"] = rec
+    del m_e, m_g, gs
+
+    # ---- predict() end to end: list of 1000 fcc-64 structures in, list of [3,3,3,3] tensors out ----
+    torch.manual_seed(0)
+    dsf = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    model = ScalarTensorModel(backbone_hparams=dict(PAPER_HPARAMS), dataset_hparams=dsf).to(dev).eval()
+    cfg = {"data": {"r_cut": 5.0, "tensor_target_name": "elastic_tensor_full", "tensor_target_formula": "ijkl=jikl=klij"}}
+    structs = synthetic.fcc64_structures(1000)
+    P.predict(structs[:8], model=model, config=cfg)
+    pr = {}
+    for bs in (200, 1000):
+        P.predict(structs, model=model, config=cfg, batch_size=bs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            outp = P.predict(structs, model=model, config=cfg, batch_size=bs)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        pr[f"batch_size={bs}"] = {"ms_per_1000_structures": 1e3 * dt, "crystals_per_sec": len(structs) / dt}
+    assert len(outp) == len(structs)
+    ex["predict_end_to_end_fcc64"] = dict(pr, note="host structure dicts -> device neighbour lists -> forward -> Cartesian "
+                                                     "tensors on the host (PCIe and host packing inside the time)")
+    return ex
+
 
 
 def algorithmic_bytes_tp_kernel(plan, deg: float) -> float:
@@ -68,15 +318,27 @@ def algorithmic_bytes_tp_kernel(plan, deg: float) -> float:
 
 def main():
     args = parse()
+    args.force_dist = args.force_dist or os.environ.get("MATTEN_FORCE_DIST") == "1"
+    in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not in_rank and (args.gpus > 1 or args.force_dist):
+        sys.exit(launch_ranks(args))
+    run_rank(args)
+
+
+def run_rank(args):
+    global np, torch
+    import numpy as np
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    # one process per GPU under torch.distributed.run; MATTEN_FORCE_DIST=1 exercises the RCCL path with a
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py itself (it launches its ranks) or "
+                         f"torch.distributed.run with --nproc-per-node {args.gpus}")
+    # one process per GPU under torch.distributed.run; --force-dist exercises the RCCL path with a
     # single rank too (init, barrier, all_gather) so it can be smoke-tested on a 1-GPU box
-    distributed = world > 1 or (os.environ.get("MATTEN_FORCE_DIST") == "1" and "RANK" in os.environ)
+    distributed = world > 1 or (args.force_dist and "RANK" in os.environ)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -154,6 +416,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "crystals_per_sec": crystals_per_s,
+        "rccl_ranks": dist.get_world_size() if distributed else 0,   # 0: no process group (plain single-GPU run)
         "config": {
             "workload": "configs[2]: synthetic fcc-64 crystals (64 atoms, cutoff 5 A, 1152 edges each), "
                         "paper hparams lmax=4, eval forward backbone+out_layer, one batch per step per GPU",
@@ -217,7 +480,7 @@ def main():
             bytes_per_launch = sum(b for _, b in dom) / len(dom)
             avg_ms = sum(m for m, _ in dom) / len(dom)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = _pmc_traffic(dom_name)
+            traffic, traffic_source = _pmc_traffic(dom_name)
             result["roofline"] = {
                 "kernel": f"{dom_name} (last radial-MLP layer on MFMA + CG paths + neighbour sum"
                           f"{' + lin2 of the l1<=1 input blocks' if light else ''}; mean over its {len(dom)} launches per "
@@ -228,6 +491,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK / 1e9),
                 "traffic": traffic,
+                # NOT measured in this run: PMC counters need their own rocprofv3 passes (separate FETCH_SIZE / WRITE_SIZE
+                # runs of this same command, tools/collect_traffic.sh); the summary they produced is committed and read here
+                "traffic_source": traffic_source,
                 # `achieved` / `frac` price the CONTRACT bytes of the launch (SURVEY 8d two-kernel architecture restricted
                 # to the input blocks this kernel takes: radial weights w[E, W] and agg[N, d_mid] that never exist here).
                 # What the memory system really moves:
@@ -245,14 +511,19 @@ def main():
         result["kernel_ms_per_launch"] = per_kernel
         # ---- matrix-core use of the radial MLP (the only GEMM of the path): hidden layers nb -> 32 -> 32 in
         # radial_hidden_kernel (fp32 MFMA), last layer 32 -> W inside the tensor-product kernels (three fp16-split products) ----
-        if layers and "radial_hidden" in per_kernel:
+        rh_key = next((k for k in ("radial_hidden_multi", "radial_hidden") if k in per_kernel), None)
+        if layers and rh_key:
             nb = int(PAPER_HPARAMS.get("num_radial_basis", 8))
-            hid_flops = 2.0 * (nb * 32 + 32 * 32) * n_edges
-            hid_ms = per_kernel["radial_hidden"]
+            # radial_hidden_multi evaluates the two hidden layers of ALL conv layers' MLPs in one launch
+            n_mlps = n_layers if rh_key == "radial_hidden_multi" else 1
+            hid_flops = 2.0 * (nb * 32 + 32 * 32) * n_edges * n_mlps
+            hid_ms = per_kernel[rh_key]
             last_flops = [2.0 * 32 * r["weight_numel"] * n_edges for r in layers]
             tp_ms = sum(r["ms"] for r in layers) / len(layers)
             result["mfma"] = {
                 "radial_hidden_kernel": {
+                    "kernel": rh_key + ("_kernel (hidden layers of all %d conv layers' radial MLPs per launch)" % n_mlps
+                                        if n_mlps > 1 else "_kernel"),
                     "flops_per_launch": hid_flops, "avg_launch_ms": hid_ms,
                     "achieved_TFLOPs": hid_flops / (hid_ms * 1e-3) / 1e12, "peak_TFLOPs": MFMA_F32_PEAK / 1e12,
                     "frac": hid_flops / (hid_ms * 1e-3) / MFMA_F32_PEAK, "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
@@ -273,38 +544,12 @@ def main():
 
         # ---- CPU baseline: the oracle on a bounded sample of the same workload ----
         if world == 1 and not args.no_cpu_baseline:
-            from oracle.matten_ref.model import ScalarTensorOracle
-
-            # The oracle's per-path einsums are small: beyond ~16 threads it gets slower, not faster
-            # (256 host threads on the MI355X box: >100x slower), so the baseline uses at most 16.
-            nthreads = min(os.cpu_count() or 1, 16)
-            torch.set_num_threads(nthreads)
-            ref = ScalarTensorOracle(dict(PAPER_HPARAMS), ds).eval()
-            ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=False)
-            sample = collate(graphs[: args.cpu_sample])
-            e_sample = int(sample["edge_index"].shape[1])
-            with torch.no_grad():
-                ref.decode(dict(sample))  # warm-up
-                times = []
-                t_budget = time.perf_counter()
-                while len(times) < 5 and (time.perf_counter() - t_budget) < 20.0:
-                    t1 = time.perf_counter()
-                    want = ref.decode(dict(sample))
-                    times.append(time.perf_counter() - t1)
-            times.sort()
-            med = times[len(times) // 2]
-            got = out[: args.cpu_sample].cpu()
-            err = (got - want).abs().max().item()
-            result["cpu_baseline"] = {
-                "value": e_sample * n_layers / med,
-                "unit": "edge-TP/s",
-                "cores": nthreads,
-                "kind": "port",
-                "sample": f"{args.cpu_sample} fcc-64 crystals ({e_sample} edges) per forward, median of {len(times)} "
-                          f"forwards after 1 warm-up; pure-PyTorch fp32 restatement of the e3nn path (not e3nn)",
-                "crystals_per_sec": args.cpu_sample / med,
-                "max_abs_diff_vs_gpu": err,
-            }
+            result["cpu_baseline"] = cpu_baseline(args, model, graphs, ds, out, n_layers)
+        # ---- the other single-GPU configurations, timed by this same driver-run command ----
+        if world == 1 and not distributed and not args.no_extras:
+            del batch, out
+            torch.cuda.empty_cache()
+            result["extras"] = extras(dev)
         print(json.dumps(result), flush=True)
 
     if distributed:

@@ -49,8 +49,8 @@ int matten_abi_version(void);
  * Out-of-range node ids set err_flag bit 0.
  * Sparse graphs (E <= 64 N) are built by counting (in-degree atomics, scan, rank of the edge ids inside every
  * segment: no device-wide sort), dense ones by a stable radix sort; the result is the same.  The ranking step costs
- * degree^2 / 16 comparisons per node: negligible for cutoff-radius graphs (degree ~ 10-200), slow (not wrong) for a
- * sparse graph with a hub node of degree >> 10^4.
+ * degree^2 / 16 comparisons per node (cutoff-radius graphs: degree ~ 10-200); a hub segment of more than 2048 edges in
+ * an otherwise sparse graph is sorted by a whole workgroup instead (O(d log^2 d), same order).
  * ------------------------------------------------------------------------------------------ */
 size_t matten_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
 int matten_csr_counting_max_avg_degree(void);   /* E <= this * N: counting build (no device-wide sort) */

@@ -11,8 +11,8 @@ What such a file holds (reference predict.py:36-46 -> ``load_from_checkpoint``; 
   ``metrics.``.  ``filter_state_dict`` drops exactly those and nothing else.
 * ``hyper_parameters``: plain dicts and, under ``tasks``, a pickled ``matten.model_factory.task.TensorRegressionTask``
   whose ``normalizer`` (if the model was trained on standardised targets) is a ``matten.data.transform`` module that
-  holds e3nn ``Irreps`` objects.  ``load_checkpoint`` unpickles the file with a RESTRICTED unpickler: torch / numpy /
-  container globals resolve normally, every other global (matten.*, e3nn.*, torchmetrics.*, pytorch_lightning.*, ...)
+  holds e3nn ``Irreps`` objects.  ``load_checkpoint`` unpickles the file with a RESTRICTED unpickler: an explicit
+  allow-list of torch / numpy / container globals resolves normally, every other global (matten.*, e3nn.*, torchmetrics.*, pytorch_lightning.*, ...)
   becomes an inert placeholder that records its constructor arguments and state and executes nothing.
   ``rebuild_tasks`` then reads name, loss weight and normaliser statistics off the placeholders and builds this
   package's own Task objects (model_factory/task.py).
@@ -43,8 +43,29 @@ _SAFE_GLOBALS = {
     ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "_reconstruct"),
     ("numpy._core.multiarray", "scalar"),
 }
-_SAFE_TORCH_PREFIXES = ("torch._utils", "torch._tensor", "torch.storage", "torch.nn.parameter", "torch.serialization")
+# torch globals a state_dict / hyper-parameter pickle legitimately references: an explicit (module, name) list, the same
+# set torch's own weights_only unpickler trusts.  Nothing is matched by prefix or by "is a class": e.g.
+# torch.serialization._open_file is a class whose constructor truncates a file.
+_SAFE_TORCH_GLOBALS = {
+    ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor_v3"),
+    ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch._utils", "_rebuild_device_tensor_from_numpy"), ("torch._utils", "_rebuild_device_tensor_from_cpu_tensor"),
+    ("torch._utils", "_rebuild_meta_tensor_no_storage"),
+    ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.nn.parameter", "Parameter"), ("torch.nn.parameter", "Buffer"),
+    ("torch.serialization", "_get_layout"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+}
 _SAFE_TORCH_CONTAINERS = {"ModuleDict", "ModuleList", "Sequential", "Module", "Identity"}
+# classes of this package a checkpoint written by it may carry (hyper_parameters['tasks'] and their normalisers)
+_SAFE_OWN_GLOBALS = {
+    ("matten_amd.model_factory.task", "Task"), ("matten_amd.model_factory.task", "TensorRegressionTask"),
+    ("matten_amd.model_factory.task", "ScalarRegressionTask"),
+    ("matten_amd.data.transform", "MeanNormNormalize"), ("matten_amd.data.transform", "ScalarNormalize"),
+    ("matten_amd.data.transform", "TensorTargetTransform"), ("matten_amd.data.transform", "ScalarTargetTransform"),
+    ("matten_amd.o3", "Irrep"), ("matten_amd.o3", "MulIr"), ("matten_amd.o3", "Irreps"),
+}
 
 
 class Opaque:
@@ -115,18 +136,18 @@ def _resolve(module: str, name: str):
         return getattr(mod, name)
     if module == "torch":
         obj = getattr(torch, name, None)
-        # dtypes, Size, device, tensor / storage classes -- never functions
-        if isinstance(obj, (torch.dtype, type)) and (isinstance(obj, torch.dtype) or obj in (torch.Size, torch.device)
-                                                      or name.endswith(("Storage", "Tensor"))):
+        # dtypes and the legacy typed tensor / storage classes (torch.FloatStorage, ...) -- never functions
+        if isinstance(obj, torch.dtype):
             return obj
-    if module.startswith(_SAFE_TORCH_PREFIXES):
-        mod = __import__(module, fromlist=["_"])
-        obj = getattr(mod, name, None)
-        if obj is not None and (name.startswith("_rebuild") or isinstance(obj, type) or name == "_get_layout"):
+        if isinstance(obj, type) and re.fullmatch(r"[A-Z][A-Za-z0-9]*(Storage|Tensor)", name):
             return obj
-    if module.startswith("torch.nn.modules") and name in _SAFE_TORCH_CONTAINERS:
+    if (module, name) in _SAFE_TORCH_GLOBALS:
+        obj = getattr(__import__(module, fromlist=["_"]), name, None)
+        if obj is not None:
+            return obj
+    if module.startswith("torch.nn.modules.") and name in _SAFE_TORCH_CONTAINERS:
         return getattr(torch.nn, name)
-    if module.startswith("matten_amd."):  # checkpoints written by this package: its own task / transform / irreps classes
+    if (module, name) in _SAFE_OWN_GLOBALS:  # checkpoints written by this package
         obj = getattr(__import__(module, fromlist=["_"]), name, None)
         if isinstance(obj, type):
             return obj

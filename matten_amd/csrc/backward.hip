@@ -360,6 +360,7 @@ extern "C" int matten_tp_backward(const float* x, int64_t d_in, const float* w_e
         MATTEN_LAUNCH_CHECK();
         return MATTEN_OK;
     }
+    if (matten_cdiv(n_edges * n_cols, T) >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
     tp_backward_kernel<<<(unsigned)matten_cdiv(n_edges * n_cols, T), T, 0, stream>>>(
         x, (int)d_in, w_edge, (int)w_ld, sh_sorted, (int)sh_stride, src_sorted, dst_sorted, (const int4*)col_meta,
         (int)n_cols, (const uchar4*)nnz_ijk, nnz_c, g_agg, (int)d_mid, avg_num_neighbors, num_neigh, n_edges, dx, dw,

@@ -80,13 +80,25 @@ __global__ void csr_place_kernel(const int64_t* __restrict__ edge_index, int64_t
     ids[rowptr[d] + slot[e]] = (int32_t)e;
 }
 
+// Segments longer than this are not ranked quadratically by 16 lanes (one hub node with 10^5-10^6 in-edges would be
+// 10^10-10^12 serial comparisons in a half-wave): csr_rank_kernel queues them and csr_hub_kernel sorts each with a
+// whole workgroup, O(d log^2 d / 1024) per thread.
+constexpr int CSR_HUB_DEGREE = 2048;
+constexpr int CSR_HUB_THREADS = 1024;
+constexpr int CSR_HUB_BLOCKS = 64;
+
+// hubs[0..N): queue of hub nodes, hubs[N]: its length (the in-degree counters, dead after the scan; counter N is zero)
 __global__ void csr_rank_kernel(const int64_t* __restrict__ edge_index, const int32_t* __restrict__ rowptr,
                                 const int32_t* __restrict__ ids, int64_t E, int64_t N, int32_t* __restrict__ perm,
-                                int32_t* __restrict__ src_sorted) {
+                                int32_t* __restrict__ src_sorted, int32_t* __restrict__ hubs) {
     const int64_t node = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (node >= N) return;
     const int sub = threadIdx.x & 15;
     const int beg = rowptr[node], d = rowptr[node + 1] - beg;
+    if (d > CSR_HUB_DEGREE) {
+        if (sub == 0) hubs[atomicAdd(&hubs[N], 1)] = (int32_t)node;
+        return;
+    }
     for (int i = sub; i < d; i += 16) {
         const int id = ids[beg + i];
         int rank = 0;
@@ -95,6 +107,43 @@ __global__ void csr_rank_kernel(const int64_t* __restrict__ edge_index, const in
         int64_t s = edge_index[id];
         s = s < 0 ? 0 : (s >= N ? N - 1 : s);
         src_sorted[beg + rank] = (int32_t)s;
+    }
+}
+
+// In-place bitonic sort of a hub segment's edge ids by one workgroup (the all-ascending network: first step of a merge
+// pairs i with its mirror i ^ (k - 1), the rest with i ^ j; partners past the end count as +inf and never move, so any
+// length works), then the same perm / src_sorted outputs as the ranking above.
+__global__ __launch_bounds__(CSR_HUB_THREADS) void csr_hub_kernel(const int64_t* __restrict__ edge_index,
+                                                                  const int32_t* __restrict__ rowptr, int32_t* ids,
+                                                                  int64_t N, int32_t* __restrict__ perm,
+                                                                  int32_t* __restrict__ src_sorted,
+                                                                  const int32_t* __restrict__ hubs) {
+    const int n_hubs = hubs[N];
+    for (int h = blockIdx.x; h < n_hubs; h += gridDim.x) {
+        const int node = hubs[h];
+        const int beg = rowptr[node], d = rowptr[node + 1] - beg;
+        int32_t* a = ids + beg;
+        for (int64_t k = 2; (k >> 1) < d; k <<= 1) {
+            for (int64_t j = k >> 1; j > 0; j >>= 1) {
+                const int64_t m = (j == (k >> 1)) ? k - 1 : j;   // mirror step, then butterfly steps
+                for (int64_t i = threadIdx.x; i < d; i += CSR_HUB_THREADS) {
+                    const int64_t l = i ^ m;
+                    if (l > i && l < d) {
+                        const int32_t x = a[i], y = a[l];
+                        if (y < x) a[i] = y, a[l] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int64_t i = threadIdx.x; i < d; i += CSR_HUB_THREADS) {
+            const int32_t id = a[i];
+            perm[beg + i] = id;
+            int64_t s = edge_index[id];
+            s = s < 0 ? 0 : (s >= N ? N - 1 : s);
+            src_sorted[beg + i] = (int32_t)s;
+        }
+        __syncthreads();
     }
 }
 
@@ -251,8 +300,14 @@ extern "C" int matten_csr_build(const int64_t* edge_index, int64_t E, int64_t N,
         csr_place_kernel<<<(unsigned)matten_cdiv(E, T), T, 0, stream>>>(edge_index, E, N, rowptr, slot, ids);
         MATTEN_LAUNCH_CHECK();
         csr_rank_kernel<<<(unsigned)matten_cdiv(N * 16, T), T, 0, stream>>>(edge_index, rowptr, ids, E, N, perm,
-                                                                           src_sorted);
+                                                                           src_sorted, deg);
         MATTEN_LAUNCH_CHECK();
+        if (E > CSR_HUB_DEGREE) {  // a segment can only be that long if the graph has that many edges
+            const int64_t max_hubs = E / CSR_HUB_DEGREE;
+            csr_hub_kernel<<<(unsigned)(max_hubs < CSR_HUB_BLOCKS ? max_hubs : CSR_HUB_BLOCKS), CSR_HUB_THREADS, 0,
+                             stream>>>(edge_index, rowptr, ids, N, perm, src_sorted, deg);
+            MATTEN_LAUNCH_CHECK();
+        }
         return MATTEN_OK;
     }
     csr_keys_kernel<<<(unsigned)matten_cdiv(E, T), T, 0, stream>>>(edge_index, E, N, keys_in, vals_in, err_flag);

@@ -9,7 +9,14 @@ a step is ~350 kernel launches for under 3 ms of kernel time: the host cannot is
 Constraints (checked): every tensor of the batch keeps its shape and dtype between steps (pad or bucket batches
 upstream), the optimiser is capturable (``torch.optim.Adam(..., capturable=True)``), and the one host synchronisation
 of the forward -- the species / edge_index range check of ``SpeciesEmbedding`` -- is done once, eagerly, before the
-capture and switched off inside it.
+capture and switched off inside it.  Replayed batches are therefore trusted by default (the kernels clamp bad ids:
+memory-safe, but the result of a malformed batch is meaningless); pass ``validate=True`` to ``step`` / ``__call__`` to
+read the flag word the captured forward rewrites on every replay (one host sync after the replay) and get the same
+exception the eager path raises.
+
+Construction runs `warmup` real optimisation steps on the construction batch (allocator pools, lazily built tables,
+optimiser state).  Model parameters, buffers (BatchNorm running statistics) and the optimiser state are snapshotted
+before and restored IN PLACE afterwards, so the first ``step()`` starts from exactly the state the caller handed over.
 """
 from typing import Callable, Dict
 
@@ -35,6 +42,13 @@ def _check_capturable(batch) -> None:
                          f"cannot be captured above {MAX_CAPTURED_SORT_KEYS} edges on this ROCm; run it eagerly")
 
 
+def _raise_for_flags(embeds, batch) -> None:
+    n_nodes = int(batch["pos"].shape[0]) if "pos" in batch else None
+    for m in embeds:
+        if hasattr(m, "raise_for_last_flags"):
+            m.raise_for_last_flags(n_nodes)
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, loss_fn: Callable, batch: Dict[str, torch.Tensor], target: torch.Tensor,
                  warmup: int = 3, task_name: str = "elastic_tensor_full"):
@@ -44,12 +58,32 @@ class GraphedTrainStep:
         self._static = {k: v.clone() if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
         self._target = target.clone()
         embeds = [m for m in model.modules() if hasattr(m, "check_species")]
+        self._embeds = embeds
+        # the warm-up steps below are real optimiser steps: snapshot what they mutate
+        with torch.no_grad():
+            snap_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            snap_opt = {p: {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                        for p, st in optimizer.state.items()}
         # warm-up on a side stream (allocator pools, lazily built tables), with the range checks on
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
                 self._eager_step()
+            # restore in place: the capture below must see the tensors the warm-up allocated (optimiser moments, step)
+            with torch.no_grad():
+                for k, v in model.state_dict().items():
+                    v.copy_(snap_model[k])
+                for p, st in optimizer.state.items():
+                    old = snap_opt.get(p)
+                    for k, v in st.items():
+                        if isinstance(v, torch.Tensor):
+                            if old is not None and isinstance(old.get(k), torch.Tensor):
+                                v.copy_(old[k])
+                            else:
+                                v.zero_()   # a freshly initialised Adam state: step 0, zero moments
+                        elif old is not None and k in old:
+                            st[k] = old[k]
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self._flags = [(m, m.check_species) for m in embeds]
@@ -72,8 +106,10 @@ class GraphedTrainStep:
         self.optimizer.step()
         return loss
 
-    def step(self, batch: Dict[str, torch.Tensor], target: torch.Tensor) -> torch.Tensor:
-        """copy the batch into the captured buffers (shapes must match) and replay; returns the captured loss tensor"""
+    def step(self, batch: Dict[str, torch.Tensor], target: torch.Tensor, validate: bool = False) -> torch.Tensor:
+        """copy the batch into the captured buffers (shapes must match) and replay; returns the captured loss tensor.
+        validate=True: afterwards read the replayed forward's species / edge_index flags (a host sync) and raise like
+        the eager path -- the parameters have already been updated with the malformed batch by then."""
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
                 s = self._static[k]
@@ -85,6 +121,8 @@ class GraphedTrainStep:
         if target.data_ptr() != self._target.data_ptr():
             self._target.copy_(target, non_blocking=True)
         self.graph.replay()
+        if validate:
+            _raise_for_flags(self._embeds, self._static)
         return self._loss
 
 
@@ -99,6 +137,7 @@ class GraphedForward:
         dev = next(model.parameters()).device
         self._static = {k: v.clone() if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
         embeds = [m for m in model.modules() if hasattr(m, "check_species")]
+        self._embeds = embeds
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
@@ -117,9 +156,9 @@ class GraphedForward:
             for m, f in flags:
                 m.check_species = f
 
-    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def __call__(self, batch: Dict[str, torch.Tensor], validate: bool = False) -> torch.Tensor:
         """NOTE: the species / edge_index range checks ran on the batch given at construction only; a replayed batch is
-        trusted (same shapes enforced)."""
+        trusted (same shapes enforced) unless validate=True (one host sync after the replay, same exceptions as eager)."""
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
                 s = self._static[k]
@@ -129,4 +168,6 @@ class GraphedForward:
                 if s.data_ptr() != v.data_ptr():
                     s.copy_(v, non_blocking=True)
         self.graph.replay()
+        if validate:
+            _raise_for_flags(self._embeds, self._static)
         return self._out

@@ -97,6 +97,19 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
         )
         self.linear = torch.nn.Linear(self.num_species, embedding_dim)
 
+    def raise_for_last_flags(self, n_nodes=None) -> None:
+        """host sync: read the validation flags of the most recent forward and raise what the reference would have
+        (unknown species: RuntimeError / ValueError of _AtomicNumberToIndex; edge_index out of range: IndexError)"""
+        flags_dev = getattr(self, "_last_flags", None)
+        if flags_dev is None:
+            return
+        flags = flags_dev.tolist()
+        if flags[0]:
+            self.atomic_number_to_index.raise_for_flags(flags[0], self._last_Z)
+        if flags[1] & 1:
+            rng = f"[0, {n_nodes})" if n_nodes is not None else "the batch's node range"
+            raise IndexError(f"edge_index holds node ids outside {rng} (a malformed batch)")
+
     def forward(self, data: DataKey.Type) -> DataKey.Type:
         a2i = self.atomic_number_to_index
         lo, hi, S = a2i._host
@@ -129,13 +142,11 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
         # waits for the flags below, so that its launches are not paced by the host afterwards (an unknown species
         # is grouped with species 0 by the kernel and never used: the check raises)
         order, seg, _ = ops.group_by_key(sidx, S, err=flags_dev[2:3])
+        # kept for a deferred check (matten_amd.graphs: inside a captured graph this is a static tensor every replay
+        # rewrites, read on request after the replay)
+        self._last_flags, self._last_Z = flags_dev, Z
         if self.check_species:
-            flags = flags_dev.tolist()
-            if flags[0]:
-                a2i.raise_for_flags(flags[0], Z)
-            if flags[1] & 1:
-                n_nodes = data[DataKey.POSITIONS].shape[0]
-                raise IndexError(f"edge_index holds node ids outside [0, {n_nodes}) (a malformed batch)")
+            self.raise_for_last_flags(data[DataKey.POSITIONS].shape[0] if DataKey.POSITIONS in data else None)
         if not provided:
             data[DataKey.SPECIES_INDEX] = sidx
         data[DataKey.AMD_SPECIES] = (order, seg)

@@ -504,15 +504,14 @@ def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk,
     dw = torch.empty(E, W, dtype=torch.float32, device=x.device)
     if num_neigh is not None:
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
-    _lib.check(
-        lib.matten_tp_backward(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
-                               _ptr(src_sorted), _ptr(dst_sorted), _ptr(col_meta), W, _ptr(nnz_ijk), _ptr(nnz_c),
-                               _ptr(g_agg), g_agg.shape[1], float(avg_num_neighbors or 0.0), _ptr(num_neigh), E,
-                               _ptr(dx), _ptr(dw), W, _ptr(in_groups[0]) if in_groups else None,
-                               _ptr(in_groups[1]) if in_groups else None,
-                               in_groups[0].shape[0] - 1 if in_groups else 0, _stream()),
-        "matten_tp_backward",
-    )
+    with _timed(f"tp_backward/d_mid={g_agg.shape[1]}/d_in={d_in}"):
+        rc = lib.matten_tp_backward(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
+                                    _ptr(src_sorted), _ptr(dst_sorted), _ptr(col_meta), W, _ptr(nnz_ijk), _ptr(nnz_c),
+                                    _ptr(g_agg), g_agg.shape[1], float(avg_num_neighbors or 0.0), _ptr(num_neigh), E,
+                                    _ptr(dx), _ptr(dw), W, _ptr(in_groups[0]) if in_groups else None,
+                                    _ptr(in_groups[1]) if in_groups else None,
+                                    in_groups[0].shape[0] - 1 if in_groups else 0, _stream())
+    _lib.check(rc, "matten_tp_backward")
     return dx, dw
 
 

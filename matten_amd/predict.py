@@ -246,6 +246,11 @@ def evaluate(model, graphs: List, batch_size: int = 200,
     converter = CartesianTensorWrapper(tensor_target_formula)
     device = model.device
     rank_dims = (3,) * len(tensor_target_formula.split("=")[0].replace("-", ""))
+    # what the model emits per crystal: the irreps row ([21] for the elasticity tensor) or, for
+    # output_format == "cartesian", the tensor itself.  The rows are what crosses xGMI (north star: ONE gather of
+    # [B, 21]); the change of basis to [3,3,3,3] (81 floats) runs after the gather, on every rank's full set.
+    cartesian_out = getattr(model, "to_cartesian", None) is not None
+    row_dims = rank_dims if cartesian_out else (converter._Q.shape[0],)
 
     def run(shard):
         outs = []
@@ -261,21 +266,23 @@ def evaluate(model, graphs: List, batch_size: int = 200,
                     except EdgelessStructures as e:
                         keep = [i for i in keep if i not in set(e.indices)]
                         batch = batch_graphs_gpu([items[i] for i in keep], r_cut, device) if keep else None
-                full = torch.full((len(items),) + rank_dims, float("nan"), device=device)
+                full = torch.full((len(items),) + row_dims, float("nan"), device=device)
                 if batch is not None:
                     preds, _ = model(batch, task_name=tensor_target_name)
                     p = preds[tensor_target_name]
-                    if p.dim() == 2:  # irreps -> Cartesian on the GPU
-                        p = converter.to_cartesian(p)
-                    full[torch.as_tensor(keep, device=device)] = p
+                    if len(keep) == len(items):
+                        full = p.reshape((len(items),) + row_dims)
+                    else:
+                        full[torch.as_tensor(keep, device=device)] = p.reshape((len(keep),) + row_dims)
                 outs.append(full)
         return torch.cat(outs, dim=0)
 
     model.eval()
     if distributed:
-        preds = sharded_apply(run, graphs, rank_dims, device)
+        rows = sharded_apply(run, graphs, row_dims, device)
     else:
-        preds = run(graphs)
+        rows = run(graphs)
+    preds = rows if cartesian_out else converter.to_cartesian(rows)   # NaN rows stay NaN tensors
     return list(preds.cpu())
 
 

@@ -159,6 +159,31 @@ def test_unpickling_executes_nothing_foreign(tmp_path):
     assert not (tmp_path / "pwned").exists()
 
 
+def test_torch_classes_outside_the_allow_list_are_inert(tmp_path):
+    """torch.serialization._open_file is a CLASS whose constructor opens (and with 'w' truncates) a file: a prefix or
+    isinstance(type) rule would resolve it.  The allow-list is by (module, name): it must come back as a placeholder."""
+    from matten_amd.checkpoint import RestrictedUnpickler, _resolve
+    import io
+
+    victim = tmp_path / "victim.txt"
+    victim.write_text("keep me")
+    payload = ("ctorch.serialization\n_open_file\n(V%s\nVw\ntR." % victim).encode()
+    obj = RestrictedUnpickler(io.BytesIO(payload)).load()
+    assert isinstance(obj, Opaque)
+    assert victim.read_text() == "keep me"
+    for module, name in [("torch.serialization", "_open_zipfile_writer_file"), ("torch._utils_internal", "justknobs_check"),
+                         ("torch.storage", "_load_from_bytes"), ("torch.serialization", "load"),
+                         ("matten_amd.predict", "predict"), ("matten_amd._lib", "MattenHipError"),
+                         ("torch.nn.modules.linear", "Linear"), ("torch", "load"), ("torch", "hub")]:
+        got = _resolve(module, name)
+        assert isinstance(got, type) and issubclass(got, Opaque), (module, name, got)
+    # what a state_dict needs still resolves to the real thing
+    assert _resolve("torch._utils", "_rebuild_tensor_v2") is torch._utils._rebuild_tensor_v2
+    assert _resolve("torch", "FloatStorage") is torch.FloatStorage
+    assert _resolve("torch.nn.parameter", "Parameter") is torch.nn.Parameter
+    assert _resolve("collections", "OrderedDict").__name__ == "OrderedDict"
+
+
 def test_unknown_state_dict_entries_are_still_an_error(tmp_path):
     sd = _write_reference_style_checkpoint(tmp_path, False)
     ckpt = load_checkpoint(tmp_path / "model_final.ckpt")

@@ -71,6 +71,26 @@ def test_csr_counting_and_radix_builds_agree_with_a_stable_sort(n_nodes, n_edges
     assert int(err.item()) == 0
 
 
+def test_csr_hub_segments_in_a_sparse_graph():
+    """a sparse graph (counting build) with hub nodes far above the 16-lane ranking's threshold: the hub segments are
+    sorted by a workgroup (csr.hip csr_hub_kernel) into the same stable order; lengths that are no power of two"""
+    from matten_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    n_nodes, n_edges = 4000, 60000
+    ei = torch.randint(0, n_nodes, (2, n_edges), generator=g)
+    hub = torch.randperm(n_edges, generator=g)
+    ei[1, hub[:20011]] = 17          # 20 011 + a few edges end in node 17
+    ei[1, hub[20011:20011 + 2049]] = 3999
+    ei[1, hub[23000:23000 + 4096]] = 0
+    assert n_edges <= 64 * n_nodes
+    perm, rowptr, src, err = ops.csr_build(ei.to(DEV), n_nodes)
+    want_perm = torch.sort(ei[1], stable=True).indices
+    assert torch.equal(perm.cpu().long(), want_perm)
+    assert torch.equal(src.cpu().long(), ei[0][want_perm])
+    assert int(err.item()) == 0
+
+
 def test_csr_properties_at_full_size():
     """BASELINE configs[2] size (1000 fcc-64 crystals, 1.15 M edges): the CSR is a permutation, sorted by destination,
     stable inside a destination, and rowptr / src_sorted agree with it (size-independent properties, checked on device)"""

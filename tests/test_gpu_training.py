@@ -126,11 +126,12 @@ def test_hipgraph_training_step_follows_the_eager_trajectory(golden_dir):
     warm = 2
     eager, opt_e = make()
     graphed, opt_g = make()
+    before = {k: v.detach().clone() for k, v in graphed.state_dict().items()}
     step = GraphedTrainStep(graphed, opt_g, loss_fn, batches[0], targets[0], warmup=warm)
-    n_pre = warm   # steps the constructor took on (batches[0], targets[0]): the warm-up ones (a capture records, it does not run)
-    for _ in range(n_pre):
-        loss = loss_fn(eager(dict(batches[0]))[0], targets[0])
-        opt_e.zero_grad(); loss.backward(); opt_e.step()
+    # the constructor's warm-up steps are undone (parameters, BatchNorm running statistics, Adam state restored in place)
+    for k, v in graphed.state_dict().items():
+        assert torch.equal(v, before[k]), f"{k} changed by the warm-up"
+    assert all(float(st["step"]) == 0.0 for st in opt_g.state.values())
     for i in range(6):
         b, t = batches[i % 2], targets[i % 2]
         le = loss_fn(eager(dict(b))[0], t)
@@ -142,6 +143,14 @@ def test_hipgraph_training_step_follows_the_eager_trajectory(golden_dir):
     small = collate(graphs[:3], device=DEV)
     with pytest.raises(ValueError, match="captured step takes"):
         step.step(small, targets[0][:3])
+    # a replayed batch is trusted unless validate=True: then a malformed one raises like the eager path
+    bad = dict(batches[0])
+    bad["edge_index"] = bad["edge_index"].clone()
+    bad["edge_index"][0, 0] = bad["pos"].shape[0] + 5
+    step.step(bad, targets[0])
+    with pytest.raises(IndexError, match="edge_index holds node ids outside"):
+        step.step(bad, targets[0], validate=True)
+    step.step(batches[0], targets[0], validate=True)
 
 
 def test_hipgraph_forward_is_bit_identical_to_eager():

@@ -561,3 +561,47 @@ def test_debug_log_level_inserts_anomaly_detectors():
         det(dict(ok, node_features=torch.tensor([1.0, float("nan")])))
     with pytest.raises(ValueError, match="inf"):
         detect_nan_and_inf(torch.tensor([float("inf")]), file="f", name="x")
+
+
+def test_bench_launches_its_ranks_as_a_child_process(monkeypatch):
+    """`python bench.py --gpus N` (no RANK in the environment) must start torch.distributed.run itself, as a CHILD
+    process, before anything imports torch.cuda; under torch.distributed.run it must run as a rank instead."""
+    import importlib
+    import subprocess
+    import sys
+
+    import bench
+
+    importlib.reload(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MATTEN_FORCE_DIST"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(bench, "run_rank", lambda args: (_ for _ in ()).throw(AssertionError("parent must not run a rank")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "127.0.0.1" in cmd and cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # one rank + --force-dist: still a launch (RCCL path with world size 1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--force-dist"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert "--nproc-per-node=1" in seen["cmd"] and seen["env"]["MATTEN_FORCE_DIST"] == "1"
+    # as a rank of torch.distributed.run: no second launch
+    ran = {}
+    monkeypatch.setattr(bench, "run_rank", lambda args: ran.setdefault("args", args))
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    seen.clear()
+    bench.main()
+    assert ran["args"].gpus == 8 and not seen
