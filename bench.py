@@ -462,7 +462,8 @@ def run_rank(args):
                        "heavy_bytes": contract_bytes(p, cols(fp.heavy_ids), blocks(fp.heavy_ids), fp.d_rest)
                        if fp.rest is not None else 0.0}
             else:
-                k = f"tp_scatter/d_mid={p.d_mid}/d_in={p.d_in}"
+                # the row stride of the neighbour sums names the launch: component-major rows are padded (plan_agg_linear)
+                k = f"tp_scatter/d_mid={m.agg_plan.ld if getattr(m, 'agg_plan', None) is not None else p.d_mid}/d_in={p.d_in}"
                 rec = {"d_mid": p.d_mid, "weight_numel": p.weight_numel, "light_ms": None, "heavy_ms": per_kernel.get(k),
                        "light_bytes": 0.0, "heavy_bytes": contract_bytes(p, p.weight_numel, p.d_in, p.d_mid)}
             rec["ms"] = (rec["light_ms"] or 0.0) + (rec["heavy_ms"] or 0.0)

@@ -160,6 +160,29 @@ int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t 
                      float* agg /*[N,d_mid]*/, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * lin2 of a conv layer as a row stream over COMPONENT-MAJOR neighbour sums (reference nn/conv.py:84-86,123:
+ * out = FullyConnectedTensorProduct(agg, one_hot(species)) + self-connection).
+ *   agg[N, ld]: per output irrep io of lin2 a region [component k][channel slot 0..16 T_io): the channels of every
+ *               path with that irrep side by side (written by matten_tp_fused when group_entries word 8+c (t_off[c])
+ *               holds the component stride 16 T_io and word 20+c (out_off[c]) the first float of the entry's channel 0);
+ *               regions back to back, so chunk f (16 floats) of a row belongs to exactly one (io, k)
+ *   io_table[n_io, 8] int32: {first chunk, T, K (channel slots used; the rest are never read as data),
+ *               d3 | n_mt << 8 | cw << 16, a_off, out_off, mul_out, 0}
+ *   blocks[n_blocks, 4] int32: the row cut into runs of <= 8 chunks of one (io, k), front to back:
+ *               {first chunk, n | first-of-unit << 8 | last-of-unit << 9 | last unit of the table row << 10 | k << 12 |
+ *               io << 20, chunk index inside the unit, 0}; a table row has mul_out * d3 <= 32 (wider irreps: several rows)
+ *   wtab[n_species, w_stride]: per species and irrep the weights as MFMA A fragments at a_off,
+ *               [t < T][mt < n_mt][g < 4][c < cw][s < 4] = fan^-1/2 W_s[slot 16 t + 4 g + s][v = 16 mt + c] (cw = 16 or mul_out)
+ *   order / seg: rows sorted by species + per-species offsets (matten_group_by_key), or NULL/NULL with n_species == 1
+ *   out[N, d_out] in the reference's mul_ir layout: out[n, out_off + v d3 + k] = add[...] + sum
+ * ------------------------------------------------------------------------------------------ */
+int matten_agg_linear_max_mt(void);        /* column tiles per io_table row (mul_out of a row <= 16 * this) */
+int matten_agg_linear_block_chunks(void);  /* chunks per block (the n of a blocks[] row is <= this) */
+int matten_agg_linear(const float* agg, int64_t ld, const int32_t* order, const int32_t* seg, int64_t n_species,
+                      const float* wtab, int64_t w_stride, const int32_t* io_table, int64_t n_io,
+                      const int32_t* blocks, int64_t n_blocks, const float* add, int64_t add_ld, int64_t d_out,
+                      int64_t n_rows, float* out, matten_stream_t stream);
+/* ------------------------------------------------------------------------------------------
  * Fused production path of one conv layer's edge work (reference nn/utils.py:246-251,260,263 +
  * nn/conv.py:113-120): the per-edge radial weights are never written to memory.
  *   matten_radial_hidden: rbf(|v|) -> 32 -> 32 (silu), fp32 MFMA; writes h2s[E,2,32] fp16 (128 B per edge): every
@@ -183,18 +206,23 @@ int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t 
  *                   w2p as ready-made MFMA A fragments.  Entry e owns tiles [a_tile, a_tile + n_mt) (group_entries
  *                   words 6, 7); tile t, lane (g = lane >> 4, c = lane & 15) holds 16 fp16: hi[kk], lo[kk], kk < 8, of
  *                   s_e * w2p[16 (kk >> 2) + 4 g + (kk & 3)][w_base + 16 (t - a_tile) + c] with s_e the power of two
- *                   that puts the entry's largest magnitude in [2^13, 2^14); a_scale_inv[e] = 1 / s_e
+ *                   that puts the entry's largest magnitude in [2^13, 2^14); a_scale_inv[e] = 1 / (s_e h_scale)
  *   lds_floats_per_wave: max over entries of 16*T*(16*ceil(mul*NC/16)+36), T = max(1, nodes_per_wave/16)
  *                   (sh_sorted rows must be 32 floats apart: sh_stride == 32)
- * ------------------------------------------------------------------------------------------ */
+ *   h_scale (device pointer to ONE float, or NULL = 1): power of two the hidden features are multiplied by before
+ *                   the fp16 split, chosen by the host so that |h_scale * h2| < 2^15 for ANY edge (from the weights'
+ *                   column sums: 1 for a normally scaled MLP); the caller multiplies a_scale_inv by 1 / h_scale
+ */
 int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                          const float* w0p, int nb_pad, const float* w1p, int hidden, uint16_t* h2s,
-                         matten_stream_t stream);
+                         const float* h_scale, matten_stream_t stream);
 /* the same for n_layers <= 8 radial MLPs over one edge list in ONE launch (every conv layer of a model reads the same
- * edge lengths; the Bessel basis is evaluated once): w0p / w1p / h2s are HOST arrays of n_layers device pointers */
+ * edge lengths; the Bessel basis is evaluated once): w0p / w1p / h2s / h_scale (or NULL) are HOST arrays of n_layers
+ * device pointers */
 int matten_radial_hidden_multi(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                                const float* const* w0p, int nb_pad, const float* const* w1p, int hidden,
-                               uint16_t* const* h2s, int n_layers, matten_stream_t stream);
+                               uint16_t* const* h2s, const float* const* h_scale, int n_layers,
+                               matten_stream_t stream);
 int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
                     const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
                     int64_t n_nodes, const int32_t* group_entries, const int32_t* unit_map, int64_t n_entries,

@@ -15,7 +15,9 @@
 // value to within 2^-24 relative.  Three products (hi hi, hi lo, lo hi; lo lo is below 2^-24) accumulate in fp32:
 // the result carries the rounding of an fp32 dot product, at 51 instead of 264 matrix cycles per 16x16 tile.
 // fp16 range: the A tile is scaled by a power of two per wave (folded into the output normalisation; the
-// contraction is linear in w); h2 are silu outputs of a normalised MLP, |h2| < 65504 is assumed (inf otherwise).
+// contraction is linear in w).  h2 (silu outputs) are kept inside the fp16 range the same way: the hidden-layer kernels
+// multiply them by a per-MLP power of two h_scale <= 1 that the host derives from a bound on |h2| (the weights' column
+// sums; 1 for any normally scaled MLP) and folds back into a_scale_inv -- a checkpoint with huge radial weights stays exact.
 //
 // A wave owns one (input block, l2 group, node group) unit exactly like tp_block_kernel (a lane = one
 // channel u of one destination node, walking the node's CSR segment).  It proceeds in chunks of
@@ -90,7 +92,8 @@ struct GroupEntry {  // 32 x int32, built by matten_amd/plan.py (same record as 
     int w_base;      // first weight column of this entry ([u][c] order)
     int a_tile;      // first 16-column tile of this entry in the pre-split A operand (Args::a_split)
     int n_mt;        // its tile count, ceil(mul * couplings / 16)
-    int t_off[MAXC];  // conv-fused kernel only: accumulator offset of coupling c in the wave's LDS region (else 0)
+    int t_off[MAXC];  // conv-fused kernel (StoreLds): accumulator offset of coupling c in the wave's LDS region;
+                      // StoreAgg: 0 = mul_ir output row, else floats between two components (component-major row)
     int out_off[MAXC];
 };
 static_assert(sizeof(GroupEntry) == 32 * 4, "GroupEntry layout");
@@ -474,10 +477,14 @@ struct StoreAgg {
             for (int cc = 0; cc < G::NC; ++cc) {
                 if ((ge.mask >> cc) & 1u) {
                     const int d3 = 2 * G::L3[cc] + 1;
-                    float* op = orow + ge.out_off[cc] + u * d3;
+                    // t_off[cc] == 0: the reference's "mul_ir" row, [channel][component].  Otherwise the component-major
+                    // row of plan.plan_agg_linear: t_off[cc] floats between components, the channel lanes side by side
+                    const int ks = ge.t_off[cc];
+                    float* op = orow + ge.out_off[cc] + (ks ? u : u * d3);
+                    const int kstep = ks ? ks : 1;
 #pragma unroll
                     for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
-                        if (k < d3) op[k] = acc[G::OFF[cc] + k] * norm;
+                        if (k < d3) op[k * kstep] = acc[G::OFF[cc] + k] * norm;
                 }
             }
         }
@@ -995,12 +1002,14 @@ template <int KS0>
 __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __restrict__ geom, int64_t E, int n_basis,
                                                             float r_start, float r_end,
                                                             const float* __restrict__ w0p,
-                                                            const float* __restrict__ w1p, _Float16* __restrict__ h2s) {
+                                                            const float* __restrict__ w1p, _Float16* __restrict__ h2s,
+                                                            const float* __restrict__ h_scale) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * (NT * 16);
     if (e0 >= E) return;
+    const float hs = h_scale ? *h_scale : 1.0f;
     const float inv_c = 1.0f / (r_end - r_start);
     const float bes_pref = sqrtf(2.0f * inv_c) * sqrtf((float)n_basis);  // soft_one_hot_linspace 'bessel' x sqrt(nb)
     float a1[2][8];
@@ -1066,9 +1075,9 @@ __global__ __launch_bounds__(256) void radial_hidden_kernel(const float4* __rest
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 _Float16 h, l;
-                split_f16(o0[r], h, l);
+                split_f16(o0[r] * hs, h, l);
                 hi[r] = h, lo[r] = l;
-                split_f16(o1[r], h, l);
+                split_f16(o1[r] * hs, h, l);
                 hi[4 + r] = h, lo[4 + r] = l;
             }
             f16x8* dst = reinterpret_cast<f16x8*>(h2s + e * (2 * HID) + g * 8);
@@ -1086,6 +1095,7 @@ struct RadialLayers {
     const float* w0p[RH_MAX_LAYERS];
     const float* w1p[RH_MAX_LAYERS];
     _Float16* h2s[RH_MAX_LAYERS];
+    const float* h_scale[RH_MAX_LAYERS];   // per MLP: device pointer to its power-of-two output scale, or NULL (1)
     int n_layers;
 };
 
@@ -1119,6 +1129,7 @@ __global__ __launch_bounds__(256) void radial_hidden_multi_kernel(const float4* 
         const float* __restrict__ w0p = L.w0p[l];
         const float* __restrict__ w1p = L.w1p[l];
         _Float16* __restrict__ h2s = L.h2s[l];
+        const float hs = L.h_scale[l] ? *L.h_scale[l] : 1.0f;
         float a0[2][KS0], a1[2][8];
 #pragma unroll
         for (int kk = 0; kk < KS0; ++kk) {
@@ -1162,9 +1173,9 @@ __global__ __launch_bounds__(256) void radial_hidden_multi_kernel(const float4* 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     _Float16 h, ll;
-                    split_f16(o0[r], h, ll);
+                    split_f16(o0[r] * hs, h, ll);
                     hi[r] = h, lo[r] = ll;
-                    split_f16(o1[r], h, ll);
+                    split_f16(o1[r] * hs, h, ll);
                     hi[4 + r] = h, lo[4 + r] = ll;
                 }
                 f16x8* dst = reinterpret_cast<f16x8*>(h2s + e * (2 * HID) + g * 8);
@@ -1179,7 +1190,8 @@ __global__ __launch_bounds__(256) void radial_hidden_multi_kernel(const float4* 
 
 extern "C" int matten_radial_hidden_multi(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start,
                                           float r_end, const float* const* w0p, int nb_pad, const float* const* w1p,
-                                          int hidden, uint16_t* const* h2s, int n_layers, matten_stream_t stream_) {
+                                          int hidden, uint16_t* const* h2s, const float* const* h_scale, int n_layers,
+                                          matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || hidden != HID || (nb_pad & 3) || nb_pad < n_basis || nb_pad > 16 || n_layers < 1 ||
         n_layers > RH_MAX_LAYERS)
@@ -1191,6 +1203,7 @@ extern "C" int matten_radial_hidden_multi(const float* geom_sorted, int64_t n_ed
     for (int l = 0; l < n_layers; ++l) {
         if (!w0p[l] || !w1p[l] || !h2s[l]) return MATTEN_EINVAL;
         L.w0p[l] = w0p[l], L.w1p[l] = w1p[l], L.h2s[l] = (_Float16*)h2s[l];
+        L.h_scale[l] = h_scale ? h_scale[l] : nullptr;
     }
     unsigned grid = (unsigned)matten_cdiv(n_edges, 4 * NT * 16);
 #define LAUNCH(K) \
@@ -1208,14 +1221,14 @@ extern "C" int matten_radial_hidden_multi(const float* geom_sorted, int64_t n_ed
 
 extern "C" int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                                     const float* w0p, int nb_pad, const float* w1p, int hidden, uint16_t* h2s,
-                                    matten_stream_t stream_) {
+                                    const float* h_scale, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || hidden != HID || (nb_pad & 3) || nb_pad < n_basis || nb_pad > 16) return MATTEN_EINVAL;
     if (n_edges == 0) return MATTEN_OK;
     if (!geom_sorted || !w0p || !w1p || !h2s) return MATTEN_EINVAL;
     unsigned grid = (unsigned)matten_cdiv(n_edges, 4 * NT * 16);
 #define LAUNCH(K) \
-    radial_hidden_kernel<K><<<grid, 256, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis, r_start, r_end, w0p, w1p, (_Float16*)h2s)
+    radial_hidden_kernel<K><<<grid, 256, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis, r_start, r_end, w0p, w1p, (_Float16*)h2s, h_scale)
     switch (nb_pad >> 2) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;

@@ -70,6 +70,17 @@ class PointConv(ModuleIrreps, torch.nn.Module):
             self._fused_atab = DerivedWeight(self._build_atab)
             self._fused_rest_w = DerivedWeight(self._pack_rest)
             self._fused_split = DerivedWeight(self._split_by_role)
+        # component-major neighbour sums + streaming lin2 (matten_agg_linear): the inference path of the two-kernel conv
+        import os
+        self.agg_plan = None
+        if self.tp.impl == "fused" and self.fused_plan is None and os.environ.get("MATTEN_AGG_LAYOUT", "km") == "km":
+            ap = _plan.plan_agg_linear(self.tp.plan, n_species, conv_layer_irreps)
+            if (ap is not None and ap.max_mt <= 5
+                    and 4 * ap.w_stride + 32 * len(ap.io_table) + 16 * len(ap.blocks) + 4 * 8 * (16 * 33 + 16) <= 64 * 1024):
+                self.agg_plan = ap
+                self._agg_tables = DeviceTables(entries=ap.entries, io=ap.io_table, blocks=ap.blocks, gather=ap.gather,
+                                                scale=ap.scale)
+                self._agg_wtab = DerivedWeight(self._pack_agg_weights)
 
     def _pack_lin1_sc(self, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
         return torch.cat([self.lin1._pack(w1), self.sc._pack(w2)], dim=1).contiguous()
@@ -109,6 +120,12 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         t, dev = self._fused_tables, frag.device
         return scale_inv[t.get("light_ids", dev)].contiguous(), scale_inv[t.get("heavy_ids", dev)].contiguous()
 
+    def _pack_agg_weights(self, w: torch.Tensor) -> torch.Tensor:
+        """lin2.weight (flat, reference layout) -> [S, w_stride] MFMA A fragments of matten_agg_linear"""
+        t, dev = self._agg_tables, w.device
+        gather, scale = t.get("gather", dev), t.get("scale", dev)
+        return torch.where(gather >= 0, w[gather.clamp(min=0)] * scale[None, :], w.new_zeros(())).contiguous()
+
     def _forward_fused(self, x1, self_connection, species, data):
         """out = lin2(agg) + self_connection without the light three quarters of agg ever reaching memory"""
         fp, t, dev = self.fused_plan, self._fused_tables, x1.device
@@ -117,7 +134,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         avg = self.avg_num_neighbors if self.avg_num_neighbors is not None else 0.0
         num_neigh = None if self.avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
         h2p, w2p = tp.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, data)
-        frag, scale_inv = tp._a_split.get(w2p)
+        frag, scale_inv = tp.a_split(r0, r1)
         inv_light, inv_heavy = self._fused_split.get(frag, scale_inv)
         out = ops.tp_lin2(
             x1, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC], t.get("light", dev),
@@ -152,6 +169,14 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         if (self.fused_plan is not None and DataKey.AMD_SPECIES_I32 in data
                 and not _ag.needs_grad(x1, self_connection, self.lin2.weight, *self.tp.weight_nn.parameters())):
             data[DataKey.NODE_FEATURES] = self._forward_fused(x1, self_connection, species, data)
+            return data
+        if self.agg_plan is not None and not _ag.needs_grad(x1, self_connection, self.lin2.weight,
+                                                             *self.tp.weight_nn.parameters()):
+            ap, t, dev = self.agg_plan, self._agg_tables, x1.device
+            agg = self.tp(x1, data, self.avg_num_neighbors, out_layout=(t.get("entries", dev), ap.ld))
+            data[DataKey.NODE_FEATURES] = ops.agg_linear(agg, species, self._agg_wtab.get(self.lin2.weight),
+                                                         t.get("io", dev), t.get("blocks", dev), ap.d_out,
+                                                         add=self_connection)
             return data
         agg = self.tp(x1, data, self.avg_num_neighbors)
         data[DataKey.NODE_FEATURES] = self.lin2(agg, species, add=self_connection)

@@ -124,6 +124,33 @@ class RadialMLP(torch.nn.Module):
         for i, (a, b) in enumerate(zip(hs, hs[1:])):
             setattr(self, f"layer{i}", _RadialLayer(a, b))
         self._packed = DerivedWeight(self._pack)
+        self._h_scale = DerivedWeight(self._fp16_scale)
+        self._h_scale_c = None
+
+    def _fp16_scale(self, w0: Tensor, w1: Tensor) -> Tensor:
+        """[s, 1/s]: the power of two s <= 1 the hidden features are multiplied by before their fp16 hi/lo split
+        (csrc/tp_fused.hip) so that |s h2| < 2^15 for EVERY possible edge length -- a bound, not a measurement, so no
+        host sync and no data dependence:  |bessel_k| <= sqrt(2/c) sqrt(nb) pi (k+1) / c  (sin(x)/x <= 1),
+        |silu(z)| <= |z|, hence |h2| <= P(c) * max_col sum_k |W0p[k,col]| (k+1) * max_col sum_k |W1p[k,col]|.
+        s = 1 whenever the bound is below 2^15 (every normally scaled MLP: the results are then bit-identical to an
+        unscaled run); a checkpoint whose radial weights are orders of magnitude larger gets s < 1 instead of inf."""
+        nb, h = self.hs[0], self.hs[1]
+        c = self._h_scale_c
+        k1 = torch.arange(1, nb + 1, device=w0.device, dtype=w0.dtype)[:, None]
+        n0 = ((w0.abs() / nb**0.5) * k1).sum(0).max()
+        n1 = (w1.abs() * (self.act_cst / h**0.5)).sum(0).max()
+        bound = (2.0 / c) ** 0.5 * nb**0.5 * 3.141592653589793 / c * n0 * n1
+        s = torch.where(bound > 2.0**15, torch.exp2(torch.floor(torch.log2(2.0**14 / bound.clamp(min=1e-30)))),
+                        torch.ones_like(bound))
+        s = torch.where(torch.isfinite(s) & (s > 0), s, torch.full_like(s, 2.0**-100))
+        return torch.stack([s, 1.0 / s]).float().contiguous()
+
+    def h_scale(self, r_start: float, r_end: float) -> Tensor:
+        c = float(r_end - r_start)
+        if c != self._h_scale_c:
+            self._h_scale_c = c
+            self._h_scale._key = None
+        return self._h_scale.get(self.layer0.weight, self.layer1.weight)
 
     def _pack(self, w0: Tensor, w1: Tensor, w2: Tensor):
         nb, h, W = self.hs[0], self.hs[1], self.hs[3]
@@ -159,7 +186,7 @@ class RadialMLP(torch.nn.Module):
         return x.contiguous()
 
     def hidden(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float, data=None):
-        """(h2s[E,2,32], w2p): the two hidden layers evaluated, the last layer left to the fused TP kernel.
+        """(h2s[E,2,32] scaled by h_scale(), w2p): the two hidden layers evaluated, the last layer left to the fused TP kernel.
         With `data` (the batch dict) and a sibling group (set by the model factory: every conv layer's radial MLP reads
         the same edge lengths) the first call evaluates ALL siblings in one launch and parks the results in the dict."""
         if n_basis != self.hs[0]:
@@ -171,11 +198,11 @@ class RadialMLP(torch.nn.Module):
             if cache is None or cache.get("geom") is not geom_sorted or id(self) not in cache:
                 packs = [m._packed.get(m.layer0.weight, m.layer1.weight, m.layer2.weight) for m in group]
                 outs = ops.radial_hidden_multi(geom_sorted, n_basis, r_start, r_end, [p[0] for p in packs],
-                                               [p[1] for p in packs])
+                                               [p[1] for p in packs], [m.h_scale(r_start, r_end) for m in group])
                 cache = {"geom": geom_sorted, **{id(m): h for m, h in zip(group, outs)}}
                 data["_amd_h2s"] = cache
             return cache.pop(id(self)), w2p   # popped: the 147 MB per layer are released after use
-        return ops.radial_hidden(geom_sorted, n_basis, r_start, r_end, w0p, w1p), w2p
+        return ops.radial_hidden(geom_sorted, n_basis, r_start, r_end, w0p, w1p, self.h_scale(r_start, r_end)), w2p
 
 
 class UVUTensorProduct(torch.nn.Module):
@@ -219,16 +246,26 @@ class UVUTensorProduct(torch.nn.Module):
 
         self._a_split = DerivedWeight(self._split_last_layer)
 
-    def _split_last_layer(self, w2p: Tensor):
-        """the last radial layer as the fp16 hi/lo MFMA fragments of matten_tp_fused (rebuilt when the weights change)"""
-        return ops.split_a_tiles(w2p, self.plan.group_entries)
+    def _split_last_layer(self, w0: Tensor, w1: Tensor, w2: Tensor):
+        """the last radial layer as the fp16 hi/lo MFMA fragments of matten_tp_fused, with 1 / (entry scale x hidden
+        feature scale) as the per-entry output factor (rebuilt when the weights change)"""
+        w2p = self.weight_nn._packed.get(w0, w1, w2)[2]
+        frag, scale_inv = ops.split_a_tiles(w2p, self.plan.group_entries)
+        return frag, (scale_inv * self.weight_nn._h_scale.get(w0, w1)[1]).contiguous()
+
+    def a_split(self, r_start: float, r_end: float):
+        """(fragments, a_scale_inv) for matten_tp_fused / matten_tp_lin2, consistent with weight_nn.hidden()"""
+        mlp = self.weight_nn
+        mlp.h_scale(r_start, r_end)   # fixes the cutoff range the bound is taken for
+        return self._a_split.get(mlp.layer0.weight, mlp.layer1.weight, mlp.layer2.weight)
 
     @property
     def irreps_out(self) -> Irreps:
         return self.irreps_mid.simplify()
 
-    def forward(self, node_feats: Tensor, data: DataKey.Type, avg_num_neighbors=None) -> Tensor:
-        """sum over incoming edges of TP(x[src], Y(edge), MLP(rbf(edge))), normalised; [N, d_mid]."""
+    def forward(self, node_feats: Tensor, data: DataKey.Type, avg_num_neighbors=None, out_layout=None) -> Tensor:
+        """sum over incoming edges of TP(x[src], Y(edge), MLP(rbf(edge))), normalised; [N, d_mid].
+        out_layout = (group entries with component-major output offsets, row stride): plan.AggLinearPlan (fused path only)"""
         nb, r0, r1 = data[DataKey.AMD_RBF].tolist()
         dev = node_feats.device
         avg = avg_num_neighbors if avg_num_neighbors is not None else 0.0
@@ -245,9 +282,10 @@ class UVUTensorProduct(torch.nn.Module):
             h2p, w2p = self.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, data)
             return ops.tp_fused(
                 node_feats, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
-                self._tables.get("gentries", dev), self._tables.get("gumap", dev), len(self.plan.fused_unit_map),
-                self.plan.fused_lds_floats_per_wave, self.plan.d_mid, avg, num_neigh,
-                a_split=self._a_split.get(w2p),
+                out_layout[0] if out_layout is not None else self._tables.get("gentries", dev),
+                self._tables.get("gumap", dev), len(self.plan.fused_unit_map),
+                self.plan.fused_lds_floats_per_wave, out_layout[1] if out_layout is not None else self.plan.d_mid, avg,
+                num_neigh, a_split=self.a_split(r0, r1),
             )
         w_edge = self.weight_nn(data[DataKey.AMD_GEOM], int(nb), r0, r1)
         if self.impl == "blocks":

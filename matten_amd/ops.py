@@ -280,21 +280,24 @@ def split_hidden(h2p: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi.half(), lo.half()], dim=1).contiguous()
 
 
-def radial_hidden(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p) -> torch.Tensor:
-    """-> h2s [E,2,32] fp16 (hi | lo pieces of the 32 hidden features, see include/matten_hip.h)"""
+def radial_hidden(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p, h_scale=None) -> torch.Tensor:
+    """-> h2s [E,2,32] fp16 (hi | lo pieces of the 32 hidden features, see include/matten_hip.h).
+    h_scale: optional fp32 device tensor whose first element is the power-of-two output scale (RadialMLP.h_scale)"""
     lib = _lib.load()
     geom_sorted = _need(geom_sorted, torch.float32, "geom_sorted")
     w0p, w1p = _need(w0p, torch.float32, "w0p"), _need(w1p, torch.float32, "w1p")
     E = geom_sorted.shape[0]
     h2p = torch.empty(E, 2, 32, dtype=torch.float16, device=geom_sorted.device)
     with _timed("radial_hidden"):
+        if h_scale is not None:
+            h_scale = _need(h_scale, torch.float32, "h_scale")
         rc = lib.matten_radial_hidden(_ptr(geom_sorted), E, n_basis, r_start, r_end, _ptr(w0p), w0p.shape[0],
-                                      _ptr(w1p), w0p.shape[1], _ptr(h2p), _stream())
+                                      _ptr(w1p), w0p.shape[1], _ptr(h2p), _ptr(h_scale), _stream())
     _lib.check(rc, "matten_radial_hidden")
     return h2p
 
 
-def radial_hidden_multi(geom_sorted, n_basis: int, r_start: float, r_end: float, w0ps, w1ps):
+def radial_hidden_multi(geom_sorted, n_basis: int, r_start: float, r_end: float, w0ps, w1ps, h_scales=None):
     """h2s of several radial MLPs over the same edges in one launch -> list of [E,2,32] fp16"""
     import ctypes
 
@@ -307,9 +310,14 @@ def radial_hidden_multi(geom_sorted, n_basis: int, r_start: float, r_end: float,
         raise ValueError("radial_hidden_multi: 1..8 layers with equal basis / hidden sizes")
     out = [torch.empty(E, 2, 32, dtype=torch.float16, device=geom_sorted.device) for _ in range(L)]
     arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+    if h_scales is not None:
+        h_scales = [_need(h, torch.float32, "h_scale") for h in h_scales]
+        if len(h_scales) != L:
+            raise ValueError("one h_scale per layer")
     with _timed("radial_hidden_multi"):
         rc = lib.matten_radial_hidden_multi(_ptr(geom_sorted), E, n_basis, r_start, r_end, arr(w0ps), w0ps[0].shape[0],
-                                            arr(w1ps), w0ps[0].shape[1], arr(out), L, _stream())
+                                            arr(w1ps), w0ps[0].shape[1], arr(out),
+                                            arr(h_scales) if h_scales is not None else None, L, _stream())
     _lib.check(rc, "matten_radial_hidden_multi")
     return out
 
@@ -413,6 +421,30 @@ def tp_lin2(x, h2p, w2p, sh_sorted, rowptr, src_sorted, light_entries, rounds, s
                                 float(avg_num_neighbors or 0.0), _ptr(num_neigh), _ptr(frag), _ptr(scale_inv), _ptr(add),
                                 add.stride(0) if add is not None else d_out, d_out, _ptr(out), _stream())
     _lib.check(rc, "matten_tp_lin2")
+    return out
+
+
+def agg_linear(agg, species_order, wtab, io_table, blocks, d_out: int, add=None) -> torch.Tensor:
+    """out[N, d_out] = add + lin2(agg) for component-major neighbour sums (include/matten_hip.h matten_agg_linear;
+    tables from plan.plan_agg_linear).  species_order: (order, seg) or None for a single species."""
+    lib = _lib.load()
+    from .plan import AGG_BLOCK, AGG_MAX_MT
+    if lib.matten_agg_linear_block_chunks() != AGG_BLOCK or lib.matten_agg_linear_max_mt() != AGG_MAX_MT:
+        raise _lib.MattenHipError("plan.AGG_BLOCK / AGG_MAX_MT do not match the library (-DAL_BLK_CHUNKS)")
+    agg = _need(agg, torch.float32, "agg")
+    wtab = _need(wtab, torch.float32, "A fragments")
+    n_rows, ld = agg.shape
+    order, seg = species_order if species_order is not None else (None, None)
+    n_species = wtab.shape[0] if wtab.dim() == 2 else 1
+    if add is not None:
+        add = _need_rows(add, torch.float32, "add")
+    out = torch.empty(n_rows, max(d_out, 32 * io_table.shape[0]) if os.environ.get("MATTEN_AL_ALIGNED_EXPERIMENT") else d_out,
+                      dtype=torch.float32, device=agg.device)
+    with _timed(f"agg_linear/ld={ld}"):
+        rc = lib.matten_agg_linear(_ptr(agg), ld, _ptr(order), _ptr(seg), n_species, _ptr(wtab), wtab.shape[-1],
+                                   _ptr(io_table), io_table.shape[0], _ptr(blocks), blocks.shape[0], _ptr(add),
+                                   add.stride(0) if add is not None else d_out, d_out, n_rows, _ptr(out), _stream())
+    _lib.check(rc, "matten_agg_linear")
     return out
 
 

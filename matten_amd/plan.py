@@ -929,3 +929,140 @@ def plan_conv_fused(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[ConvFu
         d_rest=d_rest, rest=rest, d_out=irreps_out.dim,
         light_ids=np.array(light_ids, dtype=np.int64), heavy_ids=np.array(heavy_ids, dtype=np.int64),
     )
+
+
+# ------------------------------------------------------------------------------------------
+# component-major neighbour sums + the streaming lin2 that reads them (matten_agg_linear)
+# ------------------------------------------------------------------------------------------
+AGG_CHUNK = 16  # floats per streamed piece of a row (one 16-byte load per lane group g = 0..3)
+AGG_BLOCK = int(os.environ.get("MATTEN_AGG_BLOCK", "4"))   # chunks per block of matten_agg_linear (-DAL_BLK_CHUNKS; checked by ops.agg_linear)
+AGG_STAGE_W = 32  # output floats per node of one io_table row (AL_STAGE_W)
+AGG_MAX_MT = 2  # 16-channel output tiles per io_table row (AL_MAX_MT): wider irreps become several rows
+
+
+@dataclass
+class AggLinearPlan:
+    """Layout contract between matten_tp_fused (writer) and matten_agg_linear (reader) for one conv layer
+    (reference nn/conv.py:113-123: agg = scatter(tp(...)); out = lin2(agg, species) + self-connection).
+
+    The reference's message row is "mul_ir": per path [channel u][component k].  lin2 contracts over the channels of ALL
+    paths with the same output irrep, separately for every component k, so the row the two kernels exchange is instead
+            region(io) = [component k][channel slot 0 .. Kpad_io)        one region per lin2 output irrep io
+    with the channels of every (group entry, coupling) that feeds io side by side (widest pieces first: a piece of
+    2^n channels starts at a multiple of 2^n floats) and Kpad_io = K_io rounded up to AGG_CHUNK.  The tensor-product
+    wave stores its channel lanes contiguously; lin2 streams the row front to back in 64-byte pieces, every piece being
+    the K-slice of ONE (io, k) = one accumulator, and needs no transposition.  Pad slots are never written (the
+    reader masks them)."""
+    entries: np.ndarray        # int32 [n_entries, 32]: UVUPlan.group_entries with out_off[c] / t_off[c] = (first float, k stride)
+    ld: int                    # row stride in floats (multiple of 32: rows start on a 128-byte line)
+    n_chunks: int              # AGG_CHUNK-float pieces per row that carry data
+    io_table: np.ndarray       # int32 [n_io, 8] {chunk0, T, K, d3 | n_mt << 8 | cw << 16, a_off, out_off, mo, 0}
+    blocks: np.ndarray         # int32 [n_blk, 4] {first chunk, n | first << 8 | last << 9 | k << 12 | io << 20, t0, 0}
+    w_stride: int              # floats per species of the A table
+    gather: np.ndarray         # int64 [S, w_stride] index into the flat lin2 weight, -1 = structural zero
+    scale: np.ndarray          # f32 [w_stride]
+    d_out: int
+    max_mt: int
+
+
+def plan_agg_linear(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[AggLinearPlan]:
+    """None when an output irrep of lin2 has no input path (the mul_ir path handles those layers)."""
+    irreps_out = Irreps(irreps_out).simplify()
+    S = n_species
+    ent = np.asarray(uvu.group_entries).reshape(-1, 32).copy()
+    mid = uvu.irreps_mid
+    # merged input blocks of lin2 = FullyConnectedTensorProduct(irreps_mid.simplify(), Sx0e, irreps_out)
+    blk_of_slot, uoff_of_slot, blocks = [], [], []
+    for mul, ir in mid:
+        if blocks and blocks[-1][1] == ir:
+            blk_of_slot.append(len(blocks) - 1)
+            uoff_of_slot.append(blocks[-1][0])
+            blocks[-1] = (blocks[-1][0] + mul, ir)
+        else:
+            blk_of_slot.append(len(blocks))
+            uoff_of_slot.append(0)
+            blocks.append((mul, ir))
+    flat_of, fan, flat = {}, {}, 0
+    for ib, (mi, ir) in enumerate(blocks):       # instruction order of the reference: for i_1, for i_out
+        for io, (mo, iro) in enumerate(irreps_out):
+            if iro == ir:
+                flat_of[(ib, io)] = flat
+                flat += mi * S * mo
+                fan[io] = fan.get(io, 0) + mi * S
+    o_offs = irreps_out.offsets()
+    # pieces per output irrep: (entry, coupling, channels)
+    pieces: Dict[int, List[Tuple[int, int, int]]] = {}
+    for e in range(len(ent)):
+        for c, pi in sorted(uvu.group_entry_paths[e].items()):
+            pth = uvu.paths[pi]
+            ir3 = Irrep(pth.l3, pth.p3)
+            ios = [io for io, (_, iro) in enumerate(irreps_out) if iro == ir3]
+            if len(ios) != 1:
+                return None
+            pieces.setdefault(ios[0], []).append((e, c, int(ent[e][2])))
+    if any(io not in pieces for io in range(len(irreps_out)) if irreps_out[io].dim > 0):
+        return None
+    io_rows, gather_parts, scale_parts = [], [], []
+    chunk0, a_off, max_mt = 0, 0, 1
+    for io, (mo, iro) in enumerate(irreps_out):
+        if iro.dim == 0 or mo == 0:
+            continue
+        d3 = iro.dim
+        plist = sorted(pieces[io], key=lambda t: (-(1 << max(0, (t[2] - 1).bit_length())), t[0], t[1]))
+        slot_src: List[Tuple[int, int]] = []      # channel slot -> (merged input block, channel in it)
+        piece_off = {}
+        for (e, c, mul_c) in plist:
+            width = 1 << max(0, (mul_c - 1).bit_length())
+            while len(slot_src) % min(width, AGG_CHUNK):
+                slot_src.append((-1, -1))
+            piece_off[(e, c)] = len(slot_src)
+            pth = uvu.paths[uvu.group_entry_paths[e][c]]
+            ib = blk_of_slot[pth.slot]
+            for uu in range(mul_c):
+                slot_src.append((ib, uoff_of_slot[pth.slot] + uvu.group_entry_u0[e] + uu))
+        K = len(slot_src)
+        T = -(-K // AGG_CHUNK)
+        Kpad = T * AGG_CHUNK
+        for (e, c, _) in plist:
+            ent[e][8 + 12 + c] = chunk0 * AGG_CHUNK + piece_off[(e, c)]   # out_off[c]: first float of channel 0, k = 0
+            ent[e][8 + c] = Kpad                                          # t_off[c]: floats between components
+        # table rows of this irrep: <= AGG_STAGE_W output floats per node each (the kernel's output stage: one 128-byte
+        # line per row), a power-of-two channel count; all rows of an irrep read the same region
+        step = 16 * AGG_MAX_MT
+        while step * d3 > AGG_STAGE_W and step > 1:
+            step //= 2
+        for v0 in range(0, mo, step):
+            mo_p = min(step, mo - v0)
+            n_mt = -(-mo_p // 16)
+            cw = 16 if mo_p >= 16 else mo_p
+            max_mt = max(max_mt, n_mt)
+            # A tiles: [t][mt][g][c < cw][s]  <-  W[channel slot 16 t + 4 g + s][v = v0 + 16 mt + c]
+            t_, mt_, g_, c_, s_ = np.meshgrid(np.arange(T), np.arange(n_mt), np.arange(4), np.arange(cw), np.arange(4), indexing="ij")
+            slot = (16 * t_ + 4 * g_ + s_).reshape(-1)
+            v = (v0 + 16 * mt_ + c_).reshape(-1)
+            src = np.array(slot_src + [(-1, -1)] * (Kpad - K), dtype=np.int64)
+            ib_, u_ = src[slot, 0], src[slot, 1]
+            base = np.array([flat_of.get((int(b), io), 0) for b in ib_], dtype=np.int64)
+            g0 = base + u_ * S * mo + v                     # W[u, s = 0, v]; + s * mo per species
+            valid = (ib_ >= 0) & (v < mo)
+            gather_parts.append(np.where(valid[None, :], g0[None, :] + np.arange(S)[:, None] * mo, -1))
+            scale_parts.append(np.full(slot.size, fan[io] ** -0.5, dtype=np.float32))
+            io_rows.append((chunk0, T, K, d3 | (n_mt << 8) | (cw << 16), a_off, o_offs[io] + v0 * d3, mo_p, 0))
+            a_off += slot.size
+        chunk0 += d3 * T
+    ld = -(-(chunk0 * AGG_CHUNK) // 32) * 32
+    # the row as the reader walks it: blocks of <= AGG_BLOCK chunks of one (io, k) unit
+    blocks = []
+    for ii, (c0, T, K, packed, *_rest) in enumerate(io_rows):
+        for k in range(packed & 255):
+            for t0 in range(0, T, AGG_BLOCK):
+                n = min(AGG_BLOCK, T - t0)
+                last = t0 + n == T
+                blocks.append((c0 + k * T + t0, n | (int(t0 == 0) << 8) | (int(last) << 9)
+                               | (int(last and k == (packed & 255) - 1) << 10) | (k << 12) | (ii << 20), t0, 0))
+    gather = np.concatenate(gather_parts, axis=1).astype(np.int64)
+    assert gather.max() < flat
+    return AggLinearPlan(entries=ent.astype(np.int32), ld=ld, n_chunks=chunk0,
+                         io_table=np.array(io_rows, dtype=np.int32).reshape(-1, 8),
+                         blocks=np.array(blocks, dtype=np.int32).reshape(-1, 4), w_stride=a_off, gather=gather,
+                         scale=np.concatenate(scale_parts), d_out=irreps_out.dim, max_mt=max_mt)

@@ -30,17 +30,37 @@ BLOCK_RTOL = 2e-5  # end-to-end outputs: each irrep block against ITS OWN larges
 ELASTIC_BLOCKS = ((0, 2, "2x0e"), (2, 12, "2x2e"), (12, 21, "4e"))   # CartesianTensor("ijkl=jikl=klij") = 2x0e+2x2e+4e
 
 
-def close_blocks(got, want, blocks=ELASTIC_BLOCKS, rtol=BLOCK_RTOL, what=""):
+def close_blocks(got, want, blocks=ELASTIC_BLOCKS, rtol=BLOCK_RTOL, what="", want64=None, floor=0.0):
     """A weak path (the single 4e block is ~1e-2 of the 0e magnitude at random init) must not hide inside a tolerance
-    taken from the whole tensor's maximum: every irrep block is compared relative to its own maximum."""
+    taken from the whole tensor's maximum: every irrep block is compared relative to its own maximum.
+    want64: the same oracle evaluated in fp64.  A block that (nearly) vanishes by crystal symmetry -- the pooled 2e / 4e
+    parts of a cubic cell are sums of per-atom terms that cancel -- carries the rounding of those terms, not of its own
+    size; there the fp32 oracle's own distance from the fp64 one sets the scale: the HIP path may be at most 4x as far
+    from the fp64 result as the fp32 oracle is.  floor (where no fp64 oracle is at hand: committed fp32 golden
+    vectors, two HIP paths against each other): the same allowance as a fraction of the whole tensor's maximum."""
     got, want = got.detach().cpu().double(), want.detach().cpu().double()
     assert got.shape == want.shape, (what, got.shape, want.shape)
     assert blocks[-1][1] == want.shape[-1]
     for lo, hi, name in blocks:
         scale = want[..., lo:hi].abs().max().item()
-        err = (got[..., lo:hi] - want[..., lo:hi]).abs().max().item()
+        tol = max(rtol * scale, floor * want.abs().max().item())
+        ref = want[..., lo:hi]
+        if want64 is not None:
+            ref = want64.detach().cpu().double()[..., lo:hi]
+            tol = max(tol, 4.0 * (want[..., lo:hi] - ref).abs().max().item())
+        err = (got[..., lo:hi] - ref).abs().max().item()
         assert scale > 0 or err == 0, f"{what} block {name}: empty reference block"
-        assert err <= rtol * scale, f"{what} block {name}: max err {err:.3e} vs block scale {scale:.3e} (rel {err / max(scale, 1e-300):.2e})"
+        assert err <= tol, f"{what} block {name}: max err {err:.3e} vs block scale {scale:.3e} (rel {err / max(scale, 1e-300):.2e}, allowed {tol:.3e})"
+
+
+def _fp64(ref):
+    import copy
+
+    return copy.deepcopy(ref).double()
+
+
+def _to64(batch):
+    return {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in batch.items()}
 
 
 def _fcc(n):
@@ -278,12 +298,19 @@ def _run_pair(ref, model, graphs):
     return preds["elastic_tensor_full"], want
 
 
+def _want64(ref, graphs):
+    from matten_amd.data.graph import collate
+
+    with torch.no_grad():
+        return _fp64(ref).decode(_to64(collate(graphs)))
+
+
 def test_config3_fcc64_end_to_end():
     graphs, ds = _fcc(8)
     ref, model = build_pair(PAPER, ds, randomize_bn=True)
     got, want = _run_pair(ref, model, graphs)
     assert got.shape == (8, 21)
-    close_blocks(got, want, what="fcc64 [B,21]")
+    close_blocks(got, want, what="fcc64 [B,21]", want64=_want64(ref, graphs))
 
 
 def test_config2_n100_end_to_end(golden_dir):
@@ -299,7 +326,7 @@ def test_config2_n100_end_to_end(golden_dir):
     ref, model = build_pair(PAPER, ds, randomize_bn=True)
     got, want = _run_pair(ref, model, graphs)
     assert got.shape == (100, 21)
-    close_blocks(got, want, what="n100 [B,21]")
+    close_blocks(got, want, what="n100 [B,21]", want64=_want64(ref, graphs))
 
 
 def test_gpu_matches_committed_golden_vectors(golden_dir):
@@ -332,7 +359,7 @@ def test_gpu_matches_committed_golden_vectors(golden_dir):
     want = torch.as_tensor(golden["teo_cartesian"])
     assert cart.shape == want.shape == (1, 3, 3, 3, 3)
     ct = CartesianTensorWrapper("ijkl=jikl=klij")
-    close_blocks(ct.from_cartesian(cart.cpu().double()), ct.from_cartesian(want.double()), what="golden TeO (irreps view)")
+    close_blocks(ct.from_cartesian(cart.cpu().double()), ct.from_cartesian(want.double()), what="golden TeO (irreps view)", floor=1e-6)
     close(cart, want, 2e-5, "golden TeO Cartesian")
 
     structs = structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))[:6]
@@ -342,7 +369,72 @@ def test_gpu_matches_committed_golden_vectors(golden_dir):
     model = hip_model(PAPER, ds)
     with torch.no_grad():
         got = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
-    close_blocks(got, torch.as_tensor(golden["n100_first6_irreps"]), what="golden n100 first six")
+    close_blocks(got, torch.as_tensor(golden["n100_first6_irreps"]), what="golden n100 first six", floor=1e-6)
+
+
+def test_component_major_conv_matches_mul_ir_path(monkeypatch, golden_dir):
+    """The production conv writes its neighbour sums component-major and applies lin2 with matten_agg_linear
+    (plan.plan_agg_linear); MATTEN_AGG_LAYOUT=mul_ir keeps the reference's [channel][component] row and the
+    segment-table linear.  Same weights, same batch: per conv layer and end to end the two agree to fp32 rounding, on
+    the fcc batch (10 species, whole 128-row workgroups) and on the n100 sample (73 species, ragged species groups,
+    groups smaller than one wave)."""
+    from matten_amd.data.graph import average_num_neighbors, collate, crystal_graph
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+    from oracle.matten_ref.data import structures_from_json
+
+    structs = structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))[:40]
+    g100 = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
+    ds100 = {"allowed_species": sorted({int(z) for s in structs for z in s["atomic_numbers"]}),
+             "average_num_neighbors": average_num_neighbors(g100)}
+    gf, dsf = _fcc(5)
+    for graphs, ds, hp in ((gf, dsf, PAPER), (g100, ds100, PAPER), (g100, ds100, LMAX2)):
+        torch.manual_seed(11)
+        monkeypatch.setenv("MATTEN_AGG_LAYOUT", "km")
+        new = ScalarTensorModel(backbone_hparams=dict(hp), dataset_hparams=ds).to(DEV).eval()
+        monkeypatch.setenv("MATTEN_AGG_LAYOUT", "mul_ir")
+        old = ScalarTensorModel(backbone_hparams=dict(hp), dataset_hparams=ds).to(DEV).eval()
+        old.load_state_dict(new.state_dict())
+        convs_new = [m for m in new.modules() if type(m).__name__ == "PointConv"]
+        convs_old = [m for m in old.modules() if type(m).__name__ == "PointConv"]
+        assert all(m.agg_plan is not None for m in convs_new) and all(m.agg_plan is None for m in convs_old)
+        feats = {}
+        for tag, convs in (("new", convs_new), ("old", convs_old)):
+            for i, m in enumerate(convs):
+                m.register_forward_hook(lambda mod, inp, out, key=(tag, i): feats.__setitem__(key, out["node_features"].clone()))
+        with torch.no_grad():
+            b = collate(graphs, device=DEV)
+            y_new = new(dict(b))[0]["elastic_tensor_full"]
+            y_old = old(dict(b))[0]["elastic_tensor_full"]
+        for i in range(len(convs_new)):
+            close(feats[("new", i)], feats[("old", i)], 2e-6, f"conv layer {i} node features")
+        close_blocks(y_new, y_old, rtol=5e-6, what="end to end", floor=5e-7)
+
+
+def test_huge_radial_weights_stay_inside_the_fp16_split_range():
+    """The fused kernel feeds the hidden radial features to the matrix cores as fp16 hi/lo pieces (csrc/tp_fused.hip):
+    a checkpoint whose first two radial layers are 10^4 x larger (hidden features ~10^8, far beyond fp16's 65504) must
+    still give the oracle's numbers.  The host bounds |h2| from the weights and hands the kernels a power-of-two scale
+    (RadialMLP.h_scale); for the normally scaled model that scale is exactly 1."""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _fcc(4)
+    ref, model = build_pair(PAPER, ds, randomize_bn=True)
+    mlps = [m for m in model.modules() if type(m).__name__ == "RadialMLP"]
+    assert len(mlps) == 4 and all(float(m.h_scale(0.0, 5.0)[0]) == 1.0 for m in mlps)
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if ".weight_nn.layer0." in k or ".weight_nn.layer1." in k:
+                p.mul_(1e4)
+            elif ".weight_nn.layer2." in k:
+                p.mul_(1e-8)   # keeps the per-edge weights O(1): four conv layers of 10^12 would leave fp32 itself
+    model.load_state_dict(ref.state_dict(), strict=False)
+    scales = [float(m.h_scale(0.0, 5.0)[0]) for m in mlps]
+    assert all(0.0 < s < 2.0**-10 for s in scales), scales
+    with torch.no_grad():
+        want = ref.decode(collate(graphs))
+        got = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+    assert torch.isfinite(got).all()
+    close_blocks(got, want, rtol=1e-4, what="radial hidden layers x 1e4")
 
 
 def test_config1_si_diamond_cubic_symmetry():
@@ -358,7 +450,7 @@ def test_config1_si_diamond_cubic_symmetry():
     ds = {"allowed_species": [14], "average_num_neighbors": 28.0}
     ref, model = build_pair(PAPER, ds)
     got, want = _run_pair(ref, model, [g])
-    close_blocks(got, want, what="Si [1,21]")
+    close_blocks(got, want, what="Si [1,21]", want64=_want64(ref, [g]))
     C = CartesianTensorWrapper("ijkl=jikl=klij").to_cartesian(got)[0].cpu().double()
     scale = C.abs().max().item()
     c11, c22, c33 = C[0, 0, 0, 0], C[1, 1, 1, 1], C[2, 2, 2, 2]
@@ -387,7 +479,7 @@ def test_reference_equivariance_test_on_gpu(golden_dir):
         o1 = tc(model.backbone(collate([g1], device=DEV))["my_model_output"])[0].cpu()
         o2 = tc(model.backbone(collate([g2], device=DEV))["my_model_output"])[0].cpu()
         w1 = ref.backbone(collate([g1]))["my_model_output"]
-    close_blocks(model.backbone(collate([g1], device=DEV))["my_model_output"], w1, what="TeO fixture")
+    close_blocks(model.backbone(collate([g1], device=DEV))["my_model_output"], w1, what="TeO fixture", floor=1e-6)
     assert torch.allclose(o1, o1.swapaxes(0, 1))
     assert torch.allclose(o1, o1.swapaxes(2, 3))
     assert torch.allclose(o1, o1.swapaxes(0, 2).swapaxes(1, 3))
@@ -707,7 +799,8 @@ def test_config3_full_size_batch_properties():
         y_small = model.decode(dict(small))["elastic_tensor_full"]
         want = ref.decode(collate([crystal_graph(*triples[i], 5.0) for i in pick]))
     assert torch.equal(y[pick], y_small)                                             # (a)
-    close_blocks(y[pick], want, what="full-size batch vs oracle on 6 crystals")      # (b)
+    close_blocks(y[pick], want, what="full-size batch vs oracle on 6 crystals",      # (b)
+                 want64=_want64(ref, [crystal_graph(*triples[i], 5.0) for i in pick]))
 
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).tolist()
     with torch.no_grad():
