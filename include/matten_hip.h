@@ -178,6 +178,8 @@ int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t 
  * ------------------------------------------------------------------------------------------ */
 int matten_agg_linear_max_mt(void);        /* column tiles per io_table row (mul_out of a row <= 16 * this) */
 int matten_agg_linear_block_chunks(void);  /* chunks per block (the n of a blocks[] row is <= this) */
+size_t matten_agg_linear_lds_bytes(int64_t w_stride, int64_t n_io, int64_t n_blocks);   /* LDS a launch needs ... */
+size_t matten_agg_linear_max_lds_bytes(void);                                          /* ... and may have */
 int matten_agg_linear(const float* agg, int64_t ld, const int32_t* order, const int32_t* seg, int64_t n_species,
                       const float* wtab, int64_t w_stride, const int32_t* io_table, int64_t n_io,
                       const int32_t* blocks, int64_t n_blocks, const float* add, int64_t add_ld, int64_t d_out,

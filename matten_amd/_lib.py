@@ -35,6 +35,8 @@ SIGNATURES = {
     "matten_radial_hidden_multi": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, c_int, P, P, c_int, P]),
     "matten_agg_linear_max_mt": (c_int, []),
     "matten_agg_linear_block_chunks": (c_int, []),
+    "matten_agg_linear_lds_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "matten_agg_linear_max_lds_bytes": (c_size_t, []),
     "matten_agg_linear": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int64,
                                   c_int64, P, P]),
     "matten_radial_hidden": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, c_int, P, P, P]),

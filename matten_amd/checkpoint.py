@@ -61,7 +61,7 @@ _SAFE_TORCH_CONTAINERS = {"ModuleDict", "ModuleList", "Sequential", "Module", "I
 # classes of this package a checkpoint written by it may carry (hyper_parameters['tasks'] and their normalisers)
 _SAFE_OWN_GLOBALS = {
     ("matten_amd.model_factory.task", "Task"), ("matten_amd.model_factory.task", "TensorRegressionTask"),
-    ("matten_amd.model_factory.task", "ScalarRegressionTask"),
+    ("matten_amd.model_factory.task", "ScalarRegressionTask"), ("matten_amd.model_factory.task", "CanonicalRegressionTask"),
     ("matten_amd.data.transform", "MeanNormNormalize"), ("matten_amd.data.transform", "ScalarNormalize"),
     ("matten_amd.data.transform", "TensorTargetTransform"), ("matten_amd.data.transform", "ScalarTargetTransform"),
     ("matten_amd.o3", "Irrep"), ("matten_amd.o3", "MulIr"), ("matten_amd.o3", "Irreps"),

@@ -21,7 +21,10 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int AL_WAVES = 8;      // waves per workgroup: 128 rows of one species share one copy of the weights in LDS
+#ifndef AL_WAVES_PER_WG
+#define AL_WAVES_PER_WG 8
+#endif
+constexpr int AL_WAVES = AL_WAVES_PER_WG;   // waves per workgroup: they share one copy of the species weights in LDS
 constexpr int AL_ROWS = 16;      // rows per wave (the N dimension of the matrix instruction)
 #ifndef AL_BLK_CHUNKS
 #define AL_BLK_CHUNKS 4
@@ -35,7 +38,6 @@ constexpr int AL_MAX_MT = 2;     // 16-channel output tiles per table row: wider
                                  // scalars, a few chunks per row).  Small on purpose: accumulators + addend = 16 registers,
                                  // ~80 in all, six waves per SIMD -- the stream is hidden by occupancy, not by depth
 
-constexpr int AL_STAGE_W = 32;    // output floats per row and table row (mul_out_part * d3 <= 32): one 128-byte line
 constexpr int AL_STAGE_RS = 33;   // row stride of the wave's output stage (odd: the 16 rows hit 16 banks)
 
 struct AggIo {   // plan.AggLinearPlan.io_table
@@ -61,7 +63,12 @@ struct Args {
     int n_species, w_stride, n_io, n_blk, add_ld, d_out, n_rows;
 };
 
-__global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) void agg_linear_kernel(Args a) {
+#ifdef AL_WAVES_PER_EU
+#define AL_OCC __attribute__((amdgpu_waves_per_eu(AL_WAVES_PER_EU, AL_WAVES_PER_EU)))
+#else
+#define AL_OCC
+#endif
+__global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linear_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     AggIo* io_l = reinterpret_cast<AggIo*>(lds + a.w_stride);
     AggBlk* blk_l = reinterpret_cast<AggBlk*>(io_l + a.n_io);
@@ -160,8 +167,8 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) void agg_linear_kerne
             const int rid = rowid[r];
 #ifdef AL_ABL_NO_STORE
             if (fcol < w && rid >= 0 && addv[p] == 12345.678f)
-#elif defined(AL_ABL_ALIGNED)   // timing experiment: every table row owns one aligned 128-byte line per node (wrong layout)
-            if (rid >= 0) a.out[((int64_t)rid * a.n_io + cur_ii) * 32 + fcol] = stage[r * AL_STAGE_RS + fcol] + addv[p];
+#elif defined(AL_ABL_SMALL_OUT)   // timing experiment: same store instructions, all into 64 cache-resident rows
+            if (fcol < w && rid >= 0) a.out[(int64_t)(rid & 63) * a.d_out + out_off + fcol] = stage[r * AL_STAGE_RS + fcol] + addv[p];
             if (false)
 #else
             if (fcol < w && rid >= 0)
@@ -245,7 +252,13 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) void agg_linear_kerne
 
 }  // namespace
 
-extern "C" int matten_agg_linear_max_mt(void) { return AL_MAX_MT; }
+constexpr size_t AL_MAX_LDS = 80 * 1024;   // two workgroups per CU
+extern "C" size_t matten_agg_linear_lds_bytes(int64_t w_stride, int64_t n_io, int64_t n_blocks) {
+    return sizeof(float) * (size_t)w_stride + sizeof(AggIo) * (size_t)n_io + sizeof(AggBlk) * (size_t)n_blocks +
+           sizeof(float) * AL_WAVES * (16 * AL_STAGE_RS + 16);
+}
+extern "C" size_t matten_agg_linear_max_lds_bytes(void) { return AL_MAX_LDS; }
+extern "C" int matten_agg_linear_max_mt(void) { return AL_MAX_MT; }   // (a table row is also at most 32 output floats wide)
 extern "C" int matten_agg_linear_block_chunks(void) { return AL_BLK; }
 
 extern "C" int matten_agg_linear(const float* agg, int64_t ld, const int32_t* order, const int32_t* seg,
@@ -261,10 +274,18 @@ extern "C" int matten_agg_linear(const float* agg, int64_t ld, const int32_t* or
     if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
     if (!order && n_species != 1) return MATTEN_EINVAL;
     if (add && add_ld < d_out) return MATTEN_EINVAL;
-    const size_t lds = sizeof(float) * (size_t)w_stride + sizeof(AggIo) * (size_t)n_io + sizeof(AggBlk) * (size_t)n_blocks +
-                       sizeof(float) * AL_WAVES * (16 * AL_STAGE_RS + 16);
-    if (lds > 64 * 1024) return MATTEN_EINVAL;
-    // species-major workgroups of 128 rows: at most one partly filled workgroup per species
+    const size_t lds = matten_agg_linear_lds_bytes(w_stride, n_io, n_blocks);
+    if (lds > AL_MAX_LDS) return MATTEN_EINVAL;
+    if (lds > 64 * 1024) {   // gfx950: 160 KB of LDS per CU, a workgroup may take more than the default 64 KB on request
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*)agg_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)AL_MAX_LDS) != hipSuccess)
+                return MATTEN_ELAUNCH;
+            raised = true;
+        }
+    }
+    // species-major workgroups of AL_WAVES x 16 rows: at most one partly filled workgroup per species
     const int64_t grid = matten_cdiv(n_rows, AL_WAVES * AL_ROWS) + n_species;
     if (grid >= ((int64_t)1 << 31) || n_rows >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
     Args a{agg, order, seg, wtab, (const AggIo*)io_table, (const AggBlk*)blocks, add, out, ld, (int)n_species,

@@ -12,6 +12,7 @@ from typing import Any, Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
+from ..model.model import BaseModel
 from ..nn._nequip import SphericalHarmonicEdgeAttrs
 from ..nn.conv import PointConv, PointConvWithActivation
 from ..nn.embedding import EdgeLengthEmbedding, SpeciesEmbedding
@@ -102,7 +103,7 @@ def link_radial_mlps(backbone) -> None:
                 link_radial_group(group[i:i + 8])
 
 
-class ScalarTensorModel(torch.nn.Module):
+class ScalarTensorModel(BaseModel):
     def __init__(
         self,
         tasks=None,
@@ -115,7 +116,7 @@ class ScalarTensorModel(torch.nn.Module):
         **kwargs,
     ):
         super().__init__()
-        self.hparams = {
+        hparams = {
             "tasks": tasks,
             "backbone_hparams": backbone_hparams,
             "dataset_hparams": dataset_hparams,
@@ -129,6 +130,8 @@ class ScalarTensorModel(torch.nn.Module):
         self.backbone, extra = self.init_backbone(backbone_hparams, dataset_hparams)
         self.extra_layers_dict = torch.nn.ModuleDict(extra)
         self.tasks = self.init_tasks(tasks)
+        # losses, metrics, hyper-parameter record: the training shell of the reference's BaseModel (model/model.py:66-99)
+        self._init_training_shell(hparams)
 
     # --- reference: ScalarTensorModel.init_backbone, tfn_scalar_tensor.py:33-61 -----------------
     def init_backbone(self, backbone_hparams, dataset_hparams=None) -> Tuple[torch.nn.Module, Dict]:
@@ -146,19 +149,17 @@ class ScalarTensorModel(torch.nn.Module):
     # --- reference: BaseModel.init_tasks, model/model.py:126-141 -------------------------------
     @staticmethod
     def init_tasks(tasks) -> Dict[str, Any]:
-        if tasks is None:
-            return {"elastic_tensor_full": None}
-        if isinstance(tasks, str):
-            return {tasks: None}
-        if isinstance(tasks, dict):
-            return tasks
-        if isinstance(tasks, (list, tuple)):
-            return {getattr(t, "name", t): t for t in tasks}
-        return {tasks.name: tasks}
+        from .task import TensorRegressionTask
 
-    @property
-    def device(self):
-        return next(self.parameters()).device
+        if tasks is None:   # the reference always passes a task; a bare name / nothing means "no target normaliser"
+            tasks = "elastic_tensor_full"
+        if isinstance(tasks, str):
+            return {tasks: TensorRegressionTask(name=tasks)}
+        if isinstance(tasks, dict):
+            return {k: (t if t is not None else TensorRegressionTask(name=k)) for k, t in tasks.items()}
+        if isinstance(tasks, (list, tuple)):
+            return {getattr(t, "name", t): (TensorRegressionTask(name=t) if isinstance(t, str) else t) for t in tasks}
+        return {tasks.name: tasks}
 
     # --- reference: ModelForPyGData.preprocess_batch, model/model.py:493-518 --------------------
     def preprocess_batch(self, batch):

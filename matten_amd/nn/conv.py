@@ -75,8 +75,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         self.agg_plan = None
         if self.tp.impl == "fused" and self.fused_plan is None and os.environ.get("MATTEN_AGG_LAYOUT", "km") == "km":
             ap = _plan.plan_agg_linear(self.tp.plan, n_species, conv_layer_irreps)
-            if (ap is not None and ap.max_mt <= 5
-                    and 4 * ap.w_stride + 32 * len(ap.io_table) + 16 * len(ap.blocks) + 4 * 8 * (16 * 33 + 16) <= 64 * 1024):
+            if ap is not None and self._agg_fits(ap):
                 self.agg_plan = ap
                 self._agg_tables = DeviceTables(entries=ap.entries, io=ap.io_table, blocks=ap.blocks, gather=ap.gather,
                                                 scale=ap.scale)
@@ -119,6 +118,16 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         """per-entry power-of-two scales of the A fragments, re-indexed for the light and the heavy entry lists"""
         t, dev = self._fused_tables, frag.device
         return scale_inv[t.get("light_ids", dev)].contiguous(), scale_inv[t.get("heavy_ids", dev)].contiguous()
+
+    @staticmethod
+    def _agg_fits(ap) -> bool:
+        """the layer's tables fit the LDS matten_agg_linear may take (wider layers keep the mul_ir path)"""
+        from .. import _lib
+        try:
+            lib = _lib.load()
+        except Exception:  # noqa: BLE001  (no library: construction-time planning on a build box)
+            return 4 * ap.w_stride <= 40 * 1024
+        return lib.matten_agg_linear_lds_bytes(ap.w_stride, len(ap.io_table), len(ap.blocks)) <= lib.matten_agg_linear_max_lds_bytes()
 
     def _pack_agg_weights(self, w: torch.Tensor) -> torch.Tensor:
         """lin2.weight (flat, reference layout) -> [S, w_stride] MFMA A fragments of matten_agg_linear"""

@@ -438,8 +438,7 @@ def agg_linear(agg, species_order, wtab, io_table, blocks, d_out: int, add=None)
     n_species = wtab.shape[0] if wtab.dim() == 2 else 1
     if add is not None:
         add = _need_rows(add, torch.float32, "add")
-    out = torch.empty(n_rows, max(d_out, 32 * io_table.shape[0]) if os.environ.get("MATTEN_AL_ALIGNED_EXPERIMENT") else d_out,
-                      dtype=torch.float32, device=agg.device)
+    out = torch.empty(n_rows, d_out, dtype=torch.float32, device=agg.device)
     with _timed(f"agg_linear/ld={ld}"):
         rc = lib.matten_agg_linear(_ptr(agg), ld, _ptr(order), _ptr(seg), n_species, _ptr(wtab), wtab.shape[-1],
                                    _ptr(io_table), io_table.shape[0], _ptr(blocks), blocks.shape[0], _ptr(add),

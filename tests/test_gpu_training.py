@@ -190,3 +190,37 @@ def test_hipgraph_forward_above_a_million_edges():
     dense = {"edge_index": torch.zeros(2, 2_000_000, dtype=torch.int64), "pos": torch.zeros(1000, 3)}
     with pytest.raises(ValueError, match="radix sort"):
         _check_capturable(dense)
+
+
+def test_training_script_loop_through_the_matten_alias(golden_dir):
+    """scripts/train_materials_tensor.py:34-66 of the reference on the MI355X: data module, model with the training
+    shell (shared_step / compute_loss / metrics / configure_optimizers), `Trainer.fit` + `Trainer.test` -- with this
+    package's minimal Trainer standing in for Lightning's (not installed here).  The loss falls over a few steps."""
+    from matten.dataset.structure_scalar_tensor import TensorDataModule
+    from matten.model.trainer import Trainer
+    from matten.model_factory.task import TensorRegressionTask
+    from matten.model_factory.tfn_scalar_tensor import ScalarTensorModel
+
+    dm = TensorDataModule(trainset_filename="example_crystal_elasticity_tensor_n100.json",
+                          valset_filename="example_crystal_elasticity_tensor_n100.json",
+                          testset_filename="example_crystal_elasticity_tensor_n100.json", root=golden_dir, r_cut=5.0,
+                          tensor_target_name="elastic_tensor_full", tensor_target_scale=1e-2,
+                          loader_kwargs={"batch_size": 32, "shuffle": True}, device=DEV)
+    dm.prepare_data()
+    dm.setup()
+    torch.manual_seed(35)
+    model = ScalarTensorModel(
+        tasks=TensorRegressionTask(name="elastic_tensor_full"), backbone_hparams=dict(LMAX2),
+        dataset_hparams=dm.get_to_model_info(),
+        optimizer_hparams={"class_path": "torch.optim.Adam", "init_args": {"lr": 0.01, "weight_decay": 0.00001}},
+        lr_scheduler_hparams={"class_path": "torch.optim.lr_scheduler.ReduceLROnPlateau",
+                              "init_args": {"mode": "min", "factor": 0.5, "patience": 50}},
+    ).to(DEV)
+    trainer = Trainer(max_epochs=3)
+    trainer.fit(model, datamodule=dm)
+    h = trainer.history
+    assert len(h) == 3 and all(np.isfinite(e["val/score"]) for e in h)
+    assert h[-1]["train/total_loss"] < h[0]["train/total_loss"]
+    assert h[-1]["val/score"] < h[0]["val/score"]                 # mean absolute error on the (same) validation file
+    out = trainer.test(model, datamodule=dm)
+    assert "metric_test/MeanAbsoluteError/elastic_tensor_full" in out[0]

@@ -605,3 +605,61 @@ def test_bench_launches_its_ranks_as_a_child_process(monkeypatch):
     seen.clear()
     bench.main()
     assert ran["args"].gpus == 8 and not seen
+
+
+def test_reference_training_script_call_sequence_under_the_matten_alias(golden_dir):
+    """scripts/train_materials_tensor.py:11-14,34-52 of the reference, line by line, with `import matten` resolving to
+    this package: data module -> get_to_model_info -> ScalarTensorModel(tasks=TensorRegressionTask(...), ...) ->
+    configure_optimizers (what Trainer.fit calls first).  The forward itself needs the MI355X (tests/test_gpu_training)."""
+    import matten
+    import matten_amd
+    from matten.dataset.structure_scalar_tensor import TensorDataModule
+    from matten.log import set_logger
+    from matten.model_factory.task import TensorRegressionTask
+    from matten.model_factory.tfn_scalar_tensor import ScalarTensorModel
+    from common import LMAX2
+
+    assert ScalarTensorModel is matten_amd.model_factory.tfn_scalar_tensor.ScalarTensorModel
+    assert matten.predict.predict is matten_amd.predict.predict
+    import matten.nn.conv as c1
+    import matten_amd.nn.conv as c2
+    assert c1 is c2
+    set_logger("ERROR")
+    config = {
+        "data": {"root": golden_dir, "tensor_target_name": "elastic_tensor_full",
+                 "trainset_filename": "example_crystal_elasticity_tensor_n100.json",
+                 "valset_filename": "example_crystal_elasticity_tensor_n100.json",
+                 "testset_filename": "example_crystal_elasticity_tensor_n100.json",
+                 "r_cut": 5.0, "reuse": False, "loader_kwargs": {"batch_size": 32, "shuffle": True}},
+        "model": dict(LMAX2),
+        "optimizer": {"class_path": "torch.optim.Adam", "init_args": {"lr": 0.01, "weight_decay": 0.00001}},
+        "lr_scheduler": {"class_path": "torch.optim.lr_scheduler.ReduceLROnPlateau",
+                         "init_args": {"mode": "min", "factor": 0.5, "patience": 50, "verbose": True}},
+    }
+    dm = TensorDataModule(**config["data"])
+    dm.prepare_data()
+    dm.setup()
+    info = dm.get_to_model_info()
+    assert len(info["allowed_species"]) == 73 and abs(info["average_num_neighbors"] - 30.4017) < 1e-3
+    model = ScalarTensorModel(
+        tasks=TensorRegressionTask(name=config["data"]["tensor_target_name"]),
+        backbone_hparams=config["model"],
+        dataset_hparams=info,
+        optimizer_hparams=config["optimizer"],
+        lr_scheduler_hparams=config["lr_scheduler"],
+    )
+    assert model.hparams["dataset_hparams"]["allowed_species"] == info["allowed_species"]
+    cfg = model.configure_optimizers()
+    assert isinstance(cfg["optimizer"], torch.optim.Adam) and cfg["monitor"] == "val/score"
+    assert isinstance(cfg["lr_scheduler"], torch.optim.lr_scheduler.ReduceLROnPlateau)
+    assert cfg["optimizer"].defaults["lr"] == 0.01 and cfg["optimizer"].defaults["weight_decay"] == 0.00001
+    batch = next(iter(dm.train_dataloader()))
+    assert batch["elastic_tensor_full"].shape == (32, 21) and batch["ptr"].shape == (33,)
+    # the loss / metric half of shared_step on stand-in predictions (the decode half runs on the GPU)
+    labels = {"elastic_tensor_full": batch["elastic_tensor_full"]}
+    preds = {"elastic_tensor_full": batch["elastic_tensor_full"] + 0.5}
+    individual, total = model.compute_loss(preds, labels)
+    assert abs(float(total) - 0.25) < 1e-6 and set(individual) == {"elastic_tensor_full"}
+    model.update_metrics(preds, labels, "val")
+    model.on_validation_epoch_end()
+    assert abs(float(model.logged["val/score"]) - 0.5) < 1e-6   # mean absolute error = the monitored score
