@@ -325,3 +325,61 @@ def test_real_spherical_harmonics_match_sympy():
                 c = scale * math.sqrt(2) * (-1) ** m
                 assert np.allclose(got[:, l * l + l + m], c * val.real, atol=1e-12), (l, m)
                 assert np.allclose(got[:, l * l + l - m], c * val.imag, atol=1e-12), (l, -m)
+
+
+def test_oracle_matches_e3nn_golden(golden_dir):
+    """tests/golden/e3nn_golden.npz is written by tests/golden/make_golden_e3nn.py where REAL e3nn 0.5.1 and the
+    reference run (neither exists in the build container nor on the GPU box).  When the file is there, every e3nn-held
+    piece of the oracle is compared with it: Wigner-3j for all l <= 4 triples, spherical harmonics, the Cartesian bases,
+    the normalize2mom constants, the Bessel embedding and -- with the reference model's own state_dict loaded into the
+    oracle -- the node features after every backbone module and the Cartesian tensor of the TeO fixture
+    (tests/model/test_tfn_tensor.py:23-42,99 of the reference).  Without the file the oracle is pinned only by the
+    reference's property tests, the survey's anchors and sympy: PARITY UNPINNED, reported as a skip."""
+    path = os.path.join(golden_dir, "e3nn_golden.npz")
+    if not os.path.exists(path):
+        pytest.skip("PARITY UNPINNED: tests/golden/e3nn_golden.npz absent (e3nn is not installable here; "
+                    "generate it with tests/golden/make_golden_e3nn.py where e3nn==0.5.1 runs)")
+    ref = np.load(path)
+    for key in ref.files:
+        if key.startswith("w3j_"):
+            l1, l2, l3 = map(int, key.split("_")[1:])
+            got = o3.wigner_3j(l1, l2, l3, dtype=torch.float64).numpy()
+            assert np.allclose(got, ref[key], atol=1e-12), key
+    pts = torch.as_tensor(ref["sh_points"])
+    assert np.allclose(o3.spherical_harmonics([0, 1, 2, 3, 4], pts, True, "component").numpy(), ref["sh_values"], atol=1e-12)
+    for name, formula in (("ijkl", "ijkl=jikl=klij"), ("ij", "ij=ji")):
+        ct = io.CartesianTensor(formula)
+        assert str(ct) == str(ref[f"cart_irreps_{name}"])
+        assert np.allclose(ct.change_of_basis(torch.float64).numpy(), ref[f"cart_basis_{name}"], atol=1e-10), formula
+    acts = {"silu": torch.nn.functional.silu, "sigmoid": torch.sigmoid, "tanh": torch.tanh, "abs": torch.abs,
+            "ssp": lambda x: torch.nn.functional.softplus(x) - math.log(2.0)}
+    for k, f in acts.items():
+        assert abs(enn.normalize2mom(f).cst - float(ref[f"normalize2mom_{k}"])) < 1e-6, k
+    r = torch.as_tensor(ref["soft_one_hot_r"])
+    assert np.allclose(soft_one_hot_linspace(r, 0.0, 5.0, 8, "bessel", True).numpy(), ref["soft_one_hot_bessel"], atol=1e-12)
+
+    # the reference's model on the TeO fixture, layer by layer
+    batch = {k[len("teo/in/"):]: torch.as_tensor(ref[k]) for k in ref.files if k.startswith("teo/in/")}
+    state = {k[len("teo/state/"):]: torch.as_tensor(ref[k]) for k in ref.files if k.startswith("teo/state/")}
+    model = create_model(dict(EQUIV_TEST), {"allowed_species": [8, 52]}).eval()
+    own = model.state_dict()
+    missing = [k for k in own if k not in state]
+    assert not missing, missing
+    model.load_state_dict({k: state[k] for k in own})
+    acts_out = {}
+    for name, child in model.named_children():
+        child.register_forward_hook(
+            lambda mod, inp, res, name=name: acts_out.__setitem__(name, res["node_features"].clone())
+            if isinstance(res, dict) and "node_features" in res else None)
+    with torch.no_grad():
+        res = model(dict(batch))
+    for k in ref.files:
+        if k.startswith("teo/act/"):
+            want = torch.as_tensor(ref[k])
+            got = acts_out[k[len("teo/act/"):]]
+            assert torch.allclose(got, want, rtol=0, atol=2e-5 * want.abs().max().item()), k
+    want = torch.as_tensor(ref["teo/my_model_output"])
+    assert torch.allclose(res["my_model_output"], want, rtol=0, atol=2e-5 * want.abs().max().item())
+    cart = ToCartesian("ijkl=jikl=klij")(res["my_model_output"])
+    want = torch.as_tensor(ref["teo/cartesian"])
+    assert torch.allclose(cart, want, rtol=0, atol=2e-5 * want.abs().max().item())
