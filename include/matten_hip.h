@@ -319,6 +319,22 @@ int matten_segment_reduce(const float* x, int64_t dim, const int64_t* ptr, int64
                           float* out, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Adjoint of the radial MLP (training; reference nn/utils.py:246-251,260 differentiated by autograd there).
+ * Inputs as matten_radial_mlp (packed weights; w2p in the column order of dw), plus dw[E, dw_ld] = dL/dw from
+ * matten_tp_backward (fp32, or bf16 when dw_is_bf16; only the first w_cols columns are read as data).
+ * Outputs are PARTIAL sums the caller adds up (fixed order, no atomics):
+ *   part_small[matten_radial_mlp_bwd_small_slices(E)][nb_pad*32 + 32*32]: d/dW0p [nb_pad,32] then d/dW1p [32,32]
+ *   part_w2[matten_radial_mlp_bwd_w2_ranges(E)][32][w_pad]:               d/dW2p
+ *   h2_scratch[E, 32]: workspace (the recomputed hidden features, written by the first kernel, read by the second)
+ * ------------------------------------------------------------------------------------------ */
+int64_t matten_radial_mlp_bwd_small_slices(int64_t n_edges);
+int64_t matten_radial_mlp_bwd_w2_ranges(int64_t n_edges);
+int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
+                          const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden, int w_pad,
+                          int w_cols, const void* dw, int64_t dw_ld, int dw_is_bf16, float* h2_scratch,
+                          float* part_small, float* part_w2, matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * CartesianTensor.to_cartesian (utils.py:123-124, predict.py:145): out[b,:] = x[b,:] @ Q
  *   Q [n_in, n_out] row-major (n_in = 21, n_out = 81 for ijkl=jikl=klij)
  * ------------------------------------------------------------------------------------------ */

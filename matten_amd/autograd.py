@@ -3,10 +3,9 @@ torch.autograd bindings of the HIP operators for the training step (SURVEY.md se
 
 The reference trains by autograd through e3nn's einsums and torch_scatter (model/model.py:276-372).  Here
 each operator's adjoint is a hand-written kernel (matten_amd/csrc/backward.hip); autograd only chains them
-and carries the cheap differentiable re-packings of the parameters (index + scale).  Two pieces of the
-training step are plain dense algebra and go through the library GEMM (rocBLAS via torch.mm), exactly what
-the design rules reserve libraries for: the radial MLP (three bias-free GEMMs over the edges) and the
-16-wide species embedding.
+and carries the cheap differentiable re-packings of the parameters (index + scale).  The radial MLP runs forward
+(matten_radial_mlp) and backward (matten_radial_mlp_bwd) on this library's own fp32-MFMA kernels; no library GEMM is
+left on the step (the 16-wide species embedding is an index lookup).
 """
 from typing import Optional
 
@@ -62,6 +61,27 @@ class SpeciesLinearFn(torch.autograd.Function):
             n_species = wp.shape[0] if wp.dim() == 2 else 1
             dwp = ops.species_linear_wgrad(x, g, ctx.species_order, n_species, segs, plan.w_stride).reshape(wp.shape)
         return dx, dwp, (g if ctx.has_add else None), None, None
+
+
+class RadialMLPFn(torch.autograd.Function):
+    """w[E, w_pad] = MLP(bessel(|edge|)) in the reference's weight-column order (pad columns zero); the adjoint maps
+    dL/dw back to the three raw weight matrices (the packing is a per-layer scale and a row padding)."""
+
+    @staticmethod
+    def forward(ctx, w0, w1, w2, mod, geom_sorted, n_basis, r_start, r_end):
+        w0p, w1p, w2p = mod.pack_reference_order(w0, w1, w2)
+        ctx.mod, ctx.rbf = mod, (int(n_basis), float(r_start), float(r_end))
+        ctx.save_for_backward(geom_sorted, w0p, w1p, w2p)
+        return ops.radial_mlp(geom_sorted, int(n_basis), float(r_start), float(r_end), w0p, w1p, w2p)
+
+    @staticmethod
+    def backward(ctx, g):
+        geom, w0p, w1p, w2p = ctx.saved_tensors
+        mod = ctx.mod
+        nb, h, W = mod.hs[0], mod.hs[1], mod.hs[3]
+        d0, d1, d2 = ops.radial_mlp_bwd(geom, *ctx.rbf, w0p, w1p, w2p, W, g.contiguous())
+        c = mod.act_cst / h**0.5
+        return d0[:nb] / nb**0.5, d1 * c, d2[:, :W] * c, None, None, None, None, None
 
 
 class TensorProductScatterFn(torch.autograd.Function):

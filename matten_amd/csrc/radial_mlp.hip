@@ -18,13 +18,14 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NT = 4;        // N tiles (16 edges each) per wave
+// N tiles (16 edges each) per wave: 4 on large graphs (weights fetched once per 64 edges), 1 on small ones (a training
+// batch of 32 crystals has ~4 k edges: parallelism matters more than the amortisation)
 constexpr int WAVES = 4;     // waves per workgroup
 constexpr int HID = 32;      // hidden width (2 M-tiles)
 
 __device__ __forceinline__ float silu(float z) { return z / (1.0f + expf(-z)); }
 
-template <int KS0>  // number of k-steps of the first layer: nb_pad / 4
+template <int KS0, int NT>  // number of k-steps of the first layer: nb_pad / 4; edge tiles per wave
 __global__ __launch_bounds__(WAVES * 64) void radial_mlp_kernel(
     const float4* __restrict__ geom, int64_t E, int n_basis, float r_start, float r_end,
     const float* __restrict__ w0p, const float* __restrict__ w1p, const float* __restrict__ w2p, int w_pad,
@@ -120,16 +121,18 @@ extern "C" int matten_radial_mlp(const float* geom_sorted, int64_t n_edges, int 
         return MATTEN_EINVAL;
     if (n_edges == 0) return MATTEN_OK;
     if (!geom_sorted || !w0p || !w1p || !w2p || !w_edge) return MATTEN_EINVAL;
-    unsigned grid = (unsigned)matten_cdiv(n_edges, WAVES * NT * 16);
-#define LAUNCH(K)                                                                                                    \
-    radial_mlp_kernel<K><<<grid, WAVES * 64, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis, r_start,     \
-                                                          r_end, w0p, w1p, w2p, w_pad, w_edge)
-    switch (nb_pad >> 2) {
-        case 1: LAUNCH(1); break;
-        case 2: LAUNCH(2); break;
-        case 3: LAUNCH(3); break;
-        default: LAUNCH(4); break;
+#define LAUNCH(K, NTT)                                                                                               \
+    radial_mlp_kernel<K, NTT><<<(unsigned)matten_cdiv(n_edges, WAVES * NTT * 16), WAVES * 64, 0, stream>>>(           \
+        (const float4*)geom_sorted, n_edges, n_basis, r_start, r_end, w0p, w1p, w2p, w_pad, w_edge)
+#define LAUNCH_K(NTT)                     \
+    switch (nb_pad >> 2) {                \
+        case 1: LAUNCH(1, NTT); break;    \
+        case 2: LAUNCH(2, NTT); break;    \
+        case 3: LAUNCH(3, NTT); break;    \
+        default: LAUNCH(4, NTT); break;   \
     }
+    if (n_edges >= 64 * 1024) { LAUNCH_K(4) } else { LAUNCH_K(1) }
+#undef LAUNCH_K
 #undef LAUNCH
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;

@@ -1,0 +1,303 @@
+// Adjoint of the radial MLP (training step): given dL/dw[E, w_ld] from the tensor-product adjoint, the gradients of the
+// three bias-free layers of e3nn FullyConnectedNet([nb, 32, 32, W], silu)  (reference nn/utils.py:246-251,260; the
+// reference gets them from autograd through three torch.mm).
+//
+// In the packed form the forward kernel (radial_mlp.hip) evaluates:
+//      b = bessel(|v|) [nb]   z1 = b W0p   h1 = silu(z1)   z2 = h1 W1p   h2 = silu(z2)   w = h2 W2p
+// (the 1/sqrt(fan_in) and normalize2mom factors live in W0p, W1p, W2p; the host maps the packed gradients back).
+//      dh2 = dw W2p^T          dW2p = h2^T dw
+//      dz2 = dh2 * silu'(z2)   dW1p = h1^T dz2     dh1 = dz2 W1p^T
+//      dz1 = dh1 * silu'(z1)   dW0p = b^T dz1
+// Two kernels, both on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), both reading dw once:
+//   radial_mlp_bwd_edges   a wave owns tiles of 16 edges (edges = the N dimension, like the forward kernel): recomputes
+//                          z1, h1, z2, h2 in registers, contracts dw with W2p over the weight columns (16 bytes per lane
+//                          and row: whole 64-byte pieces of 16 rows per load, the four floats being the B operands of
+//                          four matrix steps), chains dz2 -> dh1 -> dz1 in registers (the D fragment of one layer is the B
+//                          operand of the next, as in the forward kernel), writes h2 for the second kernel, and sums the
+//                          two small weight gradients over its edges (operands transposed through a wave-private LDS
+//                          tile: there the contraction runs over the edges)
+//   radial_mlp_bwd_w2      dW2p[k, q] = sum_e h2[e, k] dw[e, q]: a wave owns 16 weight columns and an edge range
+// Both write PARTIAL sums (one slice per wave / per edge range) that the host adds up in a fixed order: no atomics,
+// bit-reproducible.  dw may be fp32 or bf16 (the opt-in bf16 storage of the per-edge tensors).
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+#include "sh.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HID = 32;
+constexpr int BW_WAVES = 4;
+constexpr int BW_TILES_MAX = 8;      // 16-edge tiles per wave of radial_mlp_bwd_edges: fewer on small graphs (see bw_tiles)
+constexpr int TS = 17;               // row stride of the LDS transpose tiles (16 edges + 1: bank spread)
+constexpr int W2_RANGE_MAX = 4096;   // edges per partial sum of radial_mlp_bwd_w2: fewer on small graphs (see w2_range)
+
+// Small graphs (a training batch of 32 crystals has ~4 k edges) need the parallelism more than the short partial lists:
+// a wave takes one tile / a range is 256 edges until there are ~2000 waves' worth of work.
+inline int bw_tiles(int64_t n_edges) {
+    const int64_t t = n_edges / (16 * 2048);
+    return (int)(t < 1 ? 1 : (t > BW_TILES_MAX ? BW_TILES_MAX : t));
+}
+inline int w2_range(int64_t n_edges) {
+    int64_t r = (n_edges / 64 + 15) / 16 * 16;
+    return (int)(r < 256 ? 256 : (r > W2_RANGE_MAX ? W2_RANGE_MAX : r));
+}
+
+__device__ __forceinline__ float silu(float z) { return z / (1.0f + expf(-z)); }
+__device__ __forceinline__ float dsilu(float z) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 load4(const void* base, int64_t idx) {   // 4 consecutive elements at element index idx
+    if constexpr (BF16) {
+        const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+        return f32x4{__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                     __uint_as_float(raw.y & 0xffff0000u)};
+    } else {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ float load1(const void* base, int64_t idx) {
+    if constexpr (BF16) return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(base)[idx] << 16);
+    else return reinterpret_cast<const float*>(base)[idx];
+}
+
+// part_small[wave slice][nb_pad*32 (dW0p) + 32*32 (dW1p)]
+template <int KS0, bool BF16>
+__global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_edges(
+    const float4* __restrict__ geom, int64_t E, int n_basis, float r_start, float r_end, const float* __restrict__ w0p,
+    const float* __restrict__ w1p, const float* __restrict__ w2p, int w_pad, int w_cols, const void* __restrict__ dw,
+    int64_t dw_ld, float* __restrict__ h2_out, float* __restrict__ part_small, int tiles_per_wave) {
+    __shared__ float lds[BW_WAVES][(3 * HID + 16) * TS];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t slice = (int64_t)blockIdx.x * BW_WAVES + wave;
+    const int64_t e_first = slice * (tiles_per_wave * 16);
+    float* t_h1 = lds[wave];                 // [32][TS]  h1[k][e]
+    float* t_dz2 = t_h1 + HID * TS;          // [32][TS]
+    float* t_dz1 = t_dz2 + HID * TS;         // [32][TS]
+    float* t_b = t_dz1 + HID * TS;           // [16][TS]  bessel[k0][e]
+    // weights as matrix operands, fixed for the whole walk
+    float a0[2][KS0], a1[2][8], a1t[2][8];
+#pragma unroll
+    for (int kk = 0; kk < KS0; ++kk) {
+        a0[0][kk] = w0p[(4 * kk + g) * HID + c];
+        a0[1][kk] = w0p[(4 * kk + g) * HID + 16 + c];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);    // pi(kk, g): the feature the lane's D register (kk) holds
+        a1[0][kk] = w1p[k * HID + c];                        // forward:  A[m = out c][K = in k]
+        a1[1][kk] = w1p[k * HID + 16 + c];
+        a1t[0][kk] = w1p[c * HID + k];                       // adjoint:  A[m = in c][K = out k]
+        a1t[1][kk] = w1p[(16 + c) * HID + k];
+    }
+    f32x4 g_w1[2][2], g_w0[2];   // dW1p[m-tile over in][n-tile over out], dW0p[n-tile over hidden] (rows = basis index)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        g_w0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) g_w1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int tile = 0; tile < tiles_per_wave; ++tile) {
+        const int64_t e0 = e_first + tile * 16;
+        if (e0 >= E) break;
+        const int64_t e = e0 + c;
+        const bool e_ok = e < E;
+        const int64_t ec = e_ok ? e : E - 1;
+        const float len = geom[ec].w;
+        // ---- forward recomputation (same operand order as radial_mlp_kernel) ----
+        float bes[KS0];
+        f32x4 z1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, z2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < KS0; ++kk) {
+            const int k = 4 * kk + g;
+            bes[kk] = (k < n_basis && e_ok) ? matten::bessel_basis(len, k, n_basis, r_start, r_end) : 0.0f;
+            z1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0][kk], bes[kk], z1[0], 0, 0, 0);
+            z1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1][kk], bes[kk], z1[1], 0, 0, 0);
+        }
+        f32x4 h1[2], h2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[t][r] = silu(z1[t][r]);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float b = h1[kk >> 2][kk & 3];
+            z2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0][kk], b, z2[0], 0, 0, 0);
+            z2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1][kk], b, z2[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[t][r] = silu(z2[t][r]);
+        if (e_ok) {   // h2[e, 16 t + 4 g + r]: four consecutive floats per tile
+            *reinterpret_cast<f32x4*>(h2_out + e * HID + 4 * g) = h2[0];
+            *reinterpret_cast<f32x4*>(h2_out + e * HID + 16 + 4 * g) = h2[1];
+        }
+        // ---- dh2[k, e] = sum_q W2p[k, q] dw[e, q]: rows k = M, edges = N, columns q contracted 16 per load ----
+        f32x4 dh2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int q0 = 0; q0 < w_pad; q0 += 16) {
+            const int q = q0 + 4 * g;
+            f32x4 b4 = load4<BF16>(dw, ec * dw_ld + q);
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(w2p + (int64_t)c * w_pad + q);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(w2p + (int64_t)(16 + c) * w_pad + q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float b = (q + s < w_cols && e_ok) ? b4[s] : 0.0f;   // pad columns of dw are never written: select
+                dh2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], b, dh2[0], 0, 0, 0);
+                dh2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[s], b, dh2[1], 0, 0, 0);
+            }
+        }
+        // ---- dz2, dh1 = W1p dz2 (contraction over the out index: the D registers are the B operand), dz1 ----
+        f32x4 dz2[2], dh1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dz1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz2[t][r] = dh2[t][r] * dsilu(z2[t][r]);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float b = dz2[kk >> 2][kk & 3];
+            dh1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1t[0][kk], b, dh1[0], 0, 0, 0);
+            dh1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1t[1][kk], b, dh1[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz1[t][r] = dh1[t][r] * dsilu(z1[t][r]);
+        // ---- the two small weight gradients: contraction over the tile's 16 edges, operands through LDS ----
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * t + 4 * g + r;
+                t_h1[k * TS + c] = h1[t][r];
+                t_dz2[k * TS + c] = dz2[t][r];
+                t_dz1[k * TS + c] = dz1[t][r];
+            }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) t_b[(4 * kk + g) * TS + c] = kk < KS0 ? bes[kk < KS0 ? kk : 0] : 0.0f;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {   // K step s: edges 4 s + g
+            const int ee = 4 * s + g;
+            const float h1a = t_h1[c * TS + ee], h1b = t_h1[(16 + c) * TS + ee];
+            const float d2a = t_dz2[c * TS + ee], d2b = t_dz2[(16 + c) * TS + ee];
+            const float d1a = t_dz1[c * TS + ee], d1b = t_dz1[(16 + c) * TS + ee];
+            const float bb = t_b[c * TS + ee];
+            g_w1[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1a, d2a, g_w1[0][0], 0, 0, 0);
+            g_w1[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1a, d2b, g_w1[0][1], 0, 0, 0);
+            g_w1[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1b, d2a, g_w1[1][0], 0, 0, 0);
+            g_w1[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1b, d2b, g_w1[1][1], 0, 0, 0);
+            g_w0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb, d1a, g_w0[0], 0, 0, 0);
+            g_w0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb, d1b, g_w0[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- this wave's partial sums: D[row 4 g + r][col c] ----
+    const int nb_pad = 4 * KS0;
+    float* out = part_small + slice * (int64_t)(nb_pad * HID + HID * HID);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k0 = 4 * g + r;
+            if (k0 < nb_pad) out[k0 * HID + 16 * tn + c] = g_w0[tn][r];
+        }
+    float* out1 = out + nb_pad * HID;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out1[(16 * tm + 4 * g + r) * HID + 16 * tn + c] = g_w1[tm][tn][r];
+}
+
+// part_w2[range][32][w_pad]; grid = (ceil(w_pad / 64), n_ranges), wave w of a block owns columns [64 bx + 16 w, +16)
+template <bool BF16>
+__global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_w2(const float* __restrict__ h2, const void* __restrict__ dw,
+                                                                  int64_t dw_ld, int64_t E, int w_pad,
+                                                                  float* __restrict__ part_w2, int range) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int q0 = (blockIdx.x * BW_WAVES + wave) * 16;
+    if (q0 >= w_pad) return;
+    const int64_t e_beg = (int64_t)blockIdx.y * range;
+    const int64_t e_end = min(E, e_beg + range);
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int64_t e0 = e_beg; e0 < e_end; e0 += 16) {
+        float a[4][2], b[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {   // K step s: edge e0 + 4 s + g; A[m = k][K = edge] = h2[edge][k], B[K = edge][n = q]
+            const int64_t e = e0 + 4 * s + g;
+            const bool ok = e < e_end;
+            const int64_t ec = ok ? e : e_end - 1;
+            a[s][0] = ok ? h2[ec * HID + c] : 0.0f;
+            a[s][1] = ok ? h2[ec * HID + 16 + c] : 0.0f;
+            b[s] = ok ? load1<BF16>(dw, ec * dw_ld + q0 + c) : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][0], b[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][1], b[s], acc[1], 0, 0, 0);
+        }
+    }
+    float* out = part_w2 + (int64_t)blockIdx.y * HID * w_pad;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(int64_t)(16 * t + 4 * g + r) * w_pad + q0 + c] = acc[t][r];
+}
+
+}  // namespace
+
+extern "C" int64_t matten_radial_mlp_bwd_small_slices(int64_t n_edges) {
+    return matten_cdiv(matten_cdiv(n_edges, bw_tiles(n_edges) * 16), BW_WAVES) * BW_WAVES;
+}
+extern "C" int64_t matten_radial_mlp_bwd_w2_ranges(int64_t n_edges) { return matten_cdiv(n_edges, w2_range(n_edges)); }
+
+extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
+                                     const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden,
+                                     int w_pad, int w_cols, const void* dw, int64_t dw_ld, int dw_is_bf16,
+                                     float* h2_scratch, float* part_small, float* part_w2, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_edges < 0 || hidden != HID || (w_pad & 15) || w_pad <= 0 || w_cols <= 0 || w_cols > w_pad || (nb_pad & 3) ||
+        nb_pad < n_basis || nb_pad > 16 || dw_ld < w_pad || (dw_ld & 3))
+        return MATTEN_EINVAL;
+    if (n_edges == 0) return MATTEN_OK;
+    if (!geom_sorted || !w0p || !w1p || !w2p || !dw || !h2_scratch || !part_small || !part_w2) return MATTEN_EINVAL;
+    const unsigned grid1 = (unsigned)(matten_radial_mlp_bwd_small_slices(n_edges) / BW_WAVES);
+#define LAUNCH(K, B)                                                                                                  \
+    radial_mlp_bwd_edges<K, B><<<grid1, BW_WAVES * 64, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis,     \
+                                                                     r_start, r_end, w0p, w1p, w2p, w_pad, w_cols, dw, \
+                                                                     dw_ld, h2_scratch, part_small, bw_tiles(n_edges))
+#define LAUNCH_K(B)                     \
+    switch (nb_pad >> 2) {              \
+        case 1: LAUNCH(1, B); break;    \
+        case 2: LAUNCH(2, B); break;    \
+        case 3: LAUNCH(3, B); break;    \
+        default: LAUNCH(4, B); break;   \
+    }
+    if (dw_is_bf16) { LAUNCH_K(true) } else { LAUNCH_K(false) }
+#undef LAUNCH_K
+#undef LAUNCH
+    MATTEN_LAUNCH_CHECK();
+    dim3 grid2((unsigned)matten_cdiv(w_pad, 16 * BW_WAVES), (unsigned)matten_radial_mlp_bwd_w2_ranges(n_edges));
+    if (dw_is_bf16)
+        radial_mlp_bwd_w2<true><<<grid2, BW_WAVES * 64, 0, stream>>>(h2_scratch, dw, dw_ld, n_edges, w_pad, part_w2,
+                                                                     w2_range(n_edges));
+    else
+        radial_mlp_bwd_w2<false><<<grid2, BW_WAVES * 64, 0, stream>>>(h2_scratch, dw, dw_ld, n_edges, w_pad, part_w2,
+                                                                      w2_range(n_edges));
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}

@@ -69,12 +69,11 @@ def ensure_edge_geometry(data: DataKey.Type, lmax: int = None, want_vectors=Fals
 
 
 def ensure_training_edge_tensors(data: DataKey.Type) -> DataKey.Type:
-    """Extra per-edge tensors the adjoint kernels / the library-GEMM radial MLP need (built once per batch):
-    Bessel embedding and destination ids in destination-sorted order."""
-    if "_amd_emb_sorted" not in data:
-        ensure_edge_geometry(data, want_embedding=True)
+    """Extra per-edge tensor the tensor-product adjoint needs (built once per batch): destination ids in
+    destination-sorted order."""
+    if "_amd_dst_sorted" not in data:
+        ensure_edge_geometry(data)
         perm = data[DataKey.AMD_PERM].long()
-        data["_amd_emb_sorted"] = data[DataKey.EDGE_EMBEDDING][perm].contiguous()
         data["_amd_dst_sorted"] = data[DataKey.EDGE_INDEX][1][perm].to(torch.int32).contiguous()
     return data
 

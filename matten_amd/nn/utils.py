@@ -175,15 +175,26 @@ class RadialMLP(torch.nn.Module):
         w0p, w1p, w2p = self._packed.get(self.layer0.weight, self.layer1.weight, self.layer2.weight)
         return ops.radial_mlp(geom_sorted, n_basis, r_start, r_end, w0p, w1p, w2p)
 
-    def forward_train(self, emb_sorted: Tensor) -> Tensor:
-        """w[E, W] in the reference column order through library GEMMs (rocBLAS), differentiable.
-        Same arithmetic as e3nn FullyConnectedNet: x <- c*silu(x @ W/sqrt(h_in)); last layer linear."""
-        x = emb_sorted
-        for i, layer in enumerate((self.layer0, self.layer1, self.layer2)):
-            x = x @ (layer.weight / self.hs[i] ** 0.5)
-            if i < 2:
-                x = torch.nn.functional.silu(x) * self.act_cst
-        return x.contiguous()
+    def pack_reference_order(self, w0: Tensor, w1: Tensor, w2: Tensor):
+        """(w0p, w1p, w2p) with the LAST layer's columns in the reference's order (what the training tensor product and
+        its adjoint index), padded to a multiple of 16"""
+        nb, h, W = self.hs[0], self.hs[1], self.hs[3]
+        nb_pad, w_pad = (nb + 3) // 4 * 4, (W + 15) // 16 * 16
+        w0p = w0.new_zeros(nb_pad, h)
+        w0p[:nb] = w0 / nb**0.5
+        w1p = (w1 * (self.act_cst / h**0.5)).contiguous()
+        w2p = w2.new_zeros(h, w_pad)
+        w2p[:, :W] = w2 * (self.act_cst / h**0.5)
+        return w0p, w1p, w2p
+
+    def forward_train(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float) -> Tensor:
+        """w[E, w_pad] in the reference column order, differentiable w.r.t. the three weight matrices: forward and
+        adjoint are this library's MFMA kernels (matten_radial_mlp / matten_radial_mlp_bwd).  Same arithmetic as e3nn
+        FullyConnectedNet: x <- c*silu(x @ W/sqrt(h_in)); last layer linear."""
+        if n_basis != self.hs[0]:
+            raise ValueError(f"radial basis size {n_basis} != MLP input {self.hs[0]}")
+        return _ag.RadialMLPFn.apply(self.layer0.weight, self.layer1.weight, self.layer2.weight, self, geom_sorted,
+                                     n_basis, r_start, r_end)
 
     def hidden(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float, data=None):
         """(h2s[E,2,32] scaled by h_scale(), w2p): the two hidden layers evaluated, the last layer left to the fused TP kernel.
@@ -271,12 +282,12 @@ class UVUTensorProduct(torch.nn.Module):
         avg = avg_num_neighbors if avg_num_neighbors is not None else 0.0
         num_neigh = None if avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
         if _ag.needs_grad(node_feats, *self.weight_nn.parameters()):
-            # training path: radial weights materialised in the reference layout (library GEMMs), the
-            # tensor product + neighbour sum and its adjoint are the HIP kernels
+            # training path: radial weights materialised in the reference layout by the MLP kernel, the tensor
+            # product + neighbour sum and both adjoints are HIP kernels too
             from ._nequip import ensure_training_edge_tensors
 
             ensure_training_edge_tensors(data)
-            w_edge = self.weight_nn.forward_train(data["_amd_emb_sorted"])
+            w_edge = self.weight_nn.forward_train(data[DataKey.AMD_GEOM], int(nb), r0, r1)
             return _ag.TensorProductScatterFn.apply(node_feats, w_edge, self, data, avg, num_neigh)
         if self.impl == "fused":
             h2p, w2p = self.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, data)

@@ -203,6 +203,35 @@ def radial_mlp(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p
     return out
 
 
+def radial_mlp_bwd(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p, w2p, w_cols: int, dw):
+    """Adjoint of radial_mlp w.r.t. the packed weights -> (dW0p [nb_pad,32], dW1p [32,32], dW2p [32,w_pad]).
+    dw [E, ld >= w_pad] fp32 or bf16: dL/dw from tp_backward (pad columns are never read as data)."""
+    lib = _lib.load()
+    geom_sorted = _need(geom_sorted, torch.float32, "geom_sorted")
+    w0p, w1p, w2p = (_need(w, torch.float32, n) for w, n in ((w0p, "w0p"), (w1p, "w1p"), (w2p, "w2p")))
+    if dw.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("dw must be fp32 or bf16")
+    dw = _need(dw, dw.dtype, "dw")
+    E = geom_sorted.shape[0]
+    nb_pad, hidden = w0p.shape
+    w_pad = w2p.shape[1]
+    dev = geom_sorted.device
+    n_small, n_rng = lib.matten_radial_mlp_bwd_small_slices(E), lib.matten_radial_mlp_bwd_w2_ranges(E)
+    h2 = torch.empty(E, hidden, dtype=torch.float32, device=dev)
+    part_small = torch.empty(max(n_small, 1), nb_pad * hidden + hidden * hidden, dtype=torch.float32, device=dev)
+    part_w2 = torch.empty(max(n_rng, 1), hidden, w_pad, dtype=torch.float32, device=dev)
+    if E == 0:
+        return w0p.new_zeros(nb_pad, hidden), w1p.new_zeros(hidden, hidden), w2p.new_zeros(hidden, w_pad)
+    with _timed(f"radial_mlp_bwd/w_pad={w_pad}"):
+        rc = lib.matten_radial_mlp_bwd(_ptr(geom_sorted), E, n_basis, r_start, r_end, _ptr(w0p), nb_pad, _ptr(w1p),
+                                       _ptr(w2p), hidden, w_pad, int(w_cols), _ptr(dw), dw.shape[1],
+                                       int(dw.dtype == torch.bfloat16), _ptr(h2), _ptr(part_small), _ptr(part_w2), _stream())
+    _lib.check(rc, "matten_radial_mlp_bwd")
+    small = part_small.sum(0)     # fixed-order reductions of the per-wave / per-range partial sums (no atomics anywhere)
+    return (small[: nb_pad * hidden].reshape(nb_pad, hidden), small[nb_pad * hidden:].reshape(hidden, hidden),
+            part_w2.sum(0))
+
+
 def tp_scatter(x, w_edge, sh_sorted, rowptr, src_sorted, m_idx, m_coef, out_meta, avg_num_neighbors: float,
                num_neigh=None) -> torch.Tensor:
     lib = _lib.load()
@@ -532,14 +561,14 @@ def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk,
     E = w_edge.shape[0]
     W = col_meta.shape[0]
     dx = torch.zeros(N, d_in, dtype=torch.float32, device=x.device)
-    dw = torch.empty(E, W, dtype=torch.float32, device=x.device)
+    dw = torch.empty(E, w_edge.shape[1], dtype=torch.float32, device=x.device)   # same row stride as w_edge
     if num_neigh is not None:
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
     with _timed(f"tp_backward/d_mid={g_agg.shape[1]}/d_in={d_in}"):
         rc = lib.matten_tp_backward(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
                                     _ptr(src_sorted), _ptr(dst_sorted), _ptr(col_meta), W, _ptr(nnz_ijk), _ptr(nnz_c),
                                     _ptr(g_agg), g_agg.shape[1], float(avg_num_neighbors or 0.0), _ptr(num_neigh), E,
-                                    _ptr(dx), _ptr(dw), W, _ptr(in_groups[0]) if in_groups else None,
+                                    _ptr(dx), _ptr(dw), dw.shape[1], _ptr(in_groups[0]) if in_groups else None,
                                     _ptr(in_groups[1]) if in_groups else None,
                                     in_groups[0].shape[0] - 1 if in_groups else 0, _stream())
     _lib.check(rc, "matten_tp_backward")

@@ -224,3 +224,43 @@ def test_training_script_loop_through_the_matten_alias(golden_dir):
     assert h[-1]["val/score"] < h[0]["val/score"]                 # mean absolute error on the (same) validation file
     out = trainer.test(model, datamodule=dm)
     assert "metric_test/MeanAbsoluteError/elastic_tensor_full" in out[0]
+
+
+@pytest.mark.parametrize("n_edges,W", [(1, 48), (37, 216), (5000, 432), (4096 + 17, 842)])
+def test_radial_mlp_kernels_forward_and_adjoint(n_edges, W):
+    """matten_radial_mlp / matten_radial_mlp_bwd (fp32 MFMA, partial sums in a fixed order) against the plain formula of
+    e3nn FullyConnectedNet([8, 32, 32, W], silu) differentiated by torch autograd in fp64: w, dW0, dW1, dW2; edges at and
+    beyond the cutoff included, edge counts that leave ragged tiles / several partial-sum ranges; bitwise reproducible."""
+    from matten_amd.nn.utils import RadialMLP
+    from oracle.e3nn_lite.math import soft_one_hot_linspace
+
+    g = torch.Generator().manual_seed(n_edges + W)
+    mlp = RadialMLP([8, 32, 32, W]).to(DEV)
+    lens = torch.rand(n_edges, generator=g, dtype=torch.float64) * 5.4 + 0.05
+    if n_edges > 3:
+        lens[1], lens[2] = 5.0, 6.5      # at / beyond the cutoff: zero embedding
+    geom = torch.zeros(n_edges, 4, device=DEV)
+    geom[:, 3] = lens.float().to(DEV)
+    gout = torch.randn(n_edges, (W + 15) // 16 * 16, generator=g).to(DEV)
+
+    w = mlp.forward_train(geom, 8, 0.0, 5.0)
+    assert w.shape == gout.shape and torch.all(w[:, W:] == 0)
+    (w * gout).sum().backward()
+    got = [mlp.layer0.weight.grad.clone(), mlp.layer1.weight.grad.clone(), mlp.layer2.weight.grad.clone()]
+    for p in mlp.parameters():
+        p.grad = None
+    w_again = mlp.forward_train(geom, 8, 0.0, 5.0)
+    (w_again * gout).sum().backward()
+    assert torch.equal(w, w_again)
+    assert all(torch.equal(a, p.grad) for a, p in zip(got, (mlp.layer0.weight, mlp.layer1.weight, mlp.layer2.weight)))
+
+    ws = [p.detach().cpu().double().requires_grad_(True) for p in (mlp.layer0.weight, mlp.layer1.weight, mlp.layer2.weight)]
+    x = soft_one_hot_linspace(lens.float().double(), 0.0, 5.0, 8, "bessel", True) * 8**0.5
+    c = mlp.act_cst
+    h = torch.nn.functional.silu(x @ (ws[0] / 8**0.5)) * c
+    h = torch.nn.functional.silu(h @ (ws[1] / 32**0.5)) * c
+    want = h @ (ws[2] / 32**0.5)
+    (want * gout[:, :W].cpu().double()).sum().backward()
+    _close(w[:, :W], want, 2e-6, "radial weights")
+    for name, a, b in zip(("dW0", "dW1", "dW2"), got, ws):
+        _close(a, b.grad, 2e-5, name)
