@@ -107,11 +107,11 @@ int matten_edge_geom(const float* pos, const int64_t* edge_index, const float* e
  *   w0p[nb_pad, h], w1p[h, h], w2p[h, w_pad]: weights pre-scaled by 1/sqrt(fan_in) and by the
  *        normalize2mom constant of the *previous* activation, row-major, zero padded
  *        (nb_pad multiple of 4, h == 32, w_pad multiple of 16)
- *   out: w_edge[E, w_pad]
+ *   out: w_edge[E, w_pad] fp32, or bf16 (round to nearest even) when out_is_bf16
  * ------------------------------------------------------------------------------------------ */
 int matten_radial_mlp(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                       const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden, int w_pad,
-                      float act_cst, float* w_edge, matten_stream_t stream);
+                      float act_cst, void* w_edge, int out_is_bf16, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * 'uvu' TensorProduct + gather + scatter-add + neighbour normalisation, fused
@@ -137,11 +137,12 @@ int matten_tp_scatter(const float* x /*[N,d_in]*/, int64_t d_in, const float* w_
  *   unit_start[n_entries+1]   int32  prefix sum of waves per node tile (matten_tp_tile_nodes() nodes per tile)
  * ------------------------------------------------------------------------------------------ */
 int matten_tp_tile_nodes(void);
-int matten_tp_paths(const float* x, int64_t d_in, const float* w_edge, int64_t w_pad, const float* sh_sorted,
+/* (w_edge: fp32, or bf16 when w_is_bf16 -- the opt-in bf16 storage of the training step's per-edge tensors) */
+int matten_tp_paths(const float* x, int64_t d_in, const void* w_edge, int64_t w_pad, const float* sh_sorted,
                     int64_t sh_dim, const int32_t* rowptr, const int32_t* src_sorted, int64_t n_nodes,
                     const int32_t* path_entries, const int32_t* unit_start, int64_t n_entries,
                     int64_t units_per_tile, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
-                    float* agg /*[N,d_mid]*/, matten_stream_t stream);
+                    float* agg /*[N,d_mid]*/, int w_is_bf16, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Same operator again, production kernel v3: one wave per (input irrep block, l2 group, node
@@ -355,12 +356,13 @@ int matten_dense_rows(const float* x, int64_t n_in, const float* q, int64_t n_ou
  *   in_ptr[n_in+1] / in_cols[n_cols] (both or neither): the weight columns grouped by the input channel (x_base) they
  *   read.  With them a thread owns (edge, input channel) and adds its paths' contributions to dx in registers: one
  *   atomic per (edge, channel, component) instead of one per path; without, one thread per (edge, column). */
-int matten_tp_backward(const float* x, int64_t d_in, const float* w_edge, int64_t w_ld, const float* sh_sorted,
+int matten_tp_backward(const float* x, int64_t d_in, const void* w_edge, int64_t w_ld, const float* sh_sorted,
                        int64_t sh_stride, const int32_t* src_sorted, const int32_t* dst_sorted,
                        const int32_t* col_meta, int64_t n_cols, const uint8_t* nnz_ijk, const float* nnz_c,
                        const float* g_agg, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
-                       int64_t n_edges, float* dx, float* dw, int64_t dw_ld, const int32_t* in_ptr,
-                       const int32_t* in_cols, int64_t n_in, matten_stream_t stream);
+                       int64_t n_edges, float* dx, void* dw, int64_t dw_ld, const int32_t* in_ptr,
+                       const int32_t* in_cols, int64_t n_in, int edge_is_bf16 /* w_edge AND dw are bf16 */,
+                       matten_stream_t stream);
 
 /* adjoint of matten_species_linear w.r.t. the packed weights (the adjoint w.r.t. x is matten_species_linear
  * itself with the transposed segment table and transposed packed weights):

@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -27,10 +27,11 @@ SIGNATURES = {
     "matten_group_by_key": (c_int, [P, c_int64, c_int64, P, P, P, c_size_t, P, P]),
     "matten_species_embed": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_int64, P, P, P, P, P, P]),
     "matten_edge_geom": (c_int, [P, P, P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_float, c_float, P, P, c_int, P, P, P, P, P]),
-    "matten_radial_mlp": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, P, c_int, c_int, c_float, P, P]),
+    "matten_radial_mlp": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, P, c_int, c_int, c_float, P, c_int, P]),
     "matten_tp_scatter": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, P, c_int64, c_float, P, P, P]),
     "matten_tp_tile_nodes": (c_int, []),
-    "matten_tp_paths": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_float, P, P, P]),
+    "matten_tp_paths": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_float, P, P, c_int,
+                                P]),
     "matten_tp_blocks": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_float, P, P, P]),
     "matten_radial_hidden_multi": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, c_int, P, P, c_int, P]),
     "matten_agg_linear_max_mt": (c_int, []),
@@ -55,7 +56,7 @@ SIGNATURES = {
     "matten_radial_mlp_bwd": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, P, c_int, c_int, c_int, P, c_int64,
                                       c_int, P, P, P, P]),
     "matten_tp_backward": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, P, c_int64, P, P, P, c_int64, c_float, P, c_int64, P, P, c_int64,
-                                   P, P, c_int64, P]),
+                                   P, P, c_int64, c_int, P]),
     "matten_species_linear_wgrad": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
     "matten_gate_bwd": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, P, P]),
     "matten_bn_train_fwd": (c_int, [P, c_int64, c_int64, P, P, c_int64, P, P, c_float, P, P, P, P]),

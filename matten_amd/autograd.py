@@ -63,6 +63,21 @@ class SpeciesLinearFn(torch.autograd.Function):
         return dx, dwp, (g if ctx.has_add else None), None, None
 
 
+# Storage type of the two per-edge tensors of a training step, the radial weights w[E, W] and their gradient -- at
+# large batches the step's dominant memory traffic (BASELINE.json configs[3] names bf16 storage; the reference itself
+# is fp32 throughout, data/_dtype.py:3).  bf16 is opt-in (MATTEN_EDGE_STORAGE=bf16 or set_edge_storage_dtype): the MLP
+# kernel rounds w to bf16 on the store (nearest even), every kernel computes and accumulates in fp32, node features,
+# neighbour sums, BatchNorm statistics and all parameters stay fp32.
+EDGE_STORAGE_DTYPE = torch.bfloat16 if os.environ.get("MATTEN_EDGE_STORAGE", "fp32").lower() == "bf16" else torch.float32
+
+
+def set_edge_storage_dtype(dtype) -> None:
+    global EDGE_STORAGE_DTYPE
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("edge storage is fp32 or bf16")
+    EDGE_STORAGE_DTYPE = dtype
+
+
 class RadialMLPFn(torch.autograd.Function):
     """w[E, w_pad] = MLP(bessel(|edge|)) in the reference's weight-column order (pad columns zero); the adjoint maps
     dL/dw back to the three raw weight matrices (the packing is a per-layer scale and a row padding)."""
@@ -72,7 +87,8 @@ class RadialMLPFn(torch.autograd.Function):
         w0p, w1p, w2p = mod.pack_reference_order(w0, w1, w2)
         ctx.mod, ctx.rbf = mod, (int(n_basis), float(r_start), float(r_end))
         ctx.save_for_backward(geom_sorted, w0p, w1p, w2p)
-        return ops.radial_mlp(geom_sorted, int(n_basis), float(r_start), float(r_end), w0p, w1p, w2p)
+        return ops.radial_mlp(geom_sorted, int(n_basis), float(r_start), float(r_end), w0p, w1p, w2p,
+                              out_dtype=EDGE_STORAGE_DTYPE)
 
     @staticmethod
     def backward(ctx, g):

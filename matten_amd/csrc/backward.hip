@@ -18,13 +18,13 @@ namespace {
 // col_meta[W,4]  = {x_base, out_base, nnz_begin, nnz_count | y_off << 16}
 // nnz_ijk[nnz,4] = {i, j, k, 0} (uint8), nnz_c[nnz] = sqrt(2 l3+1) C_ijk
 // ------------------------------------------------------------------------------------------------
-__global__ void tp_backward_kernel(const float* __restrict__ x, int d_in, const float* __restrict__ w_edge, int w_ld,
+__global__ void tp_backward_kernel(const float* __restrict__ x, int d_in, const void* __restrict__ w_edge, int w_ld,
                                    const float* __restrict__ sh, int sh_stride, const int32_t* __restrict__ src_sorted,
                                    const int32_t* __restrict__ dst_sorted, const int4* __restrict__ col_meta, int W,
                                    const uchar4* __restrict__ nnz_ijk, const float* __restrict__ nnz_c,
                                    const float* __restrict__ g_agg, int d_mid, float avg_nn,
                                    const float* __restrict__ num_neigh, int64_t E, float* __restrict__ dx,
-                                   float* __restrict__ dw, int dw_ld) {
+                                   void* __restrict__ dw, int dw_ld, int edge_bf16) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= E * W) return;
     const int64_t e = idx / W;
@@ -36,7 +36,7 @@ __global__ void tp_backward_kernel(const float* __restrict__ x, int d_in, const 
     const float* xp = x + (int64_t)src * d_in + m.x;
     const float* yp = sh + e * sh_stride + y_off;
     const float* gp = g_agg + (int64_t)dst * d_mid + m.y;
-    const float wv = w_edge[e * w_ld + q];
+    const float wv = matten_ld_edge(w_edge, e * w_ld + q, edge_bf16);
     float* dxp = dx + (int64_t)src * d_in + m.x;
     const float s = wv * norm;
     // The non-zeros of a coupling are stored i-major (plan.py: np.nonzero order), so the terms of one input component
@@ -59,7 +59,7 @@ __global__ void tp_backward_kernel(const float* __restrict__ x, int d_in, const 
         dwv = fmaf(acc, xp[cur], dwv);
         if (acc != 0.0f) atomicAdd(dxp + cur, s * acc);
     }
-    dw[e * dw_ld + q] = dwv * norm;
+    matten_st_edge(dw, e * dw_ld + q, dwv * norm, edge_bf16);
 }
 
 // The same adjoint with the weight columns grouped by the INPUT channel they read (in_ptr / in_cols: columns of channel
@@ -67,7 +67,7 @@ __global__ void tp_backward_kernel(const float* __restrict__ x, int d_in, const 
 // their contributions to dx in registers, so the gather adjoint costs one atomic per (edge, channel, component)
 // instead of one per (edge, path, channel, component).  The atomics were most of the per-column kernel's time
 // (~120 M of them per layer at 290 k edges).
-__global__ void tp_backward_grouped_kernel(const float* __restrict__ x, int d_in, const float* __restrict__ w_edge, int w_ld,
+__global__ void tp_backward_grouped_kernel(const float* __restrict__ x, int d_in, const void* __restrict__ w_edge, int w_ld,
                                            const float* __restrict__ sh, int sh_stride,
                                            const int32_t* __restrict__ src_sorted, const int32_t* __restrict__ dst_sorted,
                                            const int4* __restrict__ col_meta, const int32_t* __restrict__ in_ptr,
@@ -75,7 +75,7 @@ __global__ void tp_backward_grouped_kernel(const float* __restrict__ x, int d_in
                                            const uchar4* __restrict__ nnz_ijk, const float* __restrict__ nnz_c,
                                            const float* __restrict__ g_agg, int d_mid, float avg_nn,
                                            const float* __restrict__ num_neigh, int64_t E, float* __restrict__ dx,
-                                           float* __restrict__ dw, int dw_ld) {
+                                           void* __restrict__ dw, int dw_ld, int edge_bf16) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= E * n_in) return;
     const int64_t e = idx / n_in;
@@ -97,7 +97,7 @@ __global__ void tp_backward_grouped_kernel(const float* __restrict__ x, int d_in
         const float* xp = x + (int64_t)src * d_in + m.x;
         const float* yp = yrow + (m.w >> 16);
         const float* gp = grow + m.y;
-        const float wv = w_edge[e * w_ld + q];
+        const float wv = matten_ld_edge(w_edge, e * w_ld + q, edge_bf16);
         float dwv = 0.0f, acc = 0.0f;
         int cur = cnt > 0 ? (int)nnz_ijk[m.z].x : 0;
         for (int t = 0; t <= cnt; ++t) {   // one extra round flushes the last component
@@ -114,7 +114,7 @@ __global__ void tp_backward_grouped_kernel(const float* __restrict__ x, int d_in
             }
             if (more) acc = fmaf(nnz_c[m.z + t] * yp[ijk.y], gp[ijk.z], acc);
         }
-        dw[e * dw_ld + q] = dwv * norm;
+        matten_st_edge(dw, e * dw_ld + q, dwv * norm, edge_bf16);
     }
     if (c1 > c0) {
         float* dxp = dx + (int64_t)src * d_in + x_base;
@@ -336,12 +336,12 @@ __global__ void segment_reduce_bwd_kernel(const float* __restrict__ dy, int dim,
 
 }  // namespace
 
-extern "C" int matten_tp_backward(const float* x, int64_t d_in, const float* w_edge, int64_t w_ld, const float* sh_sorted,
+extern "C" int matten_tp_backward(const float* x, int64_t d_in, const void* w_edge, int64_t w_ld, const float* sh_sorted,
                                   int64_t sh_stride, const int32_t* src_sorted, const int32_t* dst_sorted,
                                   const int32_t* col_meta, int64_t n_cols, const uint8_t* nnz_ijk, const float* nnz_c,
                                   const float* g_agg, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
-                                  int64_t n_edges, float* dx /*zero-initialised [N,d_in]*/, float* dw, int64_t dw_ld,
-                                  const int32_t* in_ptr, const int32_t* in_cols, int64_t n_in,
+                                  int64_t n_edges, float* dx /*zero-initialised [N,d_in]*/, void* dw, int64_t dw_ld,
+                                  const int32_t* in_ptr, const int32_t* in_cols, int64_t n_in, int edge_is_bf16,
                                   matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || d_in <= 0 || n_cols <= 0 || d_mid <= 0 || w_ld < n_cols || dw_ld < n_cols) return MATTEN_EINVAL;
@@ -356,7 +356,7 @@ extern "C" int matten_tp_backward(const float* x, int64_t d_in, const float* w_e
         tp_backward_grouped_kernel<<<(unsigned)matten_cdiv(n_edges * n_in, T), T, 0, stream>>>(
             x, (int)d_in, w_edge, (int)w_ld, sh_sorted, (int)sh_stride, src_sorted, dst_sorted, (const int4*)col_meta,
             in_ptr, in_cols, (int)n_in, (const uchar4*)nnz_ijk, nnz_c, g_agg, (int)d_mid, avg_num_neighbors, num_neigh,
-            n_edges, dx, dw, (int)dw_ld);
+            n_edges, dx, dw, (int)dw_ld, edge_is_bf16);
         MATTEN_LAUNCH_CHECK();
         return MATTEN_OK;
     }
@@ -364,7 +364,7 @@ extern "C" int matten_tp_backward(const float* x, int64_t d_in, const float* w_e
     tp_backward_kernel<<<(unsigned)matten_cdiv(n_edges * n_cols, T), T, 0, stream>>>(
         x, (int)d_in, w_edge, (int)w_ld, sh_sorted, (int)sh_stride, src_sorted, dst_sorted, (const int4*)col_meta,
         (int)n_cols, (const uchar4*)nnz_ijk, nnz_c, g_agg, (int)d_mid, avg_num_neighbors, num_neigh, n_edges, dx, dw,
-        (int)dw_ld);
+        (int)dw_ld, edge_is_bf16);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

@@ -29,7 +29,7 @@ template <int KS0, int NT>  // number of k-steps of the first layer: nb_pad / 4;
 __global__ __launch_bounds__(WAVES * 64) void radial_mlp_kernel(
     const float4* __restrict__ geom, int64_t E, int n_basis, float r_start, float r_end,
     const float* __restrict__ w0p, const float* __restrict__ w1p, const float* __restrict__ w2p, int w_pad,
-    float* __restrict__ w_edge) {
+    void* __restrict__ w_edge, int out_bf16) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -105,7 +105,17 @@ __global__ __launch_bounds__(WAVES * 64) void radial_mlp_kernel(
             for (int kk = 0; kk < 8; ++kk)
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], h[nt][kk >> 2][kk & 3], acc, 0, 0, 0);
             int64_t e = e0 + nt * 16 + c;
-            if (e < E) *(f32x4*)(w_edge + e * w_pad + mt * 16 + 4 * g) = acc;
+            if (e < E) {
+                const int64_t o = e * w_pad + mt * 16 + 4 * g;
+                if (out_bf16) {   // opt-in bf16 storage of the per-edge weights (training): 8 bytes per lane
+                    uint2 pk;
+                    pk.x = (uint32_t)matten_f32_to_bf16(acc[0]) | ((uint32_t)matten_f32_to_bf16(acc[1]) << 16);
+                    pk.y = (uint32_t)matten_f32_to_bf16(acc[2]) | ((uint32_t)matten_f32_to_bf16(acc[3]) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(w_edge) + o) = pk;
+                } else {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(w_edge) + o) = acc;
+                }
+            }
         }
     }
 }
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(WAVES * 64) void radial_mlp_kernel(
 
 extern "C" int matten_radial_mlp(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                                  const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden,
-                                 int w_pad, float act_cst, float* w_edge, matten_stream_t stream_) {
+                                 int w_pad, float act_cst, void* w_edge, int out_is_bf16, matten_stream_t stream_) {
     (void)act_cst;  // folded into w1p / w2p by the host-side prepack
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || hidden != HID || (w_pad & 15) || w_pad <= 0 || (nb_pad & 3) || nb_pad < n_basis || nb_pad > 16)
@@ -123,7 +133,7 @@ extern "C" int matten_radial_mlp(const float* geom_sorted, int64_t n_edges, int 
     if (!geom_sorted || !w0p || !w1p || !w2p || !w_edge) return MATTEN_EINVAL;
 #define LAUNCH(K, NTT)                                                                                               \
     radial_mlp_kernel<K, NTT><<<(unsigned)matten_cdiv(n_edges, WAVES * NTT * 16), WAVES * 64, 0, stream>>>(           \
-        (const float4*)geom_sorted, n_edges, n_basis, r_start, r_end, w0p, w1p, w2p, w_pad, w_edge)
+        (const float4*)geom_sorted, n_edges, n_basis, r_start, r_end, w0p, w1p, w2p, w_pad, w_edge, out_is_bf16)
 #define LAUNCH_K(NTT)                     \
     switch (nb_pad >> 2) {                \
         case 1: LAUNCH(1, NTT); break;    \

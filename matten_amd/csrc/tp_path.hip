@@ -35,7 +35,7 @@ struct PathEntry {  // 8 x int32, built by matten_amd/plan.py
 
 struct Args {
     const float* x;
-    const float* w_edge;
+    const void* w_edge;   // fp32, or bf16 when w_bf16
     const float* sh;
     const int* rowptr;
     const int* src_sorted;
@@ -43,6 +43,7 @@ struct Args {
     float* agg;
     int d_in, w_pad, sh_dim, d_mid, n_nodes;
     float avg_nn;
+    int w_bf16;
 };
 
 template <int L1, int L2, int L3>
@@ -53,13 +54,13 @@ __device__ __forceinline__ void run_path(const Args& a, const PathEntry& pe, int
 #pragma unroll
     for (int k = 0; k < D3; ++k) acc[k] = 0.0f;
 
-    const float* wcol = a.w_edge + pe.w_off + u;
+    const int wcol = pe.w_off + u;
     const int xcol = pe.x_off + u * D1;
     for (int s = 0; s < maxdeg; ++s) {
         if (s < deg) {
             const int e = beg + s;
             const int src = a.src_sorted[e];
-            const float w = wcol[(int64_t)e * a.w_pad];
+            const float w = matten_ld_edge(a.w_edge, (int64_t)e * a.w_pad + wcol, a.w_bf16);
             const float* xp = a.x + (int64_t)src * a.d_in + xcol;
             const float* yp = a.sh + (int64_t)e * a.sh_dim + L2 * L2;
             float xw[D1], y[D2];
@@ -145,11 +146,12 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void tp_path_kernel(Args a, c
 
 }  // namespace
 
-extern "C" int matten_tp_paths(const float* x, int64_t d_in, const float* w_edge, int64_t w_pad,
+extern "C" int matten_tp_paths(const float* x, int64_t d_in, const void* w_edge, int64_t w_pad,
                                const float* sh_sorted, int64_t sh_dim, const int32_t* rowptr,
                                const int32_t* src_sorted, int64_t n_nodes, const int32_t* path_entries,
                                const int32_t* unit_start, int64_t n_entries, int64_t units_per_tile, int64_t d_mid,
-                               float avg_num_neighbors, const float* num_neigh, float* agg, matten_stream_t stream_) {
+                               float avg_num_neighbors, const float* num_neigh, float* agg, int w_is_bf16,
+                               matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_nodes < 0 || d_in <= 0 || w_pad <= 0 || sh_dim <= 0 || sh_dim > 32 || n_entries <= 0 || units_per_tile <= 0 ||
         d_mid <= 0)
@@ -159,7 +161,7 @@ extern "C" int matten_tp_paths(const float* x, int64_t d_in, const float* w_edge
         return MATTEN_EINVAL;
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
     Args a{x, w_edge, sh_sorted, rowptr, src_sorted, num_neigh, agg, (int)d_in, (int)w_pad, (int)sh_dim, (int)d_mid,
-           (int)n_nodes, avg_num_neighbors};
+           (int)n_nodes, avg_num_neighbors, w_is_bf16};
     const int n_tiles = (int)matten_cdiv(n_nodes, TILE_NODES);
     const int blocks_per_tile = (int)matten_cdiv(units_per_tile, WAVES_PER_BLOCK);
     const int64_t grid = matten_cdiv(n_tiles, N_XCD) * N_XCD * (int64_t)blocks_per_tile;

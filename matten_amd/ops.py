@@ -188,17 +188,26 @@ def edge_geom(pos, edge_index, edge_cell_shift, cell, batch, perm, lmax: int, n_
     return out
 
 
-def radial_mlp(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p, w2p) -> torch.Tensor:
+def _edge_dtype(t: torch.Tensor, name: str) -> torch.Tensor:
+    """per-edge training tensors (radial weights, their gradient): fp32 or, opt-in, bf16 storage"""
+    if not isinstance(t, torch.Tensor) or t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"{name}: expected an fp32 or bf16 tensor")
+    return _need(t, t.dtype, name)
+
+
+def radial_mlp(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p, w2p, out_dtype=torch.float32) -> torch.Tensor:
     lib = _lib.load()
     geom_sorted = _need(geom_sorted, torch.float32, "geom_sorted")
     w0p, w1p, w2p = (_need(w, torch.float32, n) for w, n in ((w0p, "w0p"), (w1p, "w1p"), (w2p, "w2p")))
     E = geom_sorted.shape[0]
     nb_pad, hidden = w0p.shape
     w_pad = w2p.shape[1]
-    out = torch.empty(E, w_pad, dtype=torch.float32, device=geom_sorted.device)
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("radial_mlp: out_dtype must be fp32 or bf16")
+    out = torch.empty(E, w_pad, dtype=out_dtype, device=geom_sorted.device)
     with _timed(f"radial_mlp/w_pad={w_pad}"):
         rc = lib.matten_radial_mlp(_ptr(geom_sorted), E, n_basis, r_start, r_end, _ptr(w0p), nb_pad, _ptr(w1p),
-                                   _ptr(w2p), hidden, w_pad, 1.0, _ptr(out), _stream())
+                                   _ptr(w2p), hidden, w_pad, 1.0, _ptr(out), int(out_dtype == torch.bfloat16), _stream())
     _lib.check(rc, "matten_radial_mlp")
     return out
 
@@ -261,7 +270,7 @@ def tp_paths(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, unit
     if lib.matten_tp_tile_nodes() != TP_TILE_NODES:
         raise _lib.MattenHipError("plan.TP_TILE_NODES does not match the library's node tile")
     x = _need(x, torch.float32, "node_features")
-    w_edge = _need(w_edge, torch.float32, "w_edge")
+    w_edge = _edge_dtype(w_edge, "w_edge")
     sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
     N, d_in = x.shape
     if num_neigh is not None:
@@ -271,7 +280,7 @@ def tp_paths(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, unit
         rc = lib.matten_tp_paths(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
                                  _ptr(rowptr), _ptr(src_sorted), N, _ptr(entries), _ptr(unit_start),
                                  entries.shape[0], units_per_tile, d_mid, float(avg_num_neighbors or 0.0),
-                                 _ptr(num_neigh), _ptr(agg), _stream())
+                                 _ptr(num_neigh), _ptr(agg), int(w_edge.dtype == torch.bfloat16), _stream())
     _lib.check(rc, "matten_tp_paths")
     return agg
 
@@ -555,13 +564,13 @@ def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk,
     in_groups: optional (in_ptr [n_in+1] i32, in_cols [W] i32) = the columns grouped by input channel (plan.bw_in_*)."""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
-    w_edge = _need(w_edge, torch.float32, "w_edge")
+    w_edge = _edge_dtype(w_edge, "w_edge")
     g_agg = _need(g_agg, torch.float32, "grad agg")
     N, d_in = x.shape
     E = w_edge.shape[0]
     W = col_meta.shape[0]
     dx = torch.zeros(N, d_in, dtype=torch.float32, device=x.device)
-    dw = torch.empty(E, w_edge.shape[1], dtype=torch.float32, device=x.device)   # same row stride as w_edge
+    dw = torch.empty(E, w_edge.shape[1], dtype=w_edge.dtype, device=x.device)   # same row stride and storage as w_edge
     if num_neigh is not None:
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
     with _timed(f"tp_backward/d_mid={g_agg.shape[1]}/d_in={d_in}"):
@@ -570,7 +579,8 @@ def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk,
                                     _ptr(g_agg), g_agg.shape[1], float(avg_num_neighbors or 0.0), _ptr(num_neigh), E,
                                     _ptr(dx), _ptr(dw), dw.shape[1], _ptr(in_groups[0]) if in_groups else None,
                                     _ptr(in_groups[1]) if in_groups else None,
-                                    in_groups[0].shape[0] - 1 if in_groups else 0, _stream())
+                                    in_groups[0].shape[0] - 1 if in_groups else 0,
+                                    int(w_edge.dtype == torch.bfloat16), _stream())
     _lib.check(rc, "matten_tp_backward")
     return dx, dw
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
     assert lib.matten_tp_tile_nodes() == TP_TILE_NODES
     # host-detectable argument errors are reported without touching a GPU
-    assert lib.matten_radial_mlp(None, -1, 8, 0.0, 5.0, None, 8, None, None, 32, 848, 1.0, None, None) == -1
+    assert lib.matten_radial_mlp(None, -1, 8, 0.0, 5.0, None, 8, None, None, 32, 848, 1.0, None, 0, None) == -1
     assert lib.matten_species_linear(None, 0, None, None, 1, None, 0, None, 0, 0, None, 0, 1, None, None) == -1
 
 
