@@ -257,13 +257,56 @@ def extras(dev):
     m_g, opt_g = make()
     gs = GraphedTrainStep(m_g, opt_g, loss_fn, tb, target, warmup=3)
     t_g, _ = timed(lambda: gs.step(tb, target), 5, 30)
+    # the same step with this package's flat-buffer Adam (one launch for all parameters) instead of torch's fused one
+    from matten_amd.optim import FlatAdam
+    torch.manual_seed(3)
+    m_f = ScalarTensorModel(backbone_hparams=dict(lmax2), dataset_hparams=ds4).to(dev).train()
+    gf = GraphedTrainStep(m_f, FlatAdam(m_f.parameters(), lr=1e-2, weight_decay=1e-5), loss_fn, tb, target, warmup=3)
+    t_f, _ = timed(lambda: gf.step(tb, target), 5, 30)
+    del m_f, gf
+    # the same step with the per-edge tensors (radial weights, their gradient) stored as bf16 (fp32 arithmetic)
+    from matten_amd import autograd as _ag
+    _ag.set_edge_storage_dtype(torch.bfloat16)
+    try:
+        m_b, opt_b = make()
+        gb = GraphedTrainStep(m_b, opt_b, loss_fn, tb, target, warmup=3)
+        t_b, _ = timed(lambda: gb.step(tb, target), 5, 30)
+        del m_b, opt_b, gb
+    finally:
+        _ag.set_edge_storage_dtype(torch.float32)
+    # a large batch of the same set (2048 crystals: the n100 sample tiled), where the step is kernel-bound
+    BL = 2048
+    tbl = collate([graphs[i % len(graphs)] for i in range(BL)], device=dev)
+    target_l = torch.randn(BL, 21, device=dev)
+    m_l, opt_l = make()
+
+    def large_step():
+        loss = loss_fn(m_l(dict(tbl))[0], target_l)
+        opt_l.zero_grad()
+        loss.backward()
+        opt_l.step()
+        return loss
+
+    t_l, _ = timed(large_step, 3, 10)
+    El = int(tbl["edge_index"].shape[1])
+    del m_l, opt_l, tbl
     Et, Nt = int(tb["edge_index"].shape[1]), int(tb["pos"].shape[0])
     rec = {
         "crystals": BS, "atoms": Nt, "edges": Et, "dtype": "f32 (the reference's dtype; bf16 storage: see 'bf16')",
+        "library_gemms_on_the_step": 0,
         "ms_per_step_eager": 1e3 * t_e, "ms_per_step_hipgraph": 1e3 * t_g, "crystals_per_sec_hipgraph": BS / t_g,
+        "ms_per_step_hipgraph_flat_adam": 1e3 * t_f,
+        "optimizer": "torch.optim.Adam(fused, capturable) for the eager / hipgraph lines; matten_amd.optim.FlatAdam (own "
+                     "kernel over one flat buffer) for ms_per_step_hipgraph_flat_adam",
+        "bf16": {"ms_per_step_hipgraph": 1e3 * t_b,
+                 "what": "opt-in bf16 STORAGE of the per-edge tensors (radial weights w[E,W] and dL/dw), fp32 arithmetic, "
+                         "node features / BatchNorm statistics / parameters fp32 (MATTEN_EDGE_STORAGE=bf16)"},
+        "batch2048": {"crystals": BL, "edges": El, "ms_per_step_eager": 1e3 * t_l, "crystals_per_sec": BL / t_l,
+                      "dtype": "f32", "data": "the n100 sample tiled to 2048 crystals"},
         "data": "synthetic-Zenodo-like (first 32 crystals of the reference's n100 example, random targets)",
         "note": "with l <= 2 features the 4e output has no path: 9 of the 21 components are identically 0 (SURVEY 8d)",
-        "kernel_ms_per_launch_eager": {k: v for k, v in ev.items() if k.startswith(("tp_backward", "tp_scatter", "tp_train"))},
+        "kernel_ms_per_launch_eager": {k: v for k, v in ev.items()
+                                       if k.startswith(("tp_backward", "tp_scatter", "radial_mlp"))},
     }
     # roofline of the step's dominant kernel, the tensor-product adjoint: contract bytes per (edge, layer) of the
     # two-kernel architecture = ids 8 + vector 12 + w read 4W + dw written 4W + (x and dx rows: 2 d_in, grad rows: d_mid) / deg

@@ -364,6 +364,11 @@ int matten_tp_backward(const float* x, int64_t d_in, const void* w_edge, int64_t
                        const int32_t* in_cols, int64_t n_in, int edge_is_bf16 /* w_edge AND dw are bf16 */,
                        matten_stream_t stream);
 
+/* Adam (torch.optim.Adam semantics, amsgrad off, L2 weight decay added to the gradient) over ONE flat fp32 buffer of n
+ * elements; step[0] (device) = the number of this step, already incremented by the caller; buffers 16-byte aligned. */
+int matten_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* step,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, matten_stream_t stream);
+
 /* adjoint of matten_species_linear w.r.t. the packed weights (the adjoint w.r.t. x is matten_species_linear
  * itself with the transposed segment table and transposed packed weights):
  *   dWp[s, w_off + u*mo + w] = sum_{rows n of species s} sum_k x[n, x_off+u*d+k] dy[n, o_off+w*d+k] */

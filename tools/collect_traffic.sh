@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${TAG}_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${TAG}_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
 done
 python3 - <<PY
 import csv, json, collections, re
@@ -34,8 +34,13 @@ doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
                  "section HBM); KB -> bytes x1024; 'per_launch' = largest launch (last conv layer), 'mean_launch' = "
                  "average over all launches of the kernel in a forward",
        "tag": TAG, "kernels": out}
+try:
+    import subprocess
+    doc["commit"] = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    pass
 json.dump(doc, open(f"{R}/gpurun_out/traffic_{TAG}.json", "w"), indent=1)
 for k, v in out.items():
-    if any(s in k for s in ("tp_", "radial", "species_linear")):
+    if any(s in k for s in ("tp_", "radial", "species_linear", "agg_linear")):
         print(k, v)
 PY

@@ -2,7 +2,7 @@
 # kernel-level profile of the default bench: prints the per-kernel stats table
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$GRAFT_REPO_ROOT/gpurun_out/prof"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-extras > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.log" 2>&1
 tail -1 "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.log"
 f=$(find "$GRAFT_REPO_ROOT/gpurun_out/prof" -name "*kernel_stats.csv" | head -1)
 cp "$f" "$GRAFT_REPO_ROOT/gpurun_out/kernel_stats.csv"
