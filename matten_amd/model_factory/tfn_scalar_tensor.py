@@ -161,6 +161,22 @@ class ScalarTensorModel(BaseModel):
             return {getattr(t, "name", t): (TensorRegressionTask(name=t) if isinstance(t, str) else t) for t in tasks}
         return {tasks.name: tasks}
 
+    # --- input validation mode of the species embedding (the forward's one host synchronisation) ----
+    def set_input_checks(self, mode) -> None:
+        """True: every forward waits for its own species / edge_index range check (the reference's behaviour: the error
+        comes from the offending call).  "deferred": checked one forward later or at finish_input_checks(), no host
+        wait inside a loop of forwards.  False: unchecked (the kernels clamp: memory-safe, result meaningless)."""
+        for m in self.modules():
+            if hasattr(m, "check_species"):
+                if hasattr(m, "finish_checks"):
+                    m.finish_checks()
+                m.check_species = mode
+
+    def finish_input_checks(self) -> None:
+        for m in self.modules():
+            if hasattr(m, "finish_checks"):
+                m.finish_checks()
+
     # --- reference: ModelForPyGData.preprocess_batch, model/model.py:493-518 --------------------
     def preprocess_batch(self, batch):
         if hasattr(batch, "to") and not isinstance(batch, dict):

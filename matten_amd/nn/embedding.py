@@ -97,18 +97,29 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
         )
         self.linear = torch.nn.Linear(self.num_species, embedding_dim)
 
+    def finish_checks(self) -> None:
+        """check_species == "deferred": wait for and evaluate the validation flags of the most recent forward"""
+        pending, self._pending = getattr(self, "_pending", None), None
+        if pending is None:
+            return
+        ev, host, Z, n_nodes = pending
+        ev.synchronize()
+        self._raise_for(host.tolist(), Z, n_nodes)
+
+    def _raise_for(self, flags, Z, n_nodes) -> None:
+        if flags[0]:
+            self.atomic_number_to_index.raise_for_flags(flags[0], Z)
+        if flags[1] & 1:
+            rng = f"[0, {n_nodes})" if n_nodes is not None else "the batch's node range"
+            raise IndexError(f"edge_index holds node ids outside {rng} (a malformed batch)")
+
     def raise_for_last_flags(self, n_nodes=None) -> None:
         """host sync: read the validation flags of the most recent forward and raise what the reference would have
         (unknown species: RuntimeError / ValueError of _AtomicNumberToIndex; edge_index out of range: IndexError)"""
         flags_dev = getattr(self, "_last_flags", None)
         if flags_dev is None:
             return
-        flags = flags_dev.tolist()
-        if flags[0]:
-            self.atomic_number_to_index.raise_for_flags(flags[0], self._last_Z)
-        if flags[1] & 1:
-            rng = f"[0, {n_nodes})" if n_nodes is not None else "the batch's node range"
-            raise IndexError(f"edge_index holds node ids outside {rng} (a malformed batch)")
+        self._raise_for(flags_dev.tolist(), self._last_Z, n_nodes)
 
     def forward(self, data: DataKey.Type) -> DataKey.Type:
         a2i = self.atomic_number_to_index
@@ -145,8 +156,20 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
         # kept for a deferred check (matten_amd.graphs: inside a captured graph this is a static tensor every replay
         # rewrites, read on request after the replay)
         self._last_flags, self._last_Z = flags_dev, Z
-        if self.check_species:
-            self.raise_for_last_flags(data[DataKey.POSITIONS].shape[0] if DataKey.POSITIONS in data else None)
+        n_nodes = data[DataKey.POSITIONS].shape[0] if DataKey.POSITIONS in data else None
+        if self.check_species == "deferred":
+            # Pipelined validation: the flags of THIS forward travel to pinned host memory behind an event and are read
+            # when the NEXT forward (or finish_checks()) comes by -- the host never waits for the device it has just
+            # fed, so a loop of forwards runs without the launch gaps the immediate check leaves behind its sync.
+            # A malformed batch therefore raises one forward late (the kernels clamp: nothing unsafe happens meanwhile).
+            self.finish_checks()
+            host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+            host.copy_(flags_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(Z.device))
+            self._pending = (ev, host, Z, n_nodes)
+        elif self.check_species:
+            self.raise_for_last_flags(n_nodes)
         if not provided:
             data[DataKey.SPECIES_INDEX] = sidx
         data[DataKey.AMD_SPECIES] = (order, seg)

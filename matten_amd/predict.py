@@ -186,6 +186,20 @@ def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
 
     chunks = [np.arange(lo, min(B, lo + batch_size)) for lo in range(0, B, batch_size)]
     model.eval()
+    # the per-forward range checks are read one batch late (and all of them before the results leave): the host keeps
+    # building the next batch instead of waiting for the flags of the one it has just enqueued
+    modes = [(m, m.check_species) for m in model.modules() if hasattr(m, "check_species")]
+    if hasattr(model, "set_input_checks"):
+        model.set_input_checks("deferred")
+    try:
+        return _evaluate_soa_loop(model, chunks, build, main, side, out, edgeless, converter, tensor_target_name, device)
+    finally:
+        for m, mode in modes:
+            m._pending = None
+            m.check_species = mode
+
+
+def _evaluate_soa_loop(model, chunks, build, main, side, out, edgeless, converter, tensor_target_name, device):
     with torch.no_grad():
         nxt = build(chunks[0]) if chunks else None
         for k in range(len(chunks)):
@@ -203,6 +217,8 @@ def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
                 else:                                            # queued behind the forward would stall the host here)
                     out[torch.as_tensor(ids, device=device)] = p
             nxt = build(chunks[k + 1]) if k + 1 < len(chunks) else None  # overlaps the forward just enqueued
+    if hasattr(model, "finish_input_checks"):
+        model.finish_input_checks()
     return out.cpu().numpy(), sorted(edgeless)
 
 

@@ -945,3 +945,35 @@ def test_debug_mode_catches_nan_on_device():
         bad["pos"][3, 1] = float("nan")
         with pytest.raises(ValueError, match="Anomaly detected for pos of one_hot"):
             model(bad)
+
+
+def test_deferred_input_checks_raise_one_forward_late():
+    """model.set_input_checks("deferred"): the species / edge_index flags of a forward are read when the next forward is
+    enqueued (or at finish_input_checks()), so loops run without a host wait; results are unchanged and a malformed
+    batch still raises the reference's errors, one call late."""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _fcc(2)
+    _, model = build_pair(PAPER, ds)
+    good = collate(graphs, device=DEV)
+    bad = dict(good)
+    bad["edge_index"] = good["edge_index"].clone()
+    bad["edge_index"][1, 5] = good["pos"].shape[0] + 3
+    unknown = dict(good)
+    unknown["atomic_numbers"] = good["atomic_numbers"].clone()
+    unknown["atomic_numbers"][0] = 3          # lithium is not in the model's species list
+    with torch.no_grad():
+        want = model(dict(good))[0]["elastic_tensor_full"]
+        with pytest.raises(IndexError):
+            model(dict(bad))
+        model.set_input_checks("deferred")
+        assert torch.equal(model(dict(good))[0]["elastic_tensor_full"], want)
+        model(dict(bad))                                   # not yet
+        with pytest.raises(IndexError, match="edge_index holds node ids outside"):
+            model(dict(good))                              # ... now
+        model(dict(unknown))
+        with pytest.raises((RuntimeError, ValueError)):
+            model.finish_input_checks()
+        model.finish_input_checks()                        # nothing pending: no-op
+        model.set_input_checks(True)
+        assert torch.equal(model(dict(good))[0]["elastic_tensor_full"], want)
