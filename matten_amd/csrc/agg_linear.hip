@@ -182,7 +182,13 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
         const int c0 = __builtin_amdgcn_readfirstlane(d.chunk);
         const int n = __builtin_amdgcn_readfirstlane(d.info & 255);
 #pragma unroll
-        for (int i = 0; i < AL_BLK; ++i) buf[i] = *reinterpret_cast<const f32x4*>(rp + 16 * (c0 + min(i, n - 1)));
+        for (int i = 0; i < AL_BLK; ++i) {
+#ifdef AL_NT_LOADS   // the row is read exactly once: non-temporal hint (experiment, tools/agg_ab.sh)
+            buf[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 16 * (c0 + min(i, n - 1))));
+#else
+            buf[i] = *reinterpret_cast<const f32x4*>(rp + 16 * (c0 + min(i, n - 1)));
+#endif
+        }
     };
     // one block: request the next one, multiply this one, close / open units at its end
     auto step = [&](int j, const f32x4* __restrict__ cur, f32x4* __restrict__ nxt) {

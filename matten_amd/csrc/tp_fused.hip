@@ -461,10 +461,84 @@ __device__ __forceinline__ void run_loader_only(const Args& a, int cu_log2, floa
 
 // ---- what a unit does with its neighbour sums ------------------------------------------------------------------------
 // StoreAgg: one row slice of agg[N, d_mid] per (node, channel)  (the two-kernel conv: lin2 reads agg afterwards)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int STORE_PASS = 32;   // accumulators per pass of the vector epilogue (32 x 64 lanes = 2048 floats of the wave's tile)
+
 struct StoreAgg {
+    float* t;   // the wave's LDS tile (free once the walk is over), or nullptr: scalar stores only
+    // The epilogue as the walk leaves it is NACC (25-52) four-byte stores per lane: 5.6 M store instructions per launch in
+    // the last layer, and the vector-memory unit takes as long over a 4-byte-per-lane store as over a 16-byte one --
+    // 0.20 of that layer's 1.24 ms (same bytes as 16-byte stores: 0.04; tools/fused_ablate.sh, TPF_ABL_X4_STORES).  In the
+    // component-major row the channels of one (coupling, component) are contiguous, so four neighbouring channel lanes
+    // exchange their accumulators through the LDS tile ([accumulator][lane]: conflict-free both ways) and each writes
+    // one accumulator of the group for all four channels: a quarter of the instructions (half for two-channel entries).
+    // MEASURED SLOWER (last layer 1.39 vs 1.28 ms, same box): what the stores cost is not the instruction count but
+    // the number of 32-byte segments they touch (35 M per launch), and this form touches the same ones; the ablation
+    // above wrote one contiguous 128-byte piece per node.  Kept behind -DTPF_VECTOR_EPILOGUE for the record.
+    template <class G, int V>
+    __device__ __forceinline__ void store_vec(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
+                                              float norm, int node, bool node_ok) const {
+        typedef float vec_t __attribute__((ext_vector_type(V)));
+        const int lane = threadIdx.x & 63;
+        const int jq = lane & (V - 1), lbase = lane & ~(V - 1);
+        const int u0 = lbase & ((1 << ge.cu_log2) - 1);          // first channel of the lane group
+        float* orow = a.agg + (int64_t)node * a.d_mid + u0;
+#pragma unroll
+        for (int p0 = 0; p0 < G::NACC; p0 += STORE_PASS) {
+            __builtin_amdgcn_wave_barrier();                     // the previous pass's reads are done
+#pragma unroll
+            for (int i = 0; i < STORE_PASS; ++i)
+                if (p0 + i < G::NACC) t[i * 64 + lane] = acc[p0 + i] * norm;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g0 = 0; g0 < STORE_PASS; g0 += V) {
+                if (p0 + g0 < G::NACC) {
+                    int off = 0;
+                    bool on = false;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        const int ai = p0 + g0 + i;              // compile-time after unrolling: so are cc and k below
+                        if (ai < G::NACC) {
+                            int cc = 0;
+#pragma unroll
+                            for (int c2 = 1; c2 < G::NC; ++c2)
+                                if (ai >= G::OFF[c2]) cc = c2;
+                            const int k = ai - G::OFF[cc];
+                            if (jq == i) {
+                                off = ge.out_off[cc] + k * ge.t_off[cc];
+                                on = (ge.mask >> cc) & 1u;
+                            }
+                        }
+                    }
+                    const vec_t v = *reinterpret_cast<const vec_t*>(t + (g0 + jq) * 64 + lbase);
+#ifdef MATTEN_ABLATE_NO_STORE
+                    if (node_ok && on && v[0] == 12345.678f)
+#else
+                    if (node_ok && on)
+#endif
+                        *reinterpret_cast<vec_t*>(orow + off) = v;
+                }
+            }
+        }
+    }
+
     template <class G>
     __device__ __forceinline__ void store(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
                                           float a_scale_inv, int node, int j, int u, bool valid) const {
+        const int cu = 1 << ge.cu_log2;
+#ifdef TPF_VECTOR_EPILOGUE   // measured slower with the component-major row (see store_vec): off by default
+        // wave-uniform: component-major row (the stride of the entry's first coupling says so), every channel lane of a
+        // node in use, room for a pass in the tile
+        if (t != nullptr && ge.t_off[__builtin_ctz(ge.mask | 0x80000000u) % MAXC] != 0 && ge.mul == cu && cu >= 2 &&
+            a.lds_per_wave >= 64 * STORE_PASS) {
+            float norm = 0.0f;   // mul == cu: `valid` is a per-node condition here (lanes of nodes past the end store nothing)
+            if (valid) norm = a_scale_inv / sqrtf(a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node]);
+            if (cu >= 4) store_vec<G, 4>(a, ge, acc, norm, node, valid);
+            else store_vec<G, 2>(a, ge, acc, norm, node, valid);
+            return;
+        }
+#endif
 #ifdef MATTEN_ABLATE_NO_STORE
         if (valid && acc[0] == 12345.678f) {
 #else
@@ -484,7 +558,13 @@ struct StoreAgg {
                     const int kstep = ks ? ks : 1;
 #pragma unroll
                     for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
-                        if (k < d3) op[k * kstep] = acc[G::OFF[cc] + k] * norm;
+                        if (k < d3) {
+#ifdef TPF_NT_STORES   // agg is written once and read once by another kernel: non-temporal hint (experiment: slower)
+                            __builtin_nontemporal_store(acc[G::OFF[cc] + k] * norm, op + k * kstep);
+#else
+                            op[k * kstep] = acc[G::OFF[cc] + k] * norm;
+#endif
+                        }
                 }
             }
         }
@@ -735,7 +815,7 @@ template <int L1, int GI> struct HotMask { static constexpr unsigned M0 = 0, M1 
 #ifndef TPF_NO_HOT_MASKS
 template <> struct HotMask<0, 0> { static constexpr unsigned M0 = 0x1f, M1 = 0xf; };
 #endif
-#define MATTEN_RGS_ARGS a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}
+#define MATTEN_RGS_ARGS a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{tile}
 #define MATTEN_RGS(L1, GI, TT, TD, P) \
     do { \
         using HM = HotMask<L1, GI>; \
