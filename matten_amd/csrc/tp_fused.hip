@@ -480,8 +480,14 @@ struct StoreAgg {
                                               float norm, int node, bool node_ok) const {
         typedef float vec_t __attribute__((ext_vector_type(V)));
         const int lane = threadIdx.x & 63;
-        const int jq = lane & (V - 1), lbase = lane & ~(V - 1);
-        const int u0 = lbase & ((1 << ge.cu_log2) - 1);          // first channel of the lane group
+        // Which piece a lane writes: the V accumulators of a group x the node's cu channels are cu lanes x V floats.
+        // Lane lu of the node takes accumulator lu / (cu / V) of the group and channels V (lu % (cu / V)) .. + V - 1, so that
+        // when the group's accumulators are adjacent in memory (entry-major rows) consecutive lanes write consecutive
+        // 16-byte pieces: one contiguous 4 cu-float block per node and instruction, which the memory pipeline takes as
+        // whole lines (lanes whose addresses interleave are not merged).
+        const int cu = 1 << ge.cu_log2, cq = cu / V;
+        const int lu = lane & (cu - 1), nbase = lane & ~(cu - 1);
+        const int jq = lu / cq, u0 = V * (lu - jq * cq), lbase = nbase + u0;
         float* orow = a.agg + (int64_t)node * a.d_mid + u0;
 #pragma unroll
         for (int p0 = 0; p0 < G::NACC; p0 += STORE_PASS) {
