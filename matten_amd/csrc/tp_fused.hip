@@ -466,15 +466,14 @@ constexpr int STORE_PASS = 32;   // accumulators per pass of the vector epilogue
 
 struct StoreAgg {
     float* t;   // the wave's LDS tile (free once the walk is over), or nullptr: scalar stores only
-    // The epilogue as the walk leaves it is NACC (25-52) four-byte stores per lane: 5.6 M store instructions per launch in
-    // the last layer, and the vector-memory unit takes as long over a 4-byte-per-lane store as over a 16-byte one --
-    // 0.20 of that layer's 1.24 ms (same bytes as 16-byte stores: 0.04; tools/fused_ablate.sh, TPF_ABL_X4_STORES).  In the
-    // component-major row the channels of one (coupling, component) are contiguous, so four neighbouring channel lanes
-    // exchange their accumulators through the LDS tile ([accumulator][lane]: conflict-free both ways) and each writes
-    // one accumulator of the group for all four channels: a quarter of the instructions (half for two-channel entries).
-    // MEASURED SLOWER (last layer 1.39 vs 1.28 ms, same box): what the stores cost is not the instruction count but
-    // the number of 32-byte segments they touch (35 M per launch), and this form touches the same ones; the ablation
-    // above wrote one contiguous 128-byte piece per node.  Kept behind -DTPF_VECTOR_EPILOGUE for the record.
+    // Experiment (-DTPF_VECTOR_EPILOGUE, off): the epilogue as the walk leaves it is NACC (25-52) four-byte stores per
+    // lane; here four neighbouring channel lanes exchange their accumulators through the LDS tile ([accumulator][lane])
+    // and each writes one accumulator of a group for four channels with a 16-byte store (8-byte for two-channel entries).
+    // Parity-green and SLOWER: last layer 1.38 vs 1.28 ms with the component-major row, 1.31 with an entry-major row
+    // (one contiguous 128-256-byte block per node and instruction).  The stores cost 0.20 of that layer's 1.25 ms
+    // (-DMATTEN_ABLATE_NO_STORE), but neither by instruction count nor by coalescing: an ablation that issued 16-byte
+    // stores into a fifth of the address range (overlapping rows) took 1.08 ms -- it is the 1.1 GB (1.6 GB at the L2
+    // boundary) of distinct bytes per launch that costs, in a kernel whose waves wait on memory 40 % of the time.
     template <class G, int V>
     __device__ __forceinline__ void store_vec(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
                                               float norm, int node, bool node_ok) const {
