@@ -73,14 +73,42 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
     AggIo* io_l = reinterpret_cast<AggIo*>(lds + a.w_stride);
     AggBlk* blk_l = reinterpret_cast<AggBlk*>(io_l + a.n_io);
     float* stage_all = reinterpret_cast<float*>(blk_l + a.n_blk);   // [AL_WAVES][16 rows][AL_STAGE_RS] + [AL_WAVES][16] row ids
-    // ---- which species, which 128 rows of it: workgroups are numbered species-major ----
-    int s = 0, blk = blockIdx.x, beg = 0, end = 0;
-    for (; s < a.n_species; ++s) {
-        beg = a.order ? a.seg[s] : 0;
-        end = a.order ? a.seg[s + 1] : a.n_rows;
-        const int nb = (end - beg + AL_WAVES * AL_ROWS - 1) / (AL_WAVES * AL_ROWS);
-        if (blk < nb) break;
-        blk -= nb;
+    // ---- which species, which AL_WAVES x 16 rows of it: workgroups are numbered species-major.  The per-species offsets
+    // are fetched by all threads at once and scanned from LDS by one: a chain of dependent global loads (one per
+    // species) cost a small batch with 73 species more than its whole stream.
+    int s = 0, blk = blockIdx.x, beg = 0, end = a.n_rows;
+    if (a.order) {
+        int* sseg = reinterpret_cast<int*>(stage_all);                 // free until the walk starts
+        const int cap = AL_WAVES * (16 * AL_STAGE_RS + 16) - 4;
+        if (a.n_species + 1 <= cap) {
+            for (int i = threadIdx.x; i <= a.n_species; i += AL_WAVES * 64) sseg[i] = a.seg[i];
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int b = blk, sp = 0;
+                for (; sp < a.n_species; ++sp) {
+                    const int nb = (sseg[sp + 1] - sseg[sp] + AL_WAVES * AL_ROWS - 1) / (AL_WAVES * AL_ROWS);
+                    if (b < nb) break;
+                    b -= nb;
+                }
+                sseg[cap] = sp;
+                sseg[cap + 1] = b;
+            }
+            __syncthreads();
+            s = sseg[cap];
+            blk = sseg[cap + 1];
+            if (s < a.n_species) beg = sseg[s], end = sseg[s + 1];
+            __syncthreads();                                           // the region becomes the output stage again
+        } else {
+            for (; s < a.n_species; ++s) {
+                beg = a.seg[s];
+                end = a.seg[s + 1];
+                const int nb = (end - beg + AL_WAVES * AL_ROWS - 1) / (AL_WAVES * AL_ROWS);
+                if (blk < nb) break;
+                blk -= nb;
+            }
+        }
+    } else if (blk >= (a.n_rows + AL_WAVES * AL_ROWS - 1) / (AL_WAVES * AL_ROWS)) {
+        s = a.n_species;
     }
     if (s >= a.n_species) return;
     {   // the species' A fragments and the two work tables -> LDS

@@ -663,3 +663,76 @@ def test_reference_training_script_call_sequence_under_the_matten_alias(golden_d
     model.update_metrics(preds, labels, "val")
     model.on_validation_epoch_end()
     assert abs(float(model.logged["val/score"]) - 0.5) < 1e-6   # mean absolute error = the monitored score
+
+
+def test_agg_linear_plan_reproduces_lin2_on_the_host():
+    """plan.plan_agg_linear is a contract between two kernels: matten_tp_fused writes the neighbour sums component-major
+    through the group entries' (first float, component stride) pairs, matten_agg_linear walks the row by the block list
+    and multiplies with A fragments gathered from the flat lin2 weight.  Emulated here in numpy, table by table, against
+    the oracle's FullyConnectedTensorProduct(agg_mul_ir, one_hot(species)): every channel of every path lands in exactly
+    one slot, pad slots are never read as data, wide irreps split into table rows add up, the fragment layout matches the
+    kernel's operand indexing."""
+    from common import PAPER
+    from matten_amd import plan as mplan
+    from matten_amd.model_factory.tfn_scalar_tensor import create_model
+    from oracle.e3nn_lite import o3 as ro3
+
+    S = 3
+    model = create_model(dict(PAPER), {"allowed_species": [13, 29, 79], "average_num_neighbors": 18.0})
+    convs = [m for m in model.modules() if type(m).__name__ == "PointConv"]
+    rng = np.random.default_rng(0)
+    for conv in (convs[1], convs[3]):
+        uvu, lp = conv.tp.plan, conv.lin2.plan
+        ap = mplan.plan_agg_linear(uvu, S, lp.irreps_out)
+        assert ap is not None and ap.ld % 32 == 0 and ap.n_chunks * 16 <= ap.ld
+        N = 5
+        agg = rng.standard_normal((N, uvu.d_mid)).astype(np.float64)          # reference layout: per path [u][k]
+        species = rng.integers(0, S, N)
+        w = rng.standard_normal(lp.weight_numel)
+        # --- what tp_fused's epilogue does with the new entries: out_off[c] + u + k * t_off[c] ---
+        row = np.full((N, ap.ld), np.nan)                                      # NaN: a slot that is read must have been written
+        ent = ap.entries
+        written = np.zeros(ap.ld, dtype=int)
+        for e in range(len(ent)):
+            mul = int(ent[e][2])
+            for c, pi in uvu.group_entry_paths[e].items():
+                pth = uvu.paths[pi]
+                d3 = 2 * pth.l3 + 1
+                o, ks = int(ent[e][20 + c]), int(ent[e][8 + c])
+                for u in range(mul):
+                    for k in range(d3):
+                        row[:, o + u + k * ks] = agg[:, pth.out_off + (uvu.group_entry_u0[e] + u) * d3 + k]
+                        written[o + u + k * ks] += 1
+        assert written.max() == 1 and written.sum() == uvu.d_mid               # a bijection onto the used slots
+        # --- what agg_linear does: blocks -> chunks -> MFMA steps with A[t][mt][g][c][s] ---
+        wtab = np.where(ap.gather >= 0, w[np.clip(ap.gather, 0, None)] * ap.scale[None, :], 0.0)
+        out = np.zeros((N, ap.d_out))
+        seen_chunks = 0
+        for (chunk, info, t0, _) in ap.blocks.tolist():
+            n, k, ii = info & 255, (info >> 12) & 255, (info >> 20) & 4095
+            c0, T, K, packed, a_off, out_off, mo, _z = ap.io_table[ii].tolist()
+            d3, n_mt, cw = packed & 255, (packed >> 8) & 255, (packed >> 16) & 255
+            assert mo * d3 <= mplan.AGG_STAGE_W and n_mt <= mplan.AGG_MAX_MT and 1 <= n <= mplan.AGG_BLOCK
+            assert chunk == c0 + k * T + t0
+            for i in range(n):
+                t = t0 + i
+                seen_chunks += 1
+                for g in range(4):
+                    for s_ in range(4):
+                        slot = 16 * t + 4 * g + s_
+                        if slot >= K:
+                            continue                                           # masked by the kernel (select, not multiply)
+                        b = row[:, 16 * (chunk + i) + 4 * g + s_]
+                        assert not np.isnan(b).any()
+                        for mt in range(n_mt):
+                            for c in range(min(cw, 16)):
+                                v = 16 * mt + c
+                                if v >= mo:
+                                    continue
+                                a_idx = a_off + ((((t * n_mt + mt) * 4 + g) * cw + c) * 4 + s_)
+                                out[:, out_off + v * d3 + k] += wtab[species, a_idx] * b
+        ref = ro3.FullyConnectedTensorProduct(str(uvu.irreps_out), f"{S}x0e", str(lp.irreps_out)).double()
+        with torch.no_grad():
+            ref.weight.copy_(torch.as_tensor(w))
+            want = ref(torch.as_tensor(agg), torch.nn.functional.one_hot(torch.as_tensor(species), S).double()).numpy()
+        assert np.allclose(out, want, rtol=0, atol=1e-6 * np.abs(want).max()), np.abs(out - want).max()   # (scale is fp32)
