@@ -20,6 +20,11 @@ from ._tables import DerivedWeight, DeviceTables
 from .utils import ActivationLayer, NormalizationLayer, SpeciesLinear, UVUTensorProduct
 
 
+import os as _os
+
+AGG_KM_MIN_ROWS = int(_os.environ.get("MATTEN_AGG_KM_MIN_ROWS", "8192"))   # nodes per batch from which lin2 streams component-major rows
+
+
 class PointConv(ModuleIrreps, torch.nn.Module):
     def __init__(
         self,
@@ -179,8 +184,11 @@ class PointConv(ModuleIrreps, torch.nn.Module):
                 and not _ag.needs_grad(x1, self_connection, self.lin2.weight, *self.tp.weight_nn.parameters())):
             data[DataKey.NODE_FEATURES] = self._forward_fused(x1, self_connection, species, data)
             return data
-        if self.agg_plan is not None and not _ag.needs_grad(x1, self_connection, self.lin2.weight,
-                                                             *self.tp.weight_nn.parameters()):
+        # (small batches keep the mul_ir row + row kernels: matten_agg_linear's per-workgroup set-up -- weight fragments
+        # and tables into LDS, species lookup -- is ~35 us of latency per launch that only a long stream pays back:
+        # n100, 473 rows: 1.25 vs 1.08 ms per forward; 64 000 rows: -3 %)
+        if (self.agg_plan is not None and x1.shape[0] >= AGG_KM_MIN_ROWS
+                and not _ag.needs_grad(x1, self_connection, self.lin2.weight, *self.tp.weight_nn.parameters())):
             ap, t, dev = self.agg_plan, self._agg_tables, x1.device
             agg = self.tp(x1, data, self.avg_num_neighbors, out_layout=(t.get("entries", dev), ap.ld))
             data[DataKey.NODE_FEATURES] = ops.agg_linear(agg, species, self._agg_wtab.get(self.lin2.weight),

@@ -387,7 +387,10 @@ def test_component_major_conv_matches_mul_ir_path(monkeypatch, golden_dir):
     ds100 = {"allowed_species": sorted({int(z) for s in structs for z in s["atomic_numbers"]}),
              "average_num_neighbors": average_num_neighbors(g100)}
     gf, dsf = _fcc(5)
-    for graphs, ds, hp in ((gf, dsf, PAPER), (g100, ds100, PAPER), (g100, ds100, LMAX2)):
+    import matten_amd.nn.conv as conv_mod
+    monkeypatch.setattr(conv_mod, "AGG_KM_MIN_ROWS", 0)      # production takes the new path from 8192 rows: force it here
+    # (EQUIV_TEST: the reference's own test hparams -- 8 / 4-channel high-l blocks incl. 4x4o, no BatchNorm, Cartesian output)
+    for graphs, ds, hp in ((gf, dsf, PAPER), (g100, ds100, PAPER), (g100, ds100, LMAX2), (g100, ds100, EQUIV_TEST)):
         torch.manual_seed(11)
         monkeypatch.setenv("MATTEN_AGG_LAYOUT", "km")
         new = ScalarTensorModel(backbone_hparams=dict(hp), dataset_hparams=ds).to(DEV).eval()
@@ -407,7 +410,10 @@ def test_component_major_conv_matches_mul_ir_path(monkeypatch, golden_dir):
             y_old = old(dict(b))[0]["elastic_tensor_full"]
         for i in range(len(convs_new)):
             close(feats[("new", i)], feats[("old", i)], 2e-6, f"conv layer {i} node features")
-        close_blocks(y_new, y_old, rtol=5e-6, what="end to end", floor=5e-7)
+        if y_new.dim() == 2:
+            close_blocks(y_new, y_old, rtol=5e-6, what="end to end", floor=5e-7)
+        else:
+            close(y_new, y_old, 2e-6, "end to end (Cartesian)")
 
 
 def test_huge_radial_weights_stay_inside_the_fp16_split_range():
