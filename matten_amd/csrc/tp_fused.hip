@@ -531,8 +531,8 @@ struct StoreAgg {
     template <class G>
     __device__ __forceinline__ void store(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
                                           float a_scale_inv, int node, int j, int u, bool valid) const {
-        const int cu = 1 << ge.cu_log2;
-#ifdef TPF_VECTOR_EPILOGUE   // measured slower with the component-major row (see store_vec): off by default
+#ifdef TPF_VECTOR_EPILOGUE
+        const int cu = 1 << ge.cu_log2;   // measured slower with the component-major row (see store_vec): off by default
         // wave-uniform: component-major row (the stride of the entry's first coupling says so), every channel lane of a
         // node in use, room for a pass in the tile
         if (t != nullptr && ge.t_off[__builtin_ctz(ge.mask | 0x80000000u) % MAXC] != 0 && ge.mul == cu && cu >= 2 &&
