@@ -369,6 +369,16 @@ int matten_tp_backward(const float* x, int64_t d_in, const void* w_edge, int64_t
 int matten_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* step,
                      float lr, float beta1, float beta2, float eps, float weight_decay, matten_stream_t stream);
 
+/* the same adjoint with the literal-coefficient coupling code of the forward kernels (cg_gen.h): a thread owns (edge,
+ * channel of one input block) and walks the block's paths; one atomic per (edge, channel, component) into dx.
+ *   blocks[n_blocks,4] int32 {x_off, mul, l1, first path | n_paths << 16}; paths[n_paths,4] {l1*25+l2*5+l3, w_off, out_off, 0};
+ *   max_mul = the largest mul of a block (sizes the launch); w_edge / dw fp32, or both bf16 when edge_is_bf16 */
+int matten_tp_backward_lit(const float* x, int64_t d_in, const void* w_edge, int64_t w_ld, const float* sh_sorted,
+                           int64_t sh_stride, const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* blocks,
+                           int64_t n_blocks, int64_t max_mul, const int32_t* paths, int64_t n_paths, const float* g_agg,
+                           int64_t d_mid, float avg_num_neighbors, const float* num_neigh, int64_t n_edges, float* dx,
+                           void* dw, int64_t dw_ld, int edge_is_bf16, matten_stream_t stream);
+
 /* adjoint of matten_species_linear w.r.t. the packed weights (the adjoint w.r.t. x is matten_species_linear
  * itself with the transposed segment table and transposed packed weights):
  *   dWp[s, w_off + u*mo + w] = sum_{rows n of species s} sum_k x[n, x_off+u*d+k] dy[n, o_off+w*d+k] */

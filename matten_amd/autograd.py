@@ -121,6 +121,12 @@ class TensorProductScatterFn(torch.autograd.Function):
         x, w_edge = ctx.saved_tensors
         mod, dev = ctx.mod, g.device
         sh, src, dst = ctx.graph
+        impl = os.environ.get("MATTEN_TP_BWD", "lit")   # "lit": literal-coefficient kernel; "table": the table-driven ones
+        if impl == "lit":
+            dx, dw = ops.tp_backward_lit(x, w_edge, sh, src, dst, mod._tables.get("bw_blocks", dev),
+                                         mod._tables.get("bw_paths", dev), mod.plan.bw_max_mul, g.contiguous(), ctx.avg,
+                                         ctx.num_neigh)
+            return dx, dw, None, None, None, None
         dx, dw = ops.tp_backward(x, w_edge, sh, src, dst, mod._tables.get("bw_col_meta", dev),
                                  mod._tables.get("bw_nnz_ijk", dev), mod._tables.get("bw_nnz_c", dev), g.contiguous(),
                                  ctx.avg, ctx.num_neigh,

@@ -68,6 +68,23 @@ def emit_triple(l1, l2, l3, out):
                 expr = f"fmaf({lit(c)}, y[{j}], {expr})"
             out.append(f"        acc[{k}] = fmaf(xw[{i}], {expr}, acc[{k}]);")
     out.append("    }")
+    # adjoint w.r.t. the first operand (training): t[i] += sum_jk C_ijk y[j] g[k].  With it
+    #   d/dw = sum_i x[i] t[i]   and   d/dx[i] = w t[i]   for out[k] = w sum_ij C_ijk x[i] y[j]
+    out.append("    static __device__ __forceinline__ void adjoint(const float* __restrict__ y, "
+               "const float* __restrict__ g, float* __restrict__ t) {")
+    jk = sorted({(j, k) for _, j, k, _ in nz})
+    for (j, k) in jk:
+        terms = [(i, c) for (i, jj, kk, c) in nz if jj == j and kk == k]
+        if len(terms) == 1 and abs(abs(terms[0][1]) - 1.0) < 1e-12:
+            i, c = terms[0]
+            sign = "" if c > 0 else "-"
+            out.append(f"        t[{i}] = fmaf({sign}y[{j}], g[{k}], t[{i}]);")
+            continue
+        out.append(f"        {{ const float p = y[{j}] * g[{k}];")
+        for i, c in terms:
+            out.append(f"          t[{i}] = fmaf({lit(c)}, p, t[{i}]);")
+        out.append("        }")
+    out.append("    }")
     out.append("};")
     return min(cost_pair, cost_m), len(nz)
 

@@ -585,6 +585,32 @@ def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk,
     return dx, dw
 
 
+def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths, max_mul: int, g_agg,
+                    avg_num_neighbors: float, num_neigh=None):
+    """the adjoint of tp_backward with literal-coefficient coupling code (include/matten_hip.h matten_tp_backward_lit;
+    tables plan.bw_blocks / bw_paths) -> (dx [N,d_in], dw [E, ld of w_edge])"""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    w_edge = _edge_dtype(w_edge, "w_edge")
+    g_agg = _need(g_agg, torch.float32, "grad agg")
+    N, d_in = x.shape
+    E = w_edge.shape[0]
+    dx = torch.zeros(N, d_in, dtype=torch.float32, device=x.device)
+    # columns no path writes (the pad up to the row stride) must not hold NaN for the MLP adjoint's masked reads: they are
+    # masked by a select there, so plain empty storage is fine
+    dw = torch.empty(E, w_edge.shape[1], dtype=w_edge.dtype, device=x.device)
+    if num_neigh is not None:
+        num_neigh = _need(num_neigh, torch.float32, "num_neigh")
+    with _timed(f"tp_backward/d_mid={g_agg.shape[1]}/d_in={d_in}"):
+        rc = lib.matten_tp_backward_lit(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
+                                        _ptr(src_sorted), _ptr(dst_sorted), _ptr(blocks), blocks.shape[0], int(max_mul),
+                                        _ptr(paths), paths.shape[0], _ptr(g_agg), g_agg.shape[1],
+                                        float(avg_num_neighbors or 0.0), _ptr(num_neigh), E, _ptr(dx), _ptr(dw),
+                                        dw.shape[1], int(w_edge.dtype == torch.bfloat16), _stream())
+    _lib.check(rc, "matten_tp_backward_lit")
+    return dx, dw
+
+
 def species_linear_wgrad(x, dy, species_order, n_species: int, seg_tables, w_stride: int) -> torch.Tensor:
     lib = _lib.load()
     x = _need(x, torch.float32, "x")

@@ -178,6 +178,10 @@ class UVUPlan:
     bw_nnz_c: np.ndarray = None       # f32 [nnz]
     bw_in_ptr: np.ndarray = None      # int32 [n_in+1] / bw_in_cols int32 [W]: weight columns grouped by input channel
     bw_in_cols: np.ndarray = None
+    # literal-coefficient adjoint (matten_tp_backward_lit): input blocks and their path lists
+    bw_blocks: np.ndarray = None      # int32 [n_blocks, 4] {x_off, mul, l1, first path | n_paths << 16}
+    bw_paths: np.ndarray = None       # int32 [n_paths, 4] {l1*25 + l2*5 + l3, w_off, out_off, 0}
+    bw_max_mul: int = 0
 
 
 def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
@@ -378,12 +382,21 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
         for u in range(p.mul):
             col_meta[p.w_off + u] = (p.x_off + u * d1, p.out_off + u * d3, b0, cnt | (sh_offs[p.l2] << 16))
+    # literal adjoint: per input block its paths (the path list is generated block by block already)
+    bw_blocks, bw_paths = [], []
+    for i_in1, plist in by_block.items():
+        bw_blocks.append((plist[0].x_off, plist[0].mul, plist[0].l1, len(bw_paths) | (len(plist) << 16)))
+        assert len(plist) < 32768 and len(bw_paths) < 65536
+        for pth in plist:
+            bw_paths.append((pth.l1 * 25 + pth.l2 * 5 + pth.l3, pth.w_off, pth.out_off, 0))
     # weight columns grouped by the input channel they read (stable: reference column order inside a group)
     in_order = np.argsort(col_meta[:, 0], kind="stable")
     xb_sorted = col_meta[in_order, 0]
     starts = np.nonzero(np.concatenate([[True], xb_sorted[1:] != xb_sorted[:-1]]))[0]
     bw_in_ptr = np.concatenate([starts, [len(in_order)]]).astype(np.int32)
     return UVUPlan(
+        bw_blocks=np.array(bw_blocks, dtype=np.int32).reshape(-1, 4), bw_paths=np.array(bw_paths, dtype=np.int32).reshape(-1, 4),
+        bw_max_mul=max(b[1] for b in bw_blocks),
         bw_in_ptr=bw_in_ptr, bw_in_cols=in_order.astype(np.int32),
         bw_col_meta=col_meta.astype(np.int32), bw_nnz_ijk=np.array(nnz_ijk, dtype=np.uint8).reshape(-1, 4),
         bw_nnz_c=np.array(nnz_c, dtype=np.float32),

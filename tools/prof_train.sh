@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$GRAFT_REPO_ROOT/gpurun_out/prof_train"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_train" -- python3 "$GRAFT_REPO_ROOT/tools/train_bench.py" > "$GRAFT_REPO_ROOT/gpurun_out/prof_train.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_train" -- python3 "$GRAFT_REPO_ROOT/tools/train_bench.py" > "$GRAFT_REPO_ROOT/gpurun_out/prof_train.log" 2>&1
 tail -1 "$GRAFT_REPO_ROOT/gpurun_out/prof_train.log"
 f=$(find "$GRAFT_REPO_ROOT/gpurun_out/prof_train" -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
