@@ -324,8 +324,8 @@ int matten_segment_reduce(const float* x, int64_t dim, const int64_t* ptr, int64
  * Inputs as matten_radial_mlp (packed weights; w2p in the column order of dw), plus dw[E, dw_ld] = dL/dw from
  * matten_tp_backward (fp32, or bf16 when dw_is_bf16; only the first w_cols columns are read as data).
  * Outputs are PARTIAL sums the caller adds up (fixed order, no atomics):
- *   part_small[matten_radial_mlp_bwd_small_slices(E)][nb_pad*32 + 32*32]: d/dW0p [nb_pad,32] then d/dW1p [32,32]
- *   part_w2[matten_radial_mlp_bwd_w2_ranges(E)][32][w_pad]:               d/dW2p
+ *   part_small[matten_radial_mlp_bwd_small_slices(E)][nb_pad*32 + 32*32]: scale0 d/dW0p [nb_pad,32], scale1 d/dW1p [32,32]
+ *   part_w2[matten_radial_mlp_bwd_w2_ranges(E)][32][w_pad]:               scale2 d/dW2p
  *   h2_scratch[E, 32]: workspace (the recomputed hidden features, written by the first kernel, read by the second)
  * ------------------------------------------------------------------------------------------ */
 int64_t matten_radial_mlp_bwd_small_slices(int64_t n_edges);
@@ -333,7 +333,19 @@ int64_t matten_radial_mlp_bwd_w2_ranges(int64_t n_edges);
 int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                           const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden, int w_pad,
                           int w_cols, const void* dw, int64_t dw_ld, int dw_is_bf16, float* h2_scratch,
-                          float* part_small, float* part_w2, matten_stream_t stream);
+                          float* part_small, float* part_w2, float scale0, float scale1, float scale2,
+                          matten_stream_t stream);
+/* the raw layers (w0 [nb,32], w1 [32,32], w2 [32,W]) -> packed operands w0p = scale0 w0 (rows padded to nb_pad),
+ * w1p = scale1 w1, w2p = scale2 w2 (columns padded to w_pad), one launch; matten_radial_mlp_bwd multiplies its partial
+ * sums by the same three factors, so they are gradients w.r.t. the RAW layers */
+int matten_radial_pack(const float* w0, const float* w1, const float* w2, int n_basis, int nb_pad, int w_cols, int w_pad,
+                       float scale0, float scale1, float scale2, float* w0p, float* w1p, float* w2p,
+                       matten_stream_t stream);
+/* out[i] = src[idx[i]] * scale[(scale_by_source ? idx[i] : i) % scale_period]: the per-species re-packing of a flat e3nn
+ * weight (idx = gather table, scale by output position) and its adjoint (idx = inverse permutation, scale by source) */
+int matten_gather_scale(const float* src, const int64_t* idx, const float* scale, int64_t n, int64_t scale_period,
+                        int scale_by_source, float* out, matten_stream_t stream);
+int64_t matten_species_linear_wgrad_slices(int64_t n_rows, int64_t n_species);   /* 1: dwp need not be zeroed */
 
 /* ------------------------------------------------------------------------------------------
  * CartesianTensor.to_cartesian (utils.py:123-124, predict.py:145): out[b,:] = x[b,:] @ Q

@@ -24,12 +24,12 @@ class PackWeightsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, gather, scale, inverse):
         ctx.save_for_backward(scale, inverse)
-        return (weight[gather] * scale).contiguous()
+        return ops.gather_scale(weight, gather, scale)                       # one launch instead of index + multiply
 
     @staticmethod
     def backward(ctx, g):
         scale, inverse = ctx.saved_tensors
-        return (g * scale).reshape(-1)[inverse], None, None, None
+        return ops.gather_scale(g.contiguous(), inverse, scale, scale_by_source=True), None, None, None
 
 
 class SpeciesLinearFn(torch.autograd.Function):
@@ -84,7 +84,7 @@ class RadialMLPFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w0, w1, w2, mod, geom_sorted, n_basis, r_start, r_end):
-        w0p, w1p, w2p = mod.pack_reference_order(w0, w1, w2)
+        w0p, w1p, w2p = ops.radial_pack(w0, w1, w2, mod.pack_scales())          # one launch for the three layers
         ctx.mod, ctx.rbf = mod, (int(n_basis), float(r_start), float(r_end))
         ctx.save_for_backward(geom_sorted, w0p, w1p, w2p)
         return ops.radial_mlp(geom_sorted, int(n_basis), float(r_start), float(r_end), w0p, w1p, w2p,
@@ -94,10 +94,10 @@ class RadialMLPFn(torch.autograd.Function):
     def backward(ctx, g):
         geom, w0p, w1p, w2p = ctx.saved_tensors
         mod = ctx.mod
-        nb, h, W = mod.hs[0], mod.hs[1], mod.hs[3]
-        d0, d1, d2 = ops.radial_mlp_bwd(geom, *ctx.rbf, w0p, w1p, w2p, W, g.contiguous())
-        c = mod.act_cst / h**0.5
-        return d0[:nb] / nb**0.5, d1 * c, d2[:, :W] * c, None, None, None, None, None
+        nb, W = mod.hs[0], mod.hs[3]
+        # the kernels multiply their partial sums by the packing factors: gradients w.r.t. the raw layers come back
+        d0, d1, d2 = ops.radial_mlp_bwd(geom, *ctx.rbf, w0p, w1p, w2p, W, g.contiguous(), scales=mod.pack_scales())
+        return d0[:nb], d1, d2[:, :W], None, None, None, None, None
 
 
 class TensorProductScatterFn(torch.autograd.Function):

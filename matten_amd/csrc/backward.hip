@@ -370,6 +370,12 @@ extern "C" int matten_tp_backward(const float* x, int64_t d_in, const void* w_ed
     return MATTEN_OK;
 }
 
+// row slices per species: with ONE slice every packed weight is written exactly once (no atomics: the caller need not
+// zero dwp); with more the partial sums meet in a zero-initialised dwp
+extern "C" int64_t matten_species_linear_wgrad_slices(int64_t n_rows, int64_t n_species) {
+    return std::min<int64_t>(256, std::max<int64_t>(1, n_rows / (16 * std::max<int64_t>(1, n_species))));
+}
+
 extern "C" int matten_species_linear_wgrad(const float* x, int64_t d_in, const float* dy, int64_t d_out,
                                            const int32_t* order, const int32_t* seg, int64_t n_species, int64_t n_rows,
                                            const int32_t* segs, int64_t n_segs, int64_t w_stride, float* dwp,
@@ -381,7 +387,7 @@ extern "C" int matten_species_linear_wgrad(const float* x, int64_t d_in, const f
     if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
     if (!order && n_species != 1) return MATTEN_EINVAL;
     // one slice per ~16 rows of an average species (a single slice keeps the plain, order-fixed store)
-    const int64_t slices = std::min<int64_t>(256, std::max<int64_t>(1, n_rows / (16 * n_species)));
+    const int64_t slices = matten_species_linear_wgrad_slices(n_rows, n_species);
     dim3 grid((unsigned)n_species, (unsigned)n_segs, (unsigned)slices);
     species_linear_wgrad_kernel<<<grid, 256, 0, stream>>>(x, (int)d_in, dy, (int)d_out, order, seg, (int)n_rows,
                                                           (const LinSeg*)segs, (int)w_stride, dwp);
@@ -689,6 +695,31 @@ extern "C" int matten_tp_backward_lit(const float* x, int64_t d_in, const void* 
               (int)sh_stride, (int)d_mid, (int)dw_ld, edge_is_bf16, avg_num_neighbors};
     tp_backward_lit_kernel<<<dim3((unsigned)gx, (unsigned)n_blocks), 256, 0, stream>>>(a, (const int4*)blocks,
                                                                                       (const int4*)paths);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+// ---- packed[s, j] = weight[gather[s, j]] * scale[j]  (and its adjoint through the inverse permutation) in one launch.
+// The species-indexed linears keep the reference's flat e3nn parameter; every step re-packs 14 of them and maps 14
+// gradients back: as torch index + multiply that was 56 tiny launches per optimisation step.
+namespace {
+__global__ void gather_scale_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                    const float* __restrict__ scale, int64_t n, int64_t scale_period, int scale_by_source,
+                                    float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = idx[i];
+    out[i] = src[j] * scale[(scale_by_source ? j : i) % scale_period];
+}
+}  // namespace
+
+extern "C" int matten_gather_scale(const float* src, const int64_t* idx, const float* scale, int64_t n, int64_t scale_period,
+                                   int scale_by_source, float* out, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || scale_period <= 0) return MATTEN_EINVAL;
+    if (n == 0) return MATTEN_OK;
+    if (!src || !idx || !scale || !out) return MATTEN_EINVAL;
+    gather_scale_kernel<<<(unsigned)matten_cdiv(n, 256), 256, 0, stream>>>(src, idx, scale, n, scale_period, scale_by_source, out);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

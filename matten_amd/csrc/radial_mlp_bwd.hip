@@ -72,7 +72,7 @@ template <int KS0, bool BF16>
 __global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_edges(
     const float4* __restrict__ geom, int64_t E, int n_basis, float r_start, float r_end, const float* __restrict__ w0p,
     const float* __restrict__ w1p, const float* __restrict__ w2p, int w_pad, int w_cols, const void* __restrict__ dw,
-    int64_t dw_ld, float* __restrict__ h2_out, float* __restrict__ part_small, int tiles_per_wave) {
+    int64_t dw_ld, float* __restrict__ h2_out, float* __restrict__ part_small, int tiles_per_wave, float s0, float s1) {
     __shared__ float lds[BW_WAVES][(3 * HID + 16) * TS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_edges(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k0 = 4 * g + r;
-            if (k0 < nb_pad) out[k0 * HID + 16 * tn + c] = g_w0[tn][r];
+            if (k0 < nb_pad) out[k0 * HID + 16 * tn + c] = g_w0[tn][r] * s0;
         }
     float* out1 = out + nb_pad * HID;
 #pragma unroll
@@ -218,14 +218,14 @@ __global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_edges(
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out1[(16 * tm + 4 * g + r) * HID + 16 * tn + c] = g_w1[tm][tn][r];
+            for (int r = 0; r < 4; ++r) out1[(16 * tm + 4 * g + r) * HID + 16 * tn + c] = g_w1[tm][tn][r] * s1;
 }
 
 // part_w2[range][32][w_pad]; grid = (ceil(w_pad / 64), n_ranges), wave w of a block owns columns [64 bx + 16 w, +16)
 template <bool BF16>
 __global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_w2(const float* __restrict__ h2, const void* __restrict__ dw,
                                                                   int64_t dw_ld, int64_t E, int w_pad,
-                                                                  float* __restrict__ part_w2, int range) {
+                                                                  float* __restrict__ part_w2, int range, float s2) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_w2(const float* 
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(int64_t)(16 * t + 4 * g + r) * w_pad + q0 + c] = acc[t][r];
+        for (int r = 0; r < 4; ++r) out[(int64_t)(16 * t + 4 * g + r) * w_pad + q0 + c] = acc[t][r] * s2;
 }
 
 }  // namespace
@@ -268,7 +268,8 @@ extern "C" int64_t matten_radial_mlp_bwd_w2_ranges(int64_t n_edges) { return mat
 extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                                      const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden,
                                      int w_pad, int w_cols, const void* dw, int64_t dw_ld, int dw_is_bf16,
-                                     float* h2_scratch, float* part_small, float* part_w2, matten_stream_t stream_) {
+                                     float* h2_scratch, float* part_small, float* part_w2, float scale0, float scale1,
+                                     float scale2, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || hidden != HID || (w_pad & 15) || w_pad <= 0 || w_cols <= 0 || w_cols > w_pad || (nb_pad & 3) ||
         nb_pad < n_basis || nb_pad > 16 || dw_ld < w_pad || (dw_ld & 3))
@@ -279,7 +280,7 @@ extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, 
 #define LAUNCH(K, B)                                                                                                  \
     radial_mlp_bwd_edges<K, B><<<grid1, BW_WAVES * 64, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis,     \
                                                                      r_start, r_end, w0p, w1p, w2p, w_pad, w_cols, dw, \
-                                                                     dw_ld, h2_scratch, part_small, bw_tiles(n_edges))
+                                                                     dw_ld, h2_scratch, part_small, bw_tiles(n_edges), scale0, scale1)
 #define LAUNCH_K(B)                     \
     switch (nb_pad >> 2) {              \
         case 1: LAUNCH(1, B); break;    \
@@ -294,10 +295,42 @@ extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, 
     dim3 grid2((unsigned)matten_cdiv(w_pad, 16 * BW_WAVES), (unsigned)matten_radial_mlp_bwd_w2_ranges(n_edges));
     if (dw_is_bf16)
         radial_mlp_bwd_w2<true><<<grid2, BW_WAVES * 64, 0, stream>>>(h2_scratch, dw, dw_ld, n_edges, w_pad, part_w2,
-                                                                     w2_range(n_edges));
+                                                                     w2_range(n_edges), scale2);
     else
         radial_mlp_bwd_w2<false><<<grid2, BW_WAVES * 64, 0, stream>>>(h2_scratch, dw, dw_ld, n_edges, w_pad, part_w2,
-                                                                      w2_range(n_edges));
+                                                                      w2_range(n_edges), scale2);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+// (w0 [nb,32], w1 [32,32], w2 [32,W] raw parameters) -> the packed operands of matten_radial_mlp / _bwd in ONE launch:
+// w0p [nb_pad,32] = s0 w0 (zero rows past nb), w1p = s1 w1, w2p [32,w_pad] = s2 w2 (zero columns past W).
+namespace {
+__global__ void radial_pack_kernel(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
+                                   int nb, int nb_pad, int W, int w_pad, float s0, float s1, float s2,
+                                   float* __restrict__ w0p, float* __restrict__ w1p, float* __restrict__ w2p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n0 = nb_pad * HID, n1 = HID * HID, n2 = HID * w_pad;
+    if (i < n0) {
+        w0p[i] = (i / HID) < nb ? w0[i] * s0 : 0.0f;
+    } else if (i < n0 + n1) {
+        w1p[i - n0] = w1[i - n0] * s1;
+    } else if (i < n0 + n1 + n2) {
+        const int j = i - n0 - n1, k = j / w_pad, q = j - k * w_pad;
+        w2p[j] = q < W ? w2[k * W + q] * s2 : 0.0f;
+    }
+}
+}  // namespace
+
+extern "C" int matten_radial_pack(const float* w0, const float* w1, const float* w2, int n_basis, int nb_pad, int w_cols,
+                                  int w_pad, float scale0, float scale1, float scale2, float* w0p, float* w1p, float* w2p,
+                                  matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_basis <= 0 || nb_pad < n_basis || w_cols <= 0 || w_pad < w_cols) return MATTEN_EINVAL;
+    if (!w0 || !w1 || !w2 || !w0p || !w1p || !w2p) return MATTEN_EINVAL;
+    const int n = nb_pad * HID + HID * HID + HID * w_pad;
+    radial_pack_kernel<<<(unsigned)matten_cdiv(n, 256), 256, 0, stream>>>(w0, w1, w2, n_basis, nb_pad, w_cols, w_pad, scale0,
+                                                                         scale1, scale2, w0p, w1p, w2p);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

@@ -175,6 +175,11 @@ class RadialMLP(torch.nn.Module):
         w0p, w1p, w2p = self._packed.get(self.layer0.weight, self.layer1.weight, self.layer2.weight)
         return ops.radial_mlp(geom_sorted, n_basis, r_start, r_end, w0p, w1p, w2p)
 
+    def pack_scales(self):
+        """(1/sqrt(nb), c/sqrt(h), c/sqrt(h)): what turns the raw layers into the kernels' operands"""
+        nb, h = self.hs[0], self.hs[1]
+        return 1.0 / nb**0.5, self.act_cst / h**0.5, self.act_cst / h**0.5
+
     def pack_reference_order(self, w0: Tensor, w1: Tensor, w2: Tensor):
         """(w0p, w1p, w2p) with the LAST layer's columns in the reference's order (what the training tensor product and
         its adjoint index), padded to a multiple of 16"""

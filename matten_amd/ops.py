@@ -212,8 +212,39 @@ def radial_mlp(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p
     return out
 
 
-def radial_mlp_bwd(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p, w2p, w_cols: int, dw):
-    """Adjoint of radial_mlp w.r.t. the packed weights -> (dW0p [nb_pad,32], dW1p [32,32], dW2p [32,w_pad]).
+def radial_pack(w0, w1, w2, scales):
+    """raw radial layers -> (w0p [nb_pad,32], w1p [32,32], w2p [32,w_pad]) = the operands of radial_mlp in the reference's
+    column order, each multiplied by its scale, in one launch"""
+    lib = _lib.load()
+    w0, w1, w2 = (_need(w, torch.float32, n) for w, n in ((w0, "layer0.weight"), (w1, "layer1.weight"), (w2, "layer2.weight")))
+    nb, h = w0.shape
+    W = w2.shape[1]
+    nb_pad, w_pad = (nb + 3) // 4 * 4, (W + 15) // 16 * 16
+    dev = w0.device
+    w0p = torch.empty(nb_pad, h, dtype=torch.float32, device=dev)
+    w1p = torch.empty(h, h, dtype=torch.float32, device=dev)
+    w2p = torch.empty(h, w_pad, dtype=torch.float32, device=dev)
+    _lib.check(lib.matten_radial_pack(_ptr(w0), _ptr(w1), _ptr(w2), nb, nb_pad, W, w_pad, float(scales[0]), float(scales[1]),
+                                      float(scales[2]), _ptr(w0p), _ptr(w1p), _ptr(w2p), _stream()), "matten_radial_pack")
+    return w0p, w1p, w2p
+
+
+def gather_scale(src, idx, scale, scale_by_source: bool = False):
+    """out[i] = src.flat[idx.flat[i]] * scale[(idx.flat[i] if scale_by_source else i) % len(scale)], shaped like idx"""
+    lib = _lib.load()
+    src = _need(src, torch.float32, "src")
+    idx = _need(idx, torch.int64, "idx")
+    scale = _need(scale, torch.float32, "scale")
+    out = torch.empty(idx.shape, dtype=torch.float32, device=src.device)
+    _lib.check(lib.matten_gather_scale(_ptr(src), _ptr(idx), _ptr(scale), idx.numel(), scale.numel(), int(scale_by_source),
+                                       _ptr(out), _stream()), "matten_gather_scale")
+    return out
+
+
+def radial_mlp_bwd(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p, w2p, w_cols: int, dw,
+                   scales=(1.0, 1.0, 1.0)):
+    """Adjoint of radial_mlp -> (dW0 [nb_pad,32], dW1 [32,32], dW2 [32,w_pad]): gradients w.r.t. the packed weights
+    times `scales`, i.e. w.r.t. the raw layers when `scales` are the factors radial_pack applied.
     dw [E, ld >= w_pad] fp32 or bf16: dL/dw from tp_backward (pad columns are never read as data)."""
     lib = _lib.load()
     geom_sorted = _need(geom_sorted, torch.float32, "geom_sorted")
@@ -234,7 +265,8 @@ def radial_mlp_bwd(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p,
     with _timed(f"radial_mlp_bwd/w_pad={w_pad}"):
         rc = lib.matten_radial_mlp_bwd(_ptr(geom_sorted), E, n_basis, r_start, r_end, _ptr(w0p), nb_pad, _ptr(w1p),
                                        _ptr(w2p), hidden, w_pad, int(w_cols), _ptr(dw), dw.shape[1],
-                                       int(dw.dtype == torch.bfloat16), _ptr(h2), _ptr(part_small), _ptr(part_w2), _stream())
+                                       int(dw.dtype == torch.bfloat16), _ptr(h2), _ptr(part_small), _ptr(part_w2),
+                                       float(scales[0]), float(scales[1]), float(scales[2]), _stream())
     _lib.check(rc, "matten_radial_mlp_bwd")
     small = part_small.sum(0)     # fixed-order reductions of the per-wave / per-range partial sums (no atomics anywhere)
     return (small[: nb_pad * hidden].reshape(nb_pad, hidden), small[nb_pad * hidden:].reshape(hidden, hidden),
@@ -616,7 +648,10 @@ def species_linear_wgrad(x, dy, species_order, n_species: int, seg_tables, w_str
     x = _need(x, torch.float32, "x")
     dy = _need(dy, torch.float32, "dy")
     order, seg = species_order if species_order is not None else (None, None)
-    dwp = torch.zeros(n_species, w_stride, dtype=torch.float32, device=x.device)
+    # one row slice per species: every packed weight is written exactly once (nothing to pre-zero); several: partial sums
+    # meet in dwp through atomics
+    single = lib.matten_species_linear_wgrad_slices(x.shape[0], n_species) == 1
+    dwp = (torch.empty if single else torch.zeros)(n_species, w_stride, dtype=torch.float32, device=x.device)
     for segs in seg_tables:
         _lib.check(
             lib.matten_species_linear_wgrad(_ptr(x), x.shape[1], _ptr(dy), dy.shape[1], _ptr(order), _ptr(seg),
