@@ -345,7 +345,7 @@ int matten_radial_pack(const float* w0, const float* w1, const float* w2, int n_
  * weight (idx = gather table, scale by output position) and its adjoint (idx = inverse permutation, scale by source) */
 int matten_gather_scale(const float* src, const int64_t* idx, const float* scale, int64_t n, int64_t scale_period,
                         int scale_by_source, float* out, matten_stream_t stream);
-int64_t matten_species_linear_wgrad_slices(int64_t n_rows, int64_t n_species);   /* 1: dwp need not be zeroed */
+int64_t matten_species_linear_wgrad_slices(int64_t n_rows, int64_t n_species);   /* sizes matten_species_linear_wgrad's partial */
 
 /* ------------------------------------------------------------------------------------------
  * CartesianTensor.to_cartesian (utils.py:123-124, predict.py:145): out[b,:] = x[b,:] @ Q
@@ -393,10 +393,13 @@ int matten_tp_backward_lit(const float* x, int64_t d_in, const void* w_edge, int
 
 /* adjoint of matten_species_linear w.r.t. the packed weights (the adjoint w.r.t. x is matten_species_linear
  * itself with the transposed segment table and transposed packed weights):
- *   dWp[s, w_off + u*mo + w] = sum_{rows n of species s} sum_k x[n, x_off+u*d+k] dy[n, o_off+w*d+k] */
+ *   dWp[s, w_off + u*mo + w] = sum_{rows n of species s} sum_k x[n, x_off+u*d+k] dy[n, o_off+w*d+k]
+ * fp32 MFMA over (row, component); fixed summation order.  Every weight of the table's segments is written (dwp need
+ * not be initialised).  partial: scratch [matten_species_linear_wgrad_slices(n_rows, n_species), n_species, w_stride],
+ * required when that count is above 1 (large batches: the species' rows are cut into slices), else may be NULL */
 int matten_species_linear_wgrad(const float* x, int64_t d_in, const float* dy, int64_t d_out, const int32_t* order,
                                 const int32_t* seg, int64_t n_species, int64_t n_rows, const int32_t* segs,
-                                int64_t n_segs, int64_t w_stride, float* dwp, matten_stream_t stream);
+                                int64_t n_segs, int64_t w_stride, float* dwp, float* partial, matten_stream_t stream);
 
 /* adjoint of the Gate part of matten_gate_bn (bn_weight == NULL forward); dx zero-initialised */
 int matten_gate_bwd(const float* x, int64_t d_in, const int32_t* meta, int64_t d_out, const float* act_cst,

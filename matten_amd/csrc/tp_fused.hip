@@ -58,6 +58,16 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     lo = fabsf(r) < F16_MIN_NORMAL ? (_Float16)0.0f : (_Float16)r;
 }
 
+#ifdef MATTEN_ABLATE_NO_GATHER   // timing experiment: every gather reads the destination node's own (cache-resident) row
+#define TPF_SRC(v) ((v) >= 0 ? (node < a.n_nodes ? node : 0) : 0)
+#else
+#define TPF_SRC(v) (v)
+#endif
+#ifdef MATTEN_ABLATE_NO_XLOAD    // timing experiment: no neighbour-row load at all (the value depends on the index only)
+#define TPF_XLD(xp, i, v) (1e-9f * (float)((v) + (i)))
+#else
+#define TPF_XLD(xp, i, v) ((xp)[i])
+#endif
 #ifndef TPF_SETPRIO
 #define TPF_SETPRIO 3
 #endif
@@ -772,16 +782,16 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                 const int s = s0 + so;
                 if (s < deg) contract(so, xn);
                 {
-                    const float* xp = a.x + (int64_t)src_nn * a.d_in + xcol;
+                    const float* xp = a.x + (int64_t)TPF_SRC(src_nn) * a.d_in + xcol;
 #pragma unroll
-                    for (int i = 0; i < G::D1; ++i) xn[i] = xp[i];
+                    for (int i = 0; i < G::D1; ++i) xn[i] = TPF_XLD(xp, i, src_nn);
                     src_nn = a.src_sorted[min(beg + s + 4, e_last)];
                 }
                 if (s + 1 < deg) contract(so + 1, xb);
                 {
-                    const float* xp = a.x + (int64_t)src_b * a.d_in + xcol;
+                    const float* xp = a.x + (int64_t)TPF_SRC(src_b) * a.d_in + xcol;
 #pragma unroll
-                    for (int i = 0; i < G::D1; ++i) xb[i] = xp[i];
+                    for (int i = 0; i < G::D1; ++i) xb[i] = TPF_XLD(xp, i, src_b);
                     src_b = a.src_sorted[min(beg + s + 5, e_last)];
                 }
             }
@@ -793,9 +803,9 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 #pragma unroll
                 for (int i = 0; i < G::D1; ++i) x[i] = xn[i];
                 {
-                    const float* xp = a.x + (int64_t)src_nn * a.d_in + xcol;
+                    const float* xp = a.x + (int64_t)TPF_SRC(src_nn) * a.d_in + xcol;
 #pragma unroll
-                    for (int i = 0; i < G::D1; ++i) xn[i] = xp[i];
+                    for (int i = 0; i < G::D1; ++i) xn[i] = TPF_XLD(xp, i, src_nn);
                     src_nn = a.src_sorted[min(beg + s + 2, e_last)];
                 }
                 if (s < deg) contract(so, x);

@@ -648,15 +648,16 @@ def species_linear_wgrad(x, dy, species_order, n_species: int, seg_tables, w_str
     x = _need(x, torch.float32, "x")
     dy = _need(dy, torch.float32, "dy")
     order, seg = species_order if species_order is not None else (None, None)
-    # one row slice per species: every packed weight is written exactly once (nothing to pre-zero); several: partial sums
-    # meet in dwp through atomics
-    single = lib.matten_species_linear_wgrad_slices(x.shape[0], n_species) == 1
-    dwp = (torch.empty if single else torch.zeros)(n_species, w_stride, dtype=torch.float32, device=x.device)
+    # every packed weight is written exactly once (nothing to pre-zero); large batches cut the species' rows into slices
+    # whose partial sums the library adds in slice order
+    slices = lib.matten_species_linear_wgrad_slices(x.shape[0], n_species)
+    dwp = torch.empty(n_species, w_stride, dtype=torch.float32, device=x.device)
+    partial = torch.empty(slices, n_species, w_stride, dtype=torch.float32, device=x.device) if slices > 1 else None
     for segs in seg_tables:
         _lib.check(
             lib.matten_species_linear_wgrad(_ptr(x), x.shape[1], _ptr(dy), dy.shape[1], _ptr(order), _ptr(seg),
                                             n_species, x.shape[0], _ptr(segs), segs.shape[0], w_stride, _ptr(dwp),
-                                            _stream()),
+                                            _ptr(partial), _stream()),
             "matten_species_linear_wgrad",
         )
     return dwp

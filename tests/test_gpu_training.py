@@ -362,3 +362,44 @@ def test_flat_adam_follows_torch_adam(golden_dir):
     for _ in range(5):
         l = float(step.step(batch, target))
     assert l < l0 and float(o3.step_count) == 6.0
+
+
+@pytest.mark.parametrize("irreps_in,irreps_out,S,N", [
+    ("32x0e+16x1o+4x2e", "32x0e+16x1o+4x2e", 3, 7),          # a handful of rows: one slice, mostly idle row quads
+    ("32x0e+16x1o+4x2e+2x3o+2x4e", "16x0e+8x1o+4x2e+2x3o+1x4e", 4, 301),
+    ("70x0e+33x1o", "65x0e+17x1o", 2, 150),                   # more than 4 x 4 tiles per segment: two tile blocks
+    ("32x0e+16x1e+16x1o+4x2e", "32x0e+16x1e+16x1o+4x2e", 2, 6000),   # large batch: row slices + ordered reduction
+    ("8x0e+3x2e", "5x0e+2x2e", 1, 4000),                      # single species, sliced
+])
+def test_species_linear_gradients_vs_oracle_autograd(irreps_in, irreps_out, S, N):
+    """matten_species_linear_wgrad (fp32 MFMA over (row, component), fixed summation order, sliced rows for large
+    batches) and the transposed-table dx against autograd through the oracle's FullyConnectedTensorProduct in fp64;
+    two runs are bit-identical (no atomics)."""
+    from matten_amd import ops
+    from matten_amd.nn.utils import SpeciesLinear
+    from oracle.e3nn_lite import o3 as ro3
+
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    mod = SpeciesLinear(irreps_in, S, irreps_out).to(DEV)
+    ref = ro3.FullyConnectedTensorProduct(irreps_in, f"{S}x0e", irreps_out).double()
+    w = torch.randn(mod.weight.numel(), device=DEV, generator=gen)
+    x = torch.randn(N, mod.plan.d_in, device=DEV, generator=gen, requires_grad=True)
+    gy = torch.randn(N, mod.plan.d_out, device=DEV, generator=gen)
+    species = torch.randint(0, S, (N,), device=DEV, generator=gen)
+    if N > 100:
+        species[: N // 3] = 0                                    # ragged species groups
+    order, seg, _ = ops.group_by_key(species, S)
+    with torch.no_grad():
+        mod.weight.copy_(w)
+        ref.weight.copy_(w.cpu().double())
+    grads = []
+    for _ in range(2):
+        mod.weight.grad = None
+        x.grad = None
+        mod(x, (order, seg)).backward(gy)
+        grads.append((mod.weight.grad.clone(), x.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    xr = x.detach().cpu().double().requires_grad_(True)
+    ref(xr, torch.nn.functional.one_hot(species.cpu(), S).double()).backward(gy.cpu().double())
+    _close(grads[0][0], ref.weight.grad, 3e-6, "dL/dweight")
+    _close(grads[0][1], xr.grad, 3e-6, "dL/dx")
