@@ -482,7 +482,11 @@ def run_rank(args):
         # conv layer and step) -- the same average rocprofv3 --stats reports for the kernel ----
         deg = n_edges / n_nodes
         per_kernel = {k: sum(v) / len(v) for k, v in kernel_ms.items()}
-        convs = [m for m in model.backbone.modules() if type(m).__name__ == "PointConv"]
+        from matten_amd.nn import conv as pconv
+
+        full_convs = [m for m in model.backbone.modules() if type(m).__name__ == "PointConv"]
+        # what an inference forward launches: the last conv layer runs as its view for the irreps the head reads
+        convs = [m._view if (m._view is not None and pconv.DEAD_PATH_ELIMINATION) else m for m in full_convs]
 
         def contract_bytes(plan, cols, d_in_part, d_mid_part):
             """SURVEY 8d per-edge algorithmic bytes of a tensor-product launch restricted to a set of input blocks:
@@ -587,10 +591,47 @@ def run_rank(args):
                     "peak_f16_TFLOPs": MFMA_F16_PEAK / 1e12,
                 },
             }
+        # two-kernel contract bytes per edge of one layer: TP launch (ids, vector, w read, node rows) + w written once
+        two_kernel = lambda p: algorithmic_bytes_tp_kernel(p, deg) + 4.0 * p.weight_numel
+        executed_share = sum(two_kernel(m.tp.plan) for m in convs) / sum(two_kernel(m.tp.plan) for m in full_convs)
         result["path_roofline"] = {
-            "definition": "edge-TP/s x 4816 B (SURVEY 8d two-kernel algorithmic bytes) / 8.0e12 B/s, per GPU",
-            "frac": value / world * B_ALG_PER_EDGE_TP / HBM_PEAK,
+            "definition": "edge-TP/s x 4816 B (SURVEY 8d two-kernel algorithmic bytes of the FULL model) x executed_share "
+                          "/ 8.0e12 B/s, per GPU; executed_share = contract bytes of the layers as launched (the last "
+                          "conv layer without its dead output irreps) over those of the full layers",
+            "executed_share": executed_share,
+            "frac": value / world * B_ALG_PER_EDGE_TP * executed_share / HBM_PEAK,
+            "frac_at_full_model_bytes": value / world * B_ALG_PER_EDGE_TP / HBM_PEAK,
         }
+        lastf, laste = full_convs[-1], convs[-1]
+        result["dead_output_elimination"] = {
+            "enabled": laste is not lastf,
+            "what": "inference runs the last conv layer for the output irreps its only reader (the o3.Linear head onto "
+                    "conv_to_output_hidden_irreps_out) takes; the other output irreps, the tensor-product paths that end in "
+                    "them and their radial-weight columns are dead code in the reference graph "
+                    "(model_factory/tfn_scalar_tensor.py:122-139).  Same model output (tests: "
+                    "test_dead_output_elimination_matches_the_full_layer), parameters / training / checkpoints untouched; "
+                    "MATTEN_DEAD_PATH_ELIMINATION=0 runs the full layer",
+            "last_conv_layer": {"irreps_out_full": str(lastf.sc.irreps_out), "irreps_out_run": str(laste.sc.irreps_out),
+                                "weight_columns_full": lastf.tp.plan.weight_numel, "weight_columns_run": laste.tp.plan.weight_numel,
+                                "d_mid_full": lastf.tp.plan.d_mid, "d_mid_run": laste.tp.plan.d_mid},
+        }
+        if laste is not lastf and world == 1 and not distributed and not args.no_extras:
+            # the same workload with the full last layer, timed by the same loop (shorter: 3 + 10 forwards)
+            pconv.DEAD_PATH_ELIMINATION = False
+            try:
+                for _ in range(3):
+                    step()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    step()
+                model.finish_input_checks()
+                barrier()
+                ms_full = 1e3 * (time.perf_counter() - t1) / 10
+            finally:
+                pconv.DEAD_PATH_ELIMINATION = True
+            result["dead_output_elimination"]["without_it"] = {
+                "ms_per_step": ms_full, "value": n_edges * n_layers / (ms_full * 1e-3), "steps": 10, "warmup": 3}
 
         # ---- CPU baseline: the oracle on a bounded sample of the same workload ----
         if world == 1 and not args.no_cpu_baseline:

@@ -84,7 +84,37 @@ def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any], pooli
         )
     backbone = create_sequential_module(modules=layers)
     link_radial_mlps(backbone)
+    eliminate_dead_outputs(backbone)
     return backbone
+
+
+def eliminate_dead_outputs(backbone) -> None:
+    """Inference-time dead-code elimination over the layer list.  The reference's last conv layer emits every irrep of
+    conv_layer_irreps (tfn_scalar_tensor.py:122-131) and the head that follows is an o3.Linear onto
+    conv_to_output_hidden_irreps_out (16x0e+2x2e+4e in the shipped config), which by construction reads only the input
+    irreps it also emits: with the paper's hyper-parameters 66 % of that layer's neighbour-sum row, 69 % of its radial
+    weight columns and the matching lin2 / self-connection blocks are computed and never read.  A bare PointConv
+    directly followed by the only reader of its node features gets an inference view for the irreps that reader
+    takes (PointConv.build_inference_view); training (autograd) always runs the full layer, so parameters, gradients
+    and checkpoints are untouched.  MATTEN_DEAD_PATH_ELIMINATION=0 switches it off."""
+    from ..data.irreps import DataKey
+
+    mods = list(backbone._modules.values())
+    for i in range(len(mods) - 1):
+        conv, head = mods[i], mods[i + 1]
+        if type(conv) is not PointConv or not isinstance(head, NodewiseLinear):
+            continue
+        if head.field != DataKey.NODE_FEATURES or head.out_field == DataKey.NODE_FEATURES:
+            continue
+        if any(getattr(m, "field", None) == DataKey.NODE_FEATURES or isinstance(m, (PointConv, PointConvWithActivation))
+               for m in mods[i + 2:]):
+            continue   # somebody else reads the full row later
+        read = {ir for _, ir in Irreps(head.irreps_out[head.out_field])}
+        kept = Irreps([(m, ir) for m, ir in conv.irreps_out[DataKey.NODE_FEATURES] if ir in read])
+        if kept.dim == 0 or kept.dim == conv.irreps_out[DataKey.NODE_FEATURES].dim:
+            continue
+        if head.build_kept_input(kept) and not conv.build_inference_view(kept):
+            head.__dict__["_kept"] = None
 
 
 def link_radial_mlps(backbone) -> None:

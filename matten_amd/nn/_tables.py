@@ -37,3 +37,26 @@ class DerivedWeight:
                 self._val = self._fn(*params)
             self._key = key
         return self._val
+
+
+class WeightSlice:
+    """``w.index_select(dim, idx)`` kept in ONE persistent buffer that is refreshed in place whenever the source
+    parameter changes (its ``_version`` then moves too, so DerivedWeight caches keyed on the buffer notice)."""
+
+    def __init__(self, idx: np.ndarray, dim: int = 0):
+        self._idx = DeviceTables(idx=np.asarray(idx, dtype=np.int64))
+        self._dim = dim
+        self._key = None
+        self._buf = None
+
+    def get(self, w: torch.Tensor) -> torch.Tensor:
+        key = (w.data_ptr(), w._version, w.device, w.dtype)
+        if key != self._key:
+            with torch.no_grad():
+                new = w.detach().index_select(self._dim, self._idx.get("idx", w.device))
+                if self._buf is None or self._buf.device != w.device or self._buf.dtype != w.dtype:
+                    self._buf = new.contiguous()
+                else:
+                    self._buf.copy_(new)
+            self._key = key
+        return self._buf

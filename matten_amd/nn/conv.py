@@ -16,12 +16,15 @@ from .. import autograd as _ag
 from .. import ops
 from ..data.irreps import DataKey, ModuleIrreps
 from ..o3 import Irreps
-from ._tables import DerivedWeight, DeviceTables
+from ._tables import DerivedWeight, DeviceTables, WeightSlice
 from .utils import ActivationLayer, NormalizationLayer, SpeciesLinear, UVUTensorProduct
 
 
 import os as _os
 
+KEPT_ONLY = "_amd_kept_irreps_only"   # batch-dict marker: node_features hold the irreps of the inference view only
+# inference: skip the output irreps of the last conv layer nothing reads (PointConv.build_inference_view); 0 = run them
+DEAD_PATH_ELIMINATION = _os.environ.get("MATTEN_DEAD_PATH_ELIMINATION", "1") != "0"
 AGG_KM_MIN_ROWS = int(_os.environ.get("MATTEN_AGG_KM_MIN_ROWS", "8192"))   # nodes per batch from which lin2 streams component-major rows
 
 
@@ -37,6 +40,9 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         super().__init__()
         self.avg_num_neighbors = avg_num_neighbors
         self.init_irreps(irreps_in)
+        self.__dict__["_ctor"] = dict(irreps_in=dict(irreps_in), fc_num_hidden_layers=fc_num_hidden_layers,
+                                      fc_hidden_size=fc_hidden_size, avg_num_neighbors=avg_num_neighbors)
+        self.__dict__["_view"] = None   # inference view with fewer output irreps (build_inference_view)
         feats_in = self.irreps_in[DataKey.NODE_FEATURES]
         n_species = self.irreps_in[DataKey.NODE_ATTRS].dim
         edge_attrs = self.irreps_in[DataKey.EDGE_ATTRS]
@@ -167,7 +173,64 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         return ops.species_linear(agg_rest, species, self._fused_rest_w.get(self.lin2.weight), fp.rest.w_stride, metas,
                                   fp.d_out, add=out, fully_covered=True)
 
+    # ---- dead-output elimination (inference) ------------------------------------------------------------------------
+    def build_inference_view(self, kept_irreps) -> bool:
+        """When the consumer of this layer reads only SOME of its output irreps (the reference's last conv layer emits
+        all of conv_layer_irreps, model_factory/tfn_scalar_tensor.py:122-131, but the head that follows is an o3.Linear
+        onto 16x0e+2x2e+4e: every other output irrep, the tensor-product paths that end in it and their radial-weight
+        columns are computed and never read), an inference forward can run the layer for the kept irreps only.  The
+        view is a second PointConv planned for ``kept_irreps`` that owns NO parameters: lin1 and the hidden radial
+        layers are this layer's modules, the self-connection, lin2 and last radial layer read index-selected copies of
+        this layer's parameters (same instruction blocks, same fan-in normalisation: every path into a kept output is
+        kept).  Returns False (no view) when the irreps cannot be matched one to one."""
+        kept = Irreps(kept_irreps).simplify()
+        full_out = self.sc.irreps_out
+        if any(sum(1 for _, ir2 in irr if ir2 == ir) != 1 for irr in (full_out, self.lin2.irreps_in) for _, ir in irr):
+            return False
+        if any(sum(1 for m2, ir2 in full_out if ir2 == ir and m2 == m) != 1 for m, ir in kept) or kept.dim >= full_out.dim:
+            return False
+        try:
+            v = PointConv(conv_layer_irreps=kept, **self._ctor)
+        except Exception:  # noqa: BLE001  (e.g. no tensor-product path into the kept irreps)
+            return False
+
+        from .. import plan as _plan
+
+        m_sc, m_l2 = _plan.linear_flat_submap(v.sc.plan, self.sc.plan), _plan.linear_flat_submap(v.lin2.plan, self.lin2.plan)
+        fullp = {(q.i_in1, q.i_sh, q.l3, q.p3): q for q in self.tp.plan.paths}
+        cols = []
+        for q in v.tp.plan.paths:
+            f = fullp.get((q.i_in1, q.i_sh, q.l3, q.p3))
+            if f is None or f.mul != q.mul:
+                return False
+            cols.append(np.arange(f.w_off, f.w_off + f.mul))
+        if m_sc is None or m_l2 is None or not cols:
+            return False
+        v.lin1 = self.lin1
+        mlp = v.tp.weight_nn
+        mlp.layer0, mlp.layer1 = self.tp.weight_nn.layer0, self.tp.weight_nn.layer1
+        mlp.__dict__["_hidden_from"] = self.tp.weight_nn
+        for mod in (v.sc, v.lin2, mlp.layer2):
+            del mod._parameters["weight"]
+        v.__dict__["_slices"] = (WeightSlice(m_sc), WeightSlice(m_l2), WeightSlice(np.concatenate(cols), dim=1))
+        self.__dict__["_view"] = v
+        return True
+
+    def _view_forward(self, data):
+        v = self._view
+        s_sc, s_l2, s_w2 = v._slices
+        v.sc.weight = s_sc.get(self.sc.weight)
+        v.lin2.weight = s_l2.get(self.lin2.weight)
+        v.tp.weight_nn.layer2.weight = s_w2.get(self.tp.weight_nn.layer2.weight)
+        return v(data)
+
     def forward(self, data: DataKey.Type) -> DataKey.Type:
+        if (self._view is not None and DEAD_PATH_ELIMINATION
+                and not _ag.needs_grad(data[DataKey.NODE_FEATURES], *self.parameters())):
+            # the consumer (model_factory.eliminate_dead_outputs paired it with this layer) takes the kept irreps only
+            data = self._view_forward(data)
+            data[KEPT_ONLY] = True
+            return data
         x = data[DataKey.NODE_FEATURES]
         species = data[DataKey.AMD_SPECIES]
         fused = None if _ag.needs_grad(x, self.lin1.weight, self.sc.weight) else self._fused_lin1_sc_tables()

@@ -46,8 +46,32 @@ class NodewiseLinear(ModuleIrreps, torch.nn.Module):
         self.init_irreps(irreps_in=irreps_in, irreps_out={self.out_field: irreps_out},
                          required_keys_irreps_in=[self.field])
         self.linear = SpeciesLinear(self.irreps_in[field], None, self.irreps_out[self.out_field])
+        self.__dict__["_kept"] = None
+
+    def build_kept_input(self, kept_irreps) -> bool:
+        """the same linear for an input row that holds only ``kept_irreps`` (every irrep this linear reads): a second
+        plan whose flat weight is an index-selected copy of ``linear.weight`` (see PointConv.build_inference_view)"""
+        from .. import plan as _plan
+        from ._tables import WeightSlice
+
+        lin = SpeciesLinear(Irreps(kept_irreps), None, self.irreps_out[self.out_field])
+        idx = _plan.linear_flat_submap(lin.plan, self.linear.plan)
+        if idx is None or idx.size != self.linear.plan.weight_numel:   # it must read every weight the full one reads
+            return False
+        del lin._parameters["weight"]
+        self.__dict__["_kept"] = (lin, WeightSlice(idx))
+        return True
 
     def forward(self, data: DataKey.Type) -> DataKey.Type:
+        from .conv import KEPT_ONLY
+
+        if data.get(KEPT_ONLY, False):   # (the marker stays: node_features remain the kept irreps for whoever looks)
+            if self._kept is None or self.field != DataKey.NODE_FEATURES:
+                raise RuntimeError("node features were pruned for a consumer that has no kept-irreps plan")
+            lin, sl = self._kept
+            lin.weight = sl.get(self.linear.weight)
+            data[self.out_field] = lin(data[self.field])
+            return data
         data[self.out_field] = self.linear(data[self.field])
         return data
 

@@ -208,6 +208,9 @@ class RadialMLP(torch.nn.Module):
         if n_basis != self.hs[0]:
             raise ValueError(f"radial basis size {n_basis} != MLP input {self.hs[0]}")
         w0p, w1p, w2p = self._packed.get(self.layer0.weight, self.layer1.weight, self.layer2.weight)
+        src = self.__dict__.get("_hidden_from")
+        if src is not None:   # an inference view (nn/conv.py): the hidden layers ARE the full layer's (shared weights)
+            return src.hidden(geom_sorted, n_basis, r_start, r_end, data)[0], w2p
         group = radial_group_of(self)
         if data is not None and len(group) > 1 and os.environ.get("MATTEN_RADIAL_MULTI", "1") != "0":
             cache = data.get("_amd_h2s")

@@ -433,6 +433,7 @@ class LinearPlan:
     d_in: int = 0
     d_out: int = 0
     flops_per_row: int = 0
+    instr: List[Tuple[int, int, int, int]] = None   # (i_in, i_out, offset in the flat parameter, numel), reference order
 
 
 def _plan_linear_like(irreps_in: Irreps, irreps_out: Irreps, n_species: int, paths) -> LinearPlan:
@@ -447,8 +448,10 @@ def _plan_linear_like(irreps_in: Irreps, irreps_out: Irreps, n_species: int, pat
     scale_cols: List[np.ndarray] = []
     per_out: Dict[int, List[Tuple[int, int]]] = {}
     flops = 0
+    instr = []
     for i_in, i_out in paths:
         mi, mo = irreps_in[i_in].mul, irreps_out[i_out].mul
+        instr.append((i_in, i_out, flat, mi * n_species * mo))
         # flat index of W[u, s, w] = flat + (u*S + s)*mo + w ; packed index = packed + u*mo + w
         u = np.arange(mi)[:, None]
         w = np.arange(mo)[None, :]
@@ -516,7 +519,26 @@ def _plan_linear_like(irreps_in: Irreps, irreps_out: Irreps, n_species: int, pat
     gather = np.concatenate(gather_cols, axis=1) if gather_cols else np.zeros((n_species, 0), dtype=np.int64)
     scale = np.concatenate(scale_cols) if scale_cols else np.zeros(0, dtype=np.float32)
     return LinearPlan(irreps_in, irreps_out, n_species, flat, packed, gather.astype(np.int64), scale, passes,
-                      fully_covered, passes_t, perm_t, input_covered, irreps_in.dim, irreps_out.dim, flops)
+                      fully_covered, passes_t, perm_t, input_covered, irreps_in.dim, irreps_out.dim, flops, instr)
+
+
+def linear_flat_submap(view: LinearPlan, full: LinearPlan) -> Optional[np.ndarray]:
+    """Index map flat parameter of ``view`` <- flat parameter of ``full`` when every instruction of ``view`` is an
+    instruction of ``full`` between the same irreps with the same multiplicities (a plan for a subset of the input /
+    output irreps); None when the instructions cannot be matched one to one."""
+    table = {}
+    for i, o, off, n in full.instr:
+        key = (full.irreps_in[i].ir, full.irreps_out[o].ir)
+        if key in table:
+            return None
+        table[key] = (off, n, full.irreps_in[i].mul, full.irreps_out[o].mul)
+    idx = []
+    for i, o, off, n in view.instr:
+        f = table.get((view.irreps_in[i].ir, view.irreps_out[o].ir))
+        if f is None or f[1:] != (n, view.irreps_in[i].mul, view.irreps_out[o].mul):
+            return None
+        idx.append(np.arange(f[0], f[0] + n, dtype=np.int64))
+    return np.concatenate(idx) if idx else None
 
 
 def plan_fctp(irreps_in1, n_species: int, irreps_out) -> LinearPlan:

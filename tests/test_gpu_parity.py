@@ -280,13 +280,89 @@ def test_conv_layers_vs_oracle(hp_name):
     ref, model = build_pair(hp, ds, randomize_bn=True)
     cpu = collate(graphs)
     gpu = collate(graphs, device=DEV)
+    from matten_amd.nn import conv as pconv
+
     with torch.no_grad():
         for (name, rmod), (_, pmod) in zip(ref.backbone.named_children(), model.backbone.named_children()):
             cpu = rmod(cpu)
             gpu = pmod(gpu)
             if "node_features" in cpu:
-                close(gpu["node_features"], cpu["node_features"], RTOL, f"{hp_name}:{name}:node_features")
+                want = cpu["node_features"]
+                if gpu.get(pconv.KEPT_ONLY):   # the last conv layer ran for the irreps its consumer reads only
+                    want = want[:, _kept_columns(model.backbone._modules["conv_layer_last"])]
+                close(gpu["node_features"], want, RTOL, f"{hp_name}:{name}:node_features")
         close(gpu["my_model_output"], cpu["my_model_output"], RTOL, "pooled")
+
+
+def _kept_columns(conv):
+    """columns of the full output row of ``conv`` that its inference view emits, in the view's order"""
+    from matten_amd.data.irreps import DataKey
+
+    full = conv.irreps_out[DataKey.NODE_FEATURES]
+    offs = full.offsets()
+    cols = []
+    for m, ir in conv._view.sc.irreps_out:
+        (i,) = [i for i, (m2, ir2) in enumerate(full) if ir2 == ir and m2 == m]
+        cols += list(range(offs[i], offs[i] + m * ir.dim))
+    return torch.as_tensor(cols)
+
+
+@pytest.mark.parametrize("hp_name", ["paper", "lmax2"])
+def test_dead_output_elimination_matches_the_full_layer(hp_name, monkeypatch):
+    """Inference runs the last conv layer for the irreps the output head reads only (model_factory.eliminate_dead_outputs):
+    its node features equal the kept columns of the full layer's, the model output is unchanged, the full layer is
+    compared with the oracle column for column, and neither the parameters nor the state_dict know about the view."""
+    from matten_amd.data.graph import collate
+    from matten_amd.nn import conv as pconv
+
+    hp = {"paper": PAPER, "lmax2": LMAX2}[hp_name]
+    graphs, ds = _fcc(3)
+    ref, model = build_pair(hp, ds, randomize_bn=True)
+    last = model.backbone._modules["conv_layer_last"]
+    assert last._view is not None and not any("view" in k for k in model.state_dict())
+    assert sum(p.numel() for p in last._view.parameters()) == last.lin1.weight.numel() + sum(
+        getattr(last.tp.weight_nn, f"layer{i}").weight.numel() for i in (0, 1))   # shared modules only
+    kept = _kept_columns(last).to(DEV)
+    assert 0 < kept.numel() < last.irreps_out["node_features"].dim
+
+    def run(enabled):
+        monkeypatch.setattr(pconv, "DEAD_PATH_ELIMINATION", enabled)
+        data = collate(graphs, device=DEV)
+        with torch.no_grad():
+            for name, mod in model.backbone.named_children():
+                data = mod(data)
+                if name == "conv_layer_last":
+                    feats = data["node_features"].clone()
+                    assert bool(data.get(pconv.KEPT_ONLY, False)) == enabled
+        return feats, data["my_model_output"].clone()
+
+    f_on, out_on = run(True)
+    f_off, out_off = run(False)
+    assert f_on.shape == (f_off.shape[0], kept.numel()) and f_off.shape[1] == last.irreps_out["node_features"].dim
+    close(f_on, f_off[:, kept], 2e-6, "kept columns of the last conv layer")
+    close(out_on, out_off, 2e-6, "model output with / without dead-output elimination")
+    with torch.no_grad():
+        cpu = collate(graphs)
+        for name, rmod in ref.backbone.named_children():
+            cpu = rmod(cpu)
+            if name == "conv_layer_last":
+                close(f_off, cpu["node_features"], RTOL, "full last conv layer vs oracle")
+    # a parameter update reaches the view (index-selected copies follow the parameters' versions)
+    with torch.no_grad():
+        last.lin2.weight.mul_(1.5)
+        last.tp.weight_nn.layer2.weight.mul_(0.5)
+    f_on2, out_on2 = run(True)
+    f_off2, out_off2 = run(False)
+    close(f_on2, f_off2[:, kept], 2e-6, "kept columns after a parameter update")
+    assert (out_on2 - out_on).abs().max().item() > 0
+    # autograd always runs the full layer
+    monkeypatch.setattr(pconv, "DEAD_PATH_ELIMINATION", True)
+    model.train()
+    data = collate(graphs, device=DEV)
+    for name, mod in model.backbone.named_children():
+        data = mod(data)
+        if name == "conv_layer_last":
+            assert pconv.KEPT_ONLY not in data and data["node_features"].shape[1] == f_off.shape[1]
 
 
 def _run_pair(ref, model, graphs):
@@ -800,11 +876,18 @@ def test_config3_full_size_batch_properties():
     assert torch.equal(y, y_again)                                                   # (e)
 
     pick = [0, 1, 137, 500, 998, 999]
+    # (a) bitwise against another batch on the same kernel path (>= nn.conv.AGG_KM_MIN_ROWS nodes: lin2 streams
+    # component-major rows), to 2e-6 against the 6-crystal batch, whose lin2 runs on the row-resident kernel (same
+    # products, another summation order inside the matrix instructions' K loop)
+    mid_ids = sorted(set(pick) | set(range(300, 444)))
+    mid = batch_graphs_gpu([triples[i] for i in mid_ids], 5.0, DEV)
     small = batch_graphs_gpu([triples[i] for i in pick], 5.0, DEV)
     with torch.no_grad():
+        y_mid = model.decode(dict(mid))["elastic_tensor_full"]
         y_small = model.decode(dict(small))["elastic_tensor_full"]
         want = ref.decode(collate([crystal_graph(*triples[i], 5.0) for i in pick]))
-    assert torch.equal(y[pick], y_small)                                             # (a)
+    assert mid["pos"].shape[0] >= 8192 and torch.equal(y[mid_ids], y_mid)            # (a)
+    close_blocks(y[pick], y_small, rtol=2e-6, floor=2e-6, what="full-size batch vs the same crystals in a 6-crystal batch")
     close_blocks(y[pick], want, what="full-size batch vs oracle on 6 crystals",      # (b)
                  want64=_want64(ref, [crystal_graph(*triples[i], 5.0) for i in pick]))
 
@@ -825,13 +908,17 @@ def test_config3_full_size_batch_properties():
     close(t_rot, want_rot, 5e-4, "rotation equivariance of 1000 crystals")           # (d)
 
 
-def test_operands_beyond_4GB():
-    """Maximum sizes: with 4200 fcc-64 crystals the neighbour-sum output of the last conv layer is 4.5 GB, past the
-    4 GB a buffer descriptor / 32-bit byte offset can address (species_linear re-bases its descriptors per wave,
-    the TP kernels use 64-bit row offsets).  Property: predictions are bitwise those of a 4-crystal batch."""
+def test_operands_beyond_4GB(monkeypatch):
+    """Maximum sizes: with 4200 fcc-64 crystals the neighbour-sum output of the FULL last conv layer is 4.5 GB, past
+    the 4 GB a buffer descriptor / 32-bit byte offset can address (the lin2 kernels re-base their descriptors per wave,
+    the TP kernels use 64-bit row offsets); dead-output elimination is switched off here so that the full layer runs.
+    Property: predictions are bitwise those of a 150-crystal batch (same kernel path), and within 2e-6 of a 4-crystal
+    batch (row-resident lin2: another summation order)."""
     from matten_amd.data import synthetic
     from matten_amd.data.graph import batch_graphs_gpu
+    from matten_amd.nn import conv as pconv
 
+    monkeypatch.setattr(pconv, "DEAD_PATH_ELIMINATION", False)
     n = 4200
     uniq = synthetic.fcc64_structures(100)
     triples = [(uniq[i % 100]["cart_coords"], uniq[i % 100]["lattice"], uniq[i % 100]["atomic_numbers"]) for i in range(n)]
@@ -841,8 +928,11 @@ def test_operands_beyond_4GB():
     with torch.no_grad():
         y = model.decode(dict(batch_graphs_gpu(triples, 5.0, DEV)))["elastic_tensor_full"]
         pick = [0, 1, n // 2, n - 1]
+        mid_ids = sorted(set(pick) | set(range(1000, 1146)))
+        ym = model.decode(dict(batch_graphs_gpu([triples[i] for i in mid_ids], 5.0, DEV)))["elastic_tensor_full"]
         ys = model.decode(dict(batch_graphs_gpu([triples[i] for i in pick], 5.0, DEV)))["elastic_tensor_full"]
-    assert torch.isfinite(y).all() and torch.equal(y[pick], ys)
+    assert torch.isfinite(y).all() and torch.equal(y[mid_ids], ym)
+    close_blocks(y[pick], ys, rtol=2e-6, floor=2e-6, what="4200-crystal batch vs a 4-crystal batch")
     # copies of one crystal give identical rows wherever they sit in the batch
     assert torch.equal(y[0], y[100]) and torch.equal(y[7], y[4107])
 
@@ -900,7 +990,9 @@ def test_conv_fused_kernel_matches_two_kernel_path(monkeypatch):
     every 8-node group, a node count that is not a multiple of 8, per-node neighbour normalisation, and an isolated atom."""
     from matten_amd.data import synthetic
     from matten_amd.data.graph import collate, crystal_graph
+    from matten_amd.nn import conv as pconv
 
+    monkeypatch.setattr(pconv, "DEAD_PATH_ELIMINATION", False)   # all four layers at their full width
     lone = crystal_graph(np.array([[0.0, 0, 0], [1.5, 0, 0], [6.0, 6.0, 6.0]]), 12.0 * np.eye(3), [29, 79, 29], 5.0)
     lone_pair = crystal_graph(np.array([[0.0, 0, 0], [1.5, 0, 0], [2.5, 1.0, 0]]), 12.0 * np.eye(3), [29, 79, 29], 5.0)
     for avg in (18.0, None):
