@@ -384,12 +384,18 @@ int matten_adam_step(float* params, const float* grads, float* exp_avg, float* e
 /* the same adjoint with the literal-coefficient coupling code of the forward kernels (cg_gen.h): a thread owns (edge,
  * channel of one input block) and walks the block's paths; one atomic per (edge, channel, component) into dx.
  *   blocks[n_blocks,4] int32 {x_off, mul, l1, first path | n_paths << 16}; paths[n_paths,4] {l1*25+l2*5+l3, w_off, out_off, 0};
- *   max_mul = the largest mul of a block (sizes the launch); w_edge / dw fp32, or both bf16 when edge_is_bf16 */
+ *   max_mul = the largest mul of a block (sizes the launch); w_edge / dw fp32, or both bf16 when edge_is_bf16
+ * dx: two modes.  dx_edges == NULL: dx [N, d_in] zero-initialised, contributions meet through fp32 atomics (order not
+ * fixed).  dx_edges != NULL (scratch [E, d_in]; every input block's columns are written, columns of input irreps without
+ * a path must be zero on entry): each edge's contribution is stored and dx[n] = the sum over the edges leaving n in the
+ * order of out_perm[out_ptr[n] .. out_ptr[n+1]) -- sorted-edge indices grouped by source node (the CSR of src_sorted:
+ * matten_csr_build on it) -- bitwise reproducible; dx [n_nodes, d_in] need not be initialised. */
 int matten_tp_backward_lit(const float* x, int64_t d_in, const void* w_edge, int64_t w_ld, const float* sh_sorted,
                            int64_t sh_stride, const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* blocks,
                            int64_t n_blocks, int64_t max_mul, const int32_t* paths, int64_t n_paths, const float* g_agg,
                            int64_t d_mid, float avg_num_neighbors, const float* num_neigh, int64_t n_edges, float* dx,
-                           void* dw, int64_t dw_ld, int edge_is_bf16, matten_stream_t stream);
+                           void* dw, int64_t dw_ld, int edge_is_bf16, int64_t n_nodes, const int32_t* out_ptr,
+                           const int32_t* out_perm, float* dx_edges, matten_stream_t stream);
 
 /* adjoint of matten_species_linear w.r.t. the packed weights (the adjoint w.r.t. x is matten_species_linear
  * itself with the transposed segment table and transposed packed weights):
@@ -401,7 +407,8 @@ int matten_species_linear_wgrad(const float* x, int64_t d_in, const float* dy, i
                                 const int32_t* seg, int64_t n_species, int64_t n_rows, const int32_t* segs,
                                 int64_t n_segs, int64_t w_stride, float* dwp, float* partial, matten_stream_t stream);
 
-/* adjoint of the Gate part of matten_gate_bn (bn_weight == NULL forward); dx zero-initialised */
+/* adjoint of the Gate part of matten_gate_bn (bn_weight == NULL forward); every column of dx is written (no atomics:
+ * a gate's gradient is summed over its channel's components in order) */
 int matten_gate_bwd(const float* x, int64_t d_in, const int32_t* meta, int64_t d_out, const float* act_cst,
                     const float* dy, int64_t n_rows, float* dx, matten_stream_t stream);
 

@@ -111,6 +111,7 @@ class TensorProductScatterFn(torch.autograd.Function):
         p = mod.plan
         ctx.mod, ctx.avg, ctx.num_neigh = mod, avg, num_neigh
         ctx.graph = (data[DataKey.AMD_SH], data[DataKey.AMD_SRC], data["_amd_dst_sorted"])
+        ctx.out_csr = data.get("_amd_out_csr")
         ctx.save_for_backward(x, w_edge)
         return ops.tp_paths(x, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
                             mod._tables.get("entries", dev), mod._tables.get("unit_start", dev), p.units_per_tile,
@@ -123,9 +124,13 @@ class TensorProductScatterFn(torch.autograd.Function):
         sh, src, dst = ctx.graph
         impl = os.environ.get("MATTEN_TP_BWD", "lit")   # "lit": literal-coefficient kernel; "table": the table-driven ones
         if impl == "lit":
+            # dx summed per source node in a fixed order (MATTEN_TP_BWD_DX=atomic: fp32 atomics, order not fixed)
+            out_csr = ctx.out_csr if os.environ.get("MATTEN_TP_BWD_DX", "ordered") != "atomic" else None
             dx, dw = ops.tp_backward_lit(x, w_edge, sh, src, dst, mod._tables.get("bw_blocks", dev),
                                          mod._tables.get("bw_paths", dev), mod.plan.bw_max_mul, g.contiguous(), ctx.avg,
-                                         ctx.num_neigh)
+                                         ctx.num_neigh, out_csr=out_csr,
+                                         blocks_cover_input=int(mod.plan.bw_blocks[:, 1].dot(2 * mod.plan.bw_blocks[:, 2] + 1))
+                                         == mod.plan.d_in)
             return dx, dw, None, None, None, None
         dx, dw = ops.tp_backward(x, w_edge, sh, src, dst, mod._tables.get("bw_col_meta", dev),
                                  mod._tables.get("bw_nnz_ijk", dev), mod._tables.get("bw_nnz_c", dev), g.contiguous(),

@@ -318,7 +318,14 @@ __global__ void gate_bwd_kernel(const float* __restrict__ x, int d_in, const int
         const float a = gact ? act_f(gact, gt) * act_cst[gact] : gt;
         const float da = gact ? act_df(gact, gt) * act_cst[gact] : 1.0f;
         dxr[m.x] = g * a;
-        atomicAdd(dxr + m.y, g * v * da);  // 2l+1 components share one gate
+        // the 2l+1 components of a gated channel share one gate (and no other channel uses it): the thread of the first
+        // component sums the channel's terms in component order -- a plain store, no atomics, every input column written
+        if (o == 0 || meta[o - 1].y != m.y) {
+            float sum = 0.0f;
+            for (int kk = 0; o + kk < d_out && meta[o + kk].y == m.y; ++kk) sum = fmaf(dy[idx + kk], xr[meta[o + kk].x], sum);
+            dxr[m.y] = sum * da;
+        }
+        (void)v;
     }
 }
 
@@ -514,7 +521,7 @@ extern "C" int matten_species_linear_wgrad(const float* x, int64_t d_in, const f
 }
 
 extern "C" int matten_gate_bwd(const float* x, int64_t d_in, const int32_t* meta, int64_t d_out, const float* act_cst,
-                               const float* dy, int64_t n_rows, float* dx /*zero-initialised*/, matten_stream_t stream_) {
+                               const float* dy, int64_t n_rows, float* dx /*every column written*/, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows < 0 || d_in <= 0 || d_out <= 0) return MATTEN_EINVAL;
     if (n_rows == 0) return MATTEN_OK;
@@ -590,11 +597,12 @@ struct LitArgs {
     const int32_t* dst;
     const float* g_agg;
     const float* num_neigh;
-    float* dx;
+    float* dx;          // [N, d_in] accumulated with atomics, or (dx_per_edge) [E, d_in]: row e = edge e's contribution
     void* dw;
     int64_t E;
     int d_in, w_ld, sh_stride, d_mid, dw_ld, edge_bf16;
     float avg_nn;
+    int dx_per_edge;
 };
 
 template <int L1, int L2, int L3>
@@ -646,10 +654,12 @@ __device__ __forceinline__ void lit_block_0(const LitArgs& a, const int4 blk, co
             default: break;
         }
     }
-    float* dxp = a.dx + (int64_t)src * a.d_in + blk.x + u * D1;
+    float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
 #pragma unroll
-    for (int i = 0; i < D1; ++i)
-        if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    for (int i = 0; i < D1; ++i) {
+        if (a.dx_per_edge) dxp[i] = norm * dxi[i];   // summed per source node in a fixed order by rows_segment_sum_kernel
+        else if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    }
 }
 
 
@@ -675,10 +685,12 @@ __device__ __forceinline__ void lit_block_1(const LitArgs& a, const int4 blk, co
             default: break;
         }
     }
-    float* dxp = a.dx + (int64_t)src * a.d_in + blk.x + u * D1;
+    float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
 #pragma unroll
-    for (int i = 0; i < D1; ++i)
-        if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    for (int i = 0; i < D1; ++i) {
+        if (a.dx_per_edge) dxp[i] = norm * dxi[i];   // summed per source node in a fixed order by rows_segment_sum_kernel
+        else if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    }
 }
 
 
@@ -704,10 +716,12 @@ __device__ __forceinline__ void lit_block_2(const LitArgs& a, const int4 blk, co
             default: break;
         }
     }
-    float* dxp = a.dx + (int64_t)src * a.d_in + blk.x + u * D1;
+    float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
 #pragma unroll
-    for (int i = 0; i < D1; ++i)
-        if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    for (int i = 0; i < D1; ++i) {
+        if (a.dx_per_edge) dxp[i] = norm * dxi[i];   // summed per source node in a fixed order by rows_segment_sum_kernel
+        else if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    }
 }
 
 
@@ -733,10 +747,12 @@ __device__ __forceinline__ void lit_block_3(const LitArgs& a, const int4 blk, co
             default: break;
         }
     }
-    float* dxp = a.dx + (int64_t)src * a.d_in + blk.x + u * D1;
+    float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
 #pragma unroll
-    for (int i = 0; i < D1; ++i)
-        if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    for (int i = 0; i < D1; ++i) {
+        if (a.dx_per_edge) dxp[i] = norm * dxi[i];   // summed per source node in a fixed order by rows_segment_sum_kernel
+        else if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    }
 }
 
 
@@ -762,15 +778,29 @@ __device__ __forceinline__ void lit_block_4(const LitArgs& a, const int4 blk, co
             default: break;
         }
     }
-    float* dxp = a.dx + (int64_t)src * a.d_in + blk.x + u * D1;
+    float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
 #pragma unroll
-    for (int i = 0; i < D1; ++i)
-        if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    for (int i = 0; i < D1; ++i) {
+        if (a.dx_per_edge) dxp[i] = norm * dxi[i];   // summed per source node in a fixed order by rows_segment_sum_kernel
+        else if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
+    }
 }
 
 }  // namespace
 
 namespace {
+// out[n, c] = sum over k in [ptr[n], ptr[n+1]) of rows[perm[k], c], in k order (fixed: no atomics)
+__global__ void rows_segment_sum_kernel(const float* __restrict__ rows, int d, const int32_t* __restrict__ ptr,
+                                        const int32_t* __restrict__ perm, int64_t n_seg, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_seg * d) return;
+    const int64_t n = idx / d;
+    const int c = (int)(idx - n * d);
+    float acc = 0.0f;
+    for (int k = ptr[n]; k < ptr[n + 1]; ++k) acc += rows[(int64_t)perm[k] * d + c];
+    out[idx] = acc;
+}
+
 __global__ __launch_bounds__(256) void tp_backward_lit_kernel(LitArgs a, const int4* __restrict__ blocks,
                                                               const int4* __restrict__ paths) {
     const int4 blk = blocks[blockIdx.y];
@@ -796,12 +826,20 @@ extern "C" int matten_tp_backward_lit(const float* x, int64_t d_in, const void* 
                                       const int32_t* blocks, int64_t n_blocks, int64_t max_mul, const int32_t* paths,
                                       int64_t n_paths, const float* g_agg, int64_t d_mid, float avg_num_neighbors,
                                       const float* num_neigh, int64_t n_edges, float* dx, void* dw, int64_t dw_ld,
-                                      int edge_is_bf16, matten_stream_t stream_) {
+                                      int edge_is_bf16, int64_t n_nodes, const int32_t* out_ptr, const int32_t* out_perm,
+                                      float* dx_edges, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || d_in <= 0 || n_blocks <= 0 || n_blocks > 65535 || n_paths <= 0 || d_mid <= 0 || max_mul <= 0 ||
         max_mul > 4096 || w_ld <= 0 || dw_ld <= 0)
         return MATTEN_EINVAL;
-    if (n_edges == 0) return MATTEN_OK;
+    if (dx_edges && (!out_ptr || !out_perm || n_nodes < 0)) return MATTEN_EINVAL;
+    if (n_edges == 0) {
+        if (dx_edges && n_nodes > 0) {
+            if (!dx) return MATTEN_EINVAL;
+            if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n_nodes * (size_t)d_in, stream) != hipSuccess) return MATTEN_ELAUNCH;
+        }
+        return MATTEN_OK;
+    }
     if (!x || !w_edge || !sh_sorted || !src_sorted || !dst_sorted || !blocks || !paths || !g_agg || !dx || !dw)
         return MATTEN_EINVAL;
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
@@ -809,11 +847,17 @@ extern "C" int matten_tp_backward_lit(const float* x, int64_t d_in, const void* 
     while (cu < max_mul) cu <<= 1;
     const int64_t gx = matten_cdiv(n_edges * cu, 256);
     if (gx >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
-    LitArgs a{x, w_edge, sh_sorted, src_sorted, dst_sorted, g_agg, num_neigh, dx, dw, n_edges, (int)d_in, (int)w_ld,
-              (int)sh_stride, (int)d_mid, (int)dw_ld, edge_is_bf16, avg_num_neighbors};
+    LitArgs a{x, w_edge, sh_sorted, src_sorted, dst_sorted, g_agg, num_neigh, dx_edges ? dx_edges : dx, dw, n_edges, (int)d_in,
+              (int)w_ld, (int)sh_stride, (int)d_mid, (int)dw_ld, edge_is_bf16, avg_num_neighbors, dx_edges ? 1 : 0};
     tp_backward_lit_kernel<<<dim3((unsigned)gx, (unsigned)n_blocks), 256, 0, stream>>>(a, (const int4*)blocks,
                                                                                       (const int4*)paths);
     MATTEN_LAUNCH_CHECK();
+    if (dx_edges && n_nodes > 0) {
+        if (matten_cdiv(n_nodes * d_in, 256) >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+        rows_segment_sum_kernel<<<(unsigned)matten_cdiv(n_nodes * d_in, 256), 256, 0, stream>>>(dx_edges, (int)d_in, out_ptr,
+                                                                                              out_perm, n_nodes, dx);
+        MATTEN_LAUNCH_CHECK();
+    }
     return MATTEN_OK;
 }
 

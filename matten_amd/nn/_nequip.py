@@ -75,6 +75,12 @@ def ensure_training_edge_tensors(data: DataKey.Type) -> DataKey.Type:
         ensure_edge_geometry(data)
         perm = data[DataKey.AMD_PERM].long()
         data["_amd_dst_sorted"] = data[DataKey.EDGE_INDEX][1][perm].to(torch.int32).contiguous()
+        # the sorted edges grouped by SOURCE node (stable): the order in which dL/dx is summed per node -- the CSR builder
+        # keyed on the source column of the destination-sorted list (its "source" output is not used)
+        src = data[DataKey.AMD_SRC].long()
+        pairs = torch.stack([src, src])
+        out_perm, out_ptr, _, _ = ops.csr_build(pairs, int(data[DataKey.POSITIONS].shape[0]))
+        data["_amd_out_csr"] = (out_ptr, out_perm)
     return data
 
 

@@ -618,16 +618,24 @@ def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk,
 
 
 def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths, max_mul: int, g_agg,
-                    avg_num_neighbors: float, num_neigh=None):
+                    avg_num_neighbors: float, num_neigh=None, out_csr=None, blocks_cover_input: bool = True):
     """the adjoint of tp_backward with literal-coefficient coupling code (include/matten_hip.h matten_tp_backward_lit;
-    tables plan.bw_blocks / bw_paths) -> (dx [N,d_in], dw [E, ld of w_edge])"""
+    tables plan.bw_blocks / bw_paths) -> (dx [N,d_in], dw [E, ld of w_edge]).
+    out_csr = (out_ptr [N+1] i32, out_perm [E] i32): sorted-edge indices grouped by SOURCE node -- dx is then summed per
+    node in that fixed order (bitwise reproducible) instead of through atomics."""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
     w_edge = _edge_dtype(w_edge, "w_edge")
     g_agg = _need(g_agg, torch.float32, "grad agg")
     N, d_in = x.shape
     E = w_edge.shape[0]
-    dx = torch.zeros(N, d_in, dtype=torch.float32, device=x.device)
+    if out_csr is not None:
+        out_ptr, out_perm = (_need(t, torch.int32, n) for t, n in zip(out_csr, ("out_ptr", "out_perm")))
+        dx = torch.empty(N, d_in, dtype=torch.float32, device=x.device)
+        dx_edges = (torch.empty if blocks_cover_input else torch.zeros)(E, d_in, dtype=torch.float32, device=x.device)
+    else:
+        out_ptr = out_perm = dx_edges = None
+        dx = torch.zeros(N, d_in, dtype=torch.float32, device=x.device)
     # columns no path writes (the pad up to the row stride) must not hold NaN for the MLP adjoint's masked reads: they are
     # masked by a select there, so plain empty storage is fine
     dw = torch.empty(E, w_edge.shape[1], dtype=w_edge.dtype, device=x.device)
@@ -638,7 +646,8 @@ def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths,
                                         _ptr(src_sorted), _ptr(dst_sorted), _ptr(blocks), blocks.shape[0], int(max_mul),
                                         _ptr(paths), paths.shape[0], _ptr(g_agg), g_agg.shape[1],
                                         float(avg_num_neighbors or 0.0), _ptr(num_neigh), E, _ptr(dx), _ptr(dw),
-                                        dw.shape[1], int(w_edge.dtype == torch.bfloat16), _stream())
+                                        dw.shape[1], int(w_edge.dtype == torch.bfloat16), N, _ptr(out_ptr), _ptr(out_perm),
+                                        _ptr(dx_edges), _stream())
     _lib.check(rc, "matten_tp_backward_lit")
     return dx, dw
 
@@ -667,7 +676,7 @@ def gate_bwd(x, meta, act_cst, dy) -> torch.Tensor:
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
     dy = _need(dy, torch.float32, "dy")
-    dx = torch.zeros_like(x)
+    dx = torch.empty_like(x)   # every input column (scalars, gates, gated) is written exactly once
     _lib.check(lib.matten_gate_bwd(_ptr(x), x.shape[1], _ptr(meta), meta.shape[0], _ptr(act_cst), _ptr(dy), x.shape[0],
                                    _ptr(dx), _stream()), "matten_gate_bwd")
     return dx

@@ -403,3 +403,28 @@ def test_species_linear_gradients_vs_oracle_autograd(irreps_in, irreps_out, S, N
     ref(xr, torch.nn.functional.one_hot(species.cpu(), S).double()).backward(gy.cpu().double())
     _close(grads[0][0], ref.weight.grad, 3e-6, "dL/dweight")
     _close(grads[0][1], xr.grad, 3e-6, "dL/dx")
+
+
+def test_training_gradients_are_bitwise_reproducible(golden_dir):
+    """No atomics on the step: dL/dx of the tensor product is summed per source node in a fixed order (the CSR of the
+    source column), weight gradients and the radial MLP's adjoint are ordered partial sums -- two evaluations of the same
+    batch give bit-identical gradients (with MATTEN_TP_BWD_DX=atomic they differ in the last bits)."""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _graphs(golden_dir, 24)
+    _, model = build_pair(LMAX2, ds, randomize_bn=True)
+    model.train()
+    target = torch.randn(len(graphs), 21, generator=torch.Generator().manual_seed(5)).to(DEV)
+    runs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        bn = copy.deepcopy({k: v.clone() for k, v in model.named_buffers()})
+        preds, _ = model(collate(graphs, device=DEV))
+        torch.nn.functional.mse_loss(preds["elastic_tensor_full"], target).backward()
+        runs.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        with torch.no_grad():   # same BatchNorm running statistics for the second evaluation
+            for k, v in model.named_buffers():
+                v.copy_(bn[k])
+    assert runs[0].keys() == runs[1].keys() and len(runs[0]) > 20
+    diff = [k for k in runs[0] if not torch.equal(runs[0][k], runs[1][k])]
+    assert not diff, diff
