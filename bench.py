@@ -609,7 +609,7 @@ def run_rank(args):
                     "conv_to_output_hidden_irreps_out) takes; the other output irreps, the tensor-product paths that end in "
                     "them and their radial-weight columns are dead code in the reference graph "
                     "(model_factory/tfn_scalar_tensor.py:122-139).  Same model output (tests: "
-                    "test_dead_output_elimination_matches_the_full_layer), parameters / training / checkpoints untouched; "
+                    "test_dead_output_elimination_matches_the_full_layer), same gradients (dead weights: exact zeros), parameters / checkpoints untouched; "
                     "MATTEN_DEAD_PATH_ELIMINATION=0 runs the full layer",
             "last_conv_layer": {"irreps_out_full": str(lastf.sc.irreps_out), "irreps_out_run": str(laste.sc.irreps_out),
                                 "weight_columns_full": lastf.tp.plan.weight_numel, "weight_columns_run": laste.tp.plan.weight_numel,

@@ -95,7 +95,8 @@ def eliminate_dead_outputs(backbone) -> None:
     irreps it also emits: with the paper's hyper-parameters 66 % of that layer's neighbour-sum row, 69 % of its radial
     weight columns and the matching lin2 / self-connection blocks are computed and never read.  A bare PointConv
     directly followed by the only reader of its node features gets an inference view for the irreps that reader
-    takes (PointConv.build_inference_view); training (autograd) always runs the full layer, so parameters, gradients
+    takes (PointConv.build_inference_view); under autograd the view reads index_select slices of the parameters, so the
+    kept blocks get their gradients and dead weights exact zeros (what the reference's autograd gives them); parameters
     and checkpoints are untouched.  MATTEN_DEAD_PATH_ELIMINATION=0 switches it off."""
     from ..data.irreps import DataKey
 

@@ -44,10 +44,19 @@ class WeightSlice:
     parameter changes (its ``_version`` then moves too, so DerivedWeight caches keyed on the buffer notice)."""
 
     def __init__(self, idx: np.ndarray, dim: int = 0):
-        self._idx = DeviceTables(idx=np.asarray(idx, dtype=np.int64))
+        idx = np.asarray(idx, dtype=np.int64)
+        self._idx = DeviceTables(idx=idx)
         self._dim = dim
         self._key = None
         self._buf = None
+        self._n = int(idx.size)
+        self._identity = bool(idx.size and (idx == np.arange(idx.size)).all())
+
+    def select(self, w: torch.Tensor) -> torch.Tensor:
+        """the same slice inside autograd (training): gradients flow back to ``w``, zeros where nothing was selected"""
+        if self._identity and w.shape[self._dim] == self._n:
+            return w
+        return w.index_select(self._dim, self._idx.get("idx", w.device))
 
     def get(self, w: torch.Tensor) -> torch.Tensor:
         key = (w.data_ptr(), w._version, w.device, w.dtype)

@@ -216,19 +216,29 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         self.__dict__["_view"] = v
         return True
 
-    def _view_forward(self, data):
+    def _view_forward(self, data, differentiable: bool):
         v = self._view
         s_sc, s_l2, s_w2 = v._slices
-        v.sc.weight = s_sc.get(self.sc.weight)
-        v.lin2.weight = s_l2.get(self.lin2.weight)
-        v.tp.weight_nn.layer2.weight = s_w2.get(self.tp.weight_nn.layer2.weight)
-        return v(data)
+        # inference: cached copies that follow the parameters' versions; under autograd: index_select nodes, so the kept
+        # blocks' gradients reach the layer's parameters and everything else gets exact zeros -- what the reference's
+        # autograd gives the weights of paths that never reach the loss
+        pick = (lambda sl, w: sl.select(w)) if differentiable else (lambda sl, w: sl.get(w))
+        # (plain instance attributes: Module.__setattr__ would register a Parameter that select() hands back unchanged)
+        targets = ((v.sc, s_sc, self.sc.weight), (v.lin2, s_l2, self.lin2.weight),
+                   (v.tp.weight_nn.layer2, s_w2, self.tp.weight_nn.layer2.weight))
+        for mod, sl, w in targets:
+            mod.__dict__["weight"] = pick(sl, w)
+        try:
+            return v(data)
+        finally:
+            if differentiable:   # do not keep autograd graphs alive through module attributes
+                for mod, _, _ in targets:
+                    mod.__dict__["weight"] = None
 
     def forward(self, data: DataKey.Type) -> DataKey.Type:
-        if (self._view is not None and DEAD_PATH_ELIMINATION
-                and not _ag.needs_grad(data[DataKey.NODE_FEATURES], *self.parameters())):
+        if self._view is not None and DEAD_PATH_ELIMINATION:
             # the consumer (model_factory.eliminate_dead_outputs paired it with this layer) takes the kept irreps only
-            data = self._view_forward(data)
+            data = self._view_forward(data, _ag.needs_grad(data[DataKey.NODE_FEATURES], *self.parameters()))
             data[KEPT_ONLY] = True
             return data
         x = data[DataKey.NODE_FEATURES]

@@ -69,8 +69,14 @@ class NodewiseLinear(ModuleIrreps, torch.nn.Module):
             if self._kept is None or self.field != DataKey.NODE_FEATURES:
                 raise RuntimeError("node features were pruned for a consumer that has no kept-irreps plan")
             lin, sl = self._kept
-            lin.weight = sl.get(self.linear.weight)
-            data[self.out_field] = lin(data[self.field])
+            w = self.linear.weight
+            grad = torch.is_grad_enabled() and (w.requires_grad or data[self.field].requires_grad)
+            lin.__dict__["weight"] = sl.select(w) if grad else sl.get(w)   # (not via Module.__setattr__: select() may return the Parameter)
+            try:
+                data[self.out_field] = lin(data[self.field])
+            finally:
+                if grad:
+                    lin.__dict__["weight"] = None
             return data
         data[self.out_field] = self.linear(data[self.field])
         return data

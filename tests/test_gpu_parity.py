@@ -355,14 +355,33 @@ def test_dead_output_elimination_matches_the_full_layer(hp_name, monkeypatch):
     f_off2, out_off2 = run(False)
     close(f_on2, f_off2[:, kept], 2e-6, "kept columns after a parameter update")
     assert (out_on2 - out_on).abs().max().item() > 0
-    # autograd always runs the full layer
-    monkeypatch.setattr(pconv, "DEAD_PATH_ELIMINATION", True)
+    # under autograd the view runs too (index_select nodes): the kept blocks' gradients equal the full layer's, the
+    # weights of paths that never reach the loss get exact zeros -- as from the reference's autograd
     model.train()
-    data = collate(graphs, device=DEV)
-    for name, mod in model.backbone.named_children():
-        data = mod(data)
-        if name == "conv_layer_last":
-            assert pconv.KEPT_ONLY not in data and data["node_features"].shape[1] == f_off.shape[1]
+    target = torch.randn(len(graphs), 21, generator=torch.Generator().manual_seed(2)).to(DEV)
+    grads = {}
+    for enabled in (True, False):
+        monkeypatch.setattr(pconv, "DEAD_PATH_ELIMINATION", enabled)
+        model.zero_grad(set_to_none=True)
+        bufs = {k: v.clone() for k, v in model.named_buffers()}
+        data = collate(graphs, device=DEV)
+        for name, mod in model.backbone.named_children():
+            data = mod(data)
+            if name == "conv_layer_last":
+                assert bool(data.get(pconv.KEPT_ONLY, False)) == enabled
+                assert data["node_features"].shape[1] == (kept.numel() if enabled else f_off.shape[1])
+        out = model.extra_layers_dict["out_layer"](data["my_model_output"])
+        torch.nn.functional.mse_loss(out, target).backward()
+        grads[enabled] = {k: p.grad.clone() for k, p in model.named_parameters()}
+        with torch.no_grad():
+            for k, v in model.named_buffers():
+                v.copy_(bufs[k])
+    assert grads[True].keys() == grads[False].keys()
+    for k in grads[True]:
+        close(grads[True][k], grads[False][k], 2e-5, f"grad {k} with / without dead-output elimination")
+    w2 = grads[True]["backbone.conv_layer_last.tp.weight_nn.layer2.weight"]
+    dead = (grads[False]["backbone.conv_layer_last.tp.weight_nn.layer2.weight"] == 0).all(dim=0)
+    assert 0 < int(dead.sum()) < w2.shape[1] and bool((w2[:, dead] == 0).all())
 
 
 def _run_pair(ref, model, graphs):
