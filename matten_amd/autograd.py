@@ -32,6 +32,26 @@ class PackWeightsFn(torch.autograd.Function):
         return ops.gather_scale(g.contiguous(), inverse, scale, scale_by_source=True), None, None, None
 
 
+class SpeciesEmbedFn(torch.autograd.Function):
+    """node features of the one-hot embedding, ``feats`` as the species_embed kernel computed them; the adjoint sums the
+    incoming gradient per species with the weight-gradient kernel of the species linear (input = the constant 1:
+    dWp[s, w] = sum over the species' rows of dy[n, w]; ordered partial sums, no atomics, no index sort)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, feats, species_order, segs):
+        ctx.species_order, ctx.segs = species_order, segs   # segs: int32 [[0, 1, 1, 0, dim, 0, 0, 0]] on the device
+        ctx.n_species = weight.shape[1]
+        return feats.view_as(feats)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        n, dim = g.shape
+        ones = torch.ones(n, 1, dtype=torch.float32, device=g.device)
+        per_species = ops.species_linear_wgrad(ones, g, ctx.species_order, ctx.n_species, [ctx.segs], dim)   # [S, dim]
+        return per_species.t(), per_species.sum(0), None, None, None
+
+
 class SpeciesLinearFn(torch.autograd.Function):
     """out = add + x W_species  (matten_species_linear); adjoints: same kernel with W^T, and the weight-gradient kernel."""
 

@@ -10,6 +10,7 @@ Input embeddings of the backbone on MI355X.
 """
 from typing import Dict, List, Tuple
 
+import numpy as np
 import torch
 
 from .. import ops
@@ -177,8 +178,16 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
         if attrs is not None:
             data[DataKey.NODE_ATTRS] = attrs
         if torch.is_grad_enabled() and self.linear.weight.requires_grad:
-            # training path: Linear(one_hot) == column lookup + bias (library indexing, differentiable)
-            feats = self.linear.weight.t()[sidx.clamp(min=0)] + self.linear.bias
+            # training path: the same kernel output; the adjoint sums the gradient per species (autograd.SpeciesEmbedFn)
+            from ..autograd import SpeciesEmbedFn
+
+            if self.__dict__.get("_wgrad_segs") is None:
+                from ._tables import DeviceTables
+
+                dim = self.linear.weight.shape[0]
+                self.__dict__["_wgrad_segs"] = DeviceTables(segs=np.array([[0, 1, 1, 0, dim, 0, 0, 0]], dtype=np.int32))
+            feats = SpeciesEmbedFn.apply(self.linear.weight, self.linear.bias, feats, (order, seg),
+                                         self._wgrad_segs.get("segs", feats.device))
         data[DataKey.NODE_FEATURES] = feats
         return data
 
