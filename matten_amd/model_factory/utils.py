@@ -56,7 +56,7 @@ def validate_hparams(hparams: Dict, dataset_hparams: Dict = None) -> None:
       nonlinearity_type         gate                            (nn/utils.py:96-140)
       normalization             batch | none                    (nn/utils.py:414-418)
       reduce                    mean | sum                      (nn/nodewise.py:142-148)
-      use_atom_feats            false                           (nn/embedding.py:96-108)
+      use_atom_feats            false | true (data['atom_feats'] [n_atoms, atom_feats_size])   (nn/embedding.py:59-68,103-105)
       dataset_hparams           allowed_species given
     """
     from ..o3 import Irreps
@@ -83,8 +83,8 @@ def validate_hparams(hparams: Dict, dataset_hparams: Dict = None) -> None:
         problems.append(f"normalization={norm!r}: only 'batch' or none")
     if str(hparams.get("reduce", "mean")).lower() not in ("mean", "sum"):
         problems.append(f"reduce={hparams['reduce']!r}: only 'mean' or 'sum'")
-    if hparams.get("use_atom_feats", False):
-        problems.append("use_atom_feats=True: extra per-atom input features are not implemented")
+    if hparams.get("use_atom_feats", False) and dataset_hparams is not None and not dataset_hparams.get("atom_feats_size"):
+        problems.append("use_atom_feats=True needs dataset_hparams['atom_feats_size'] (reference nn/embedding.py:60-64)")
     if dataset_hparams is not None and not dataset_hparams.get("allowed_species"):
         problems.append("dataset_hparams['allowed_species'] is required")
     if problems:

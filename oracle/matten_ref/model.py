@@ -44,7 +44,9 @@ def create_model(hparams: Dict[str, Any], dataset_hparams: Dict[str, Any], atomi
     layers = {
         "one_hot": (
             rnn.SpeciesEmbedding,
-            {"embedding_dim": hparams["species_embedding_dim"], "allowed_species": dataset_hparams["allowed_species"]},
+            {"embedding_dim": hparams["species_embedding_dim"], "allowed_species": dataset_hparams["allowed_species"],
+             "use_atom_feats": hparams.get("use_atom_feats", False),
+             "atom_feats_dim": dataset_hparams.get("atom_feats_size", None)},
         ),
         "spharm_edges": (rnn.SphericalHarmonicEdgeAttrs, {"irreps_edge_sh": hparams["irreps_edge_sh"]}),
         "radial_basis": (

@@ -149,16 +149,21 @@ class _AtomicNumberToIndex(torch.nn.Module):
 
 
 class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
-    """nn/embedding.py:12-110 (use_atom_feats=False branch)"""
+    """nn/embedding.py:12-110 (use_atom_feats: :59-68 feature width, :103-105 hstack with data["atom_feats"])"""
 
-    def __init__(self, irreps_in=None, embedding_dim: int = 16, allowed_species: List[int] = None, **_ignored):
+    def __init__(self, irreps_in=None, embedding_dim: int = 16, allowed_species: List[int] = None,
+                 use_atom_feats: bool = False, atom_feats_dim: int = None, **_ignored):
         super().__init__()
         self.embedding_dim = embedding_dim
+        self.use_atom_feats = use_atom_feats
         self.atomic_number_to_index = _AtomicNumberToIndex(allowed_species)
         self.num_species = int(self.atomic_number_to_index.num_species)
+        if use_atom_feats and atom_feats_dim is None:
+            raise ValueError("`atom_feats_dim` must be provided if `use_atom_feats` is True.")
+        feats_dim = embedding_dim + (atom_feats_dim if use_atom_feats else 0)
         irreps_out = {
             DataKey.NODE_ATTRS: Irreps(f"{self.num_species}x0e"),
-            DataKey.NODE_FEATURES: Irreps(f"{embedding_dim}x0e"),
+            DataKey.NODE_FEATURES: Irreps(f"{feats_dim}x0e"),
         }
         self.init_irreps(irreps_in, irreps_out)
         self.linear = torch.nn.Linear(self.num_species, embedding_dim)
@@ -173,6 +178,8 @@ class SpeciesEmbedding(ModuleIrreps, torch.nn.Module):
             raise ValueError("Nothing in `data` to encode. Need either species_index or atomic_numbers")
         attrs = torch.nn.functional.one_hot(type_numbers, num_classes=self.num_species).to(self.linear.weight.dtype)
         embed = self.linear(attrs)
+        if self.use_atom_feats:
+            embed = torch.hstack((embed, data["atom_feats"].to(embed.dtype)))
         data[DataKey.NODE_ATTRS] = attrs
         data[DataKey.NODE_FEATURES] = embed
         return data

@@ -1094,3 +1094,34 @@ def test_deferred_input_checks_raise_one_forward_late():
         model.finish_input_checks()                        # nothing pending: no-op
         model.set_input_checks(True)
         assert torch.equal(model(dict(good))[0]["elastic_tensor_full"], want)
+
+
+def test_atom_feats_ride_behind_the_species_embedding(golden_dir):
+    """use_atom_feats=True (reference nn/embedding.py:59-68,103-105): data["atom_feats"] [n_atoms, F] is stacked behind
+    the species embedding, so the first conv layer sees (16 + F)x0e -- forward against the oracle, and one training
+    step's gradients (the features enter lin1 / self-connection of the first layer)."""
+    from matten_amd.data.graph import average_num_neighbors, collate, crystal_graph
+    from oracle.matten_ref import data as rdata
+
+    structs = rdata.structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))[:7]
+    graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
+    gen = torch.Generator().manual_seed(3)
+    F = 5
+    for g in graphs:
+        g["atom_feats"] = torch.randn(g["pos"].shape[0], F, generator=gen)
+    ds = {"allowed_species": sorted({int(z) for s in structs for z in s["atomic_numbers"]}),
+          "average_num_neighbors": average_num_neighbors(graphs), "atom_feats_size": F}
+    ref, model = build_pair(dict(LMAX2, use_atom_feats=True), ds, randomize_bn=True)
+    assert str(model.backbone.one_hot.irreps_out["node_features"]) == f"{16 + F}x0e"
+    with torch.no_grad():
+        want = ref.decode(collate(graphs))
+        got = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+    close(got[:, :12], want[:, :12], RTOL, "forward with atom features")       # (lmax 2: the 4e block has no path)
+    ref.train(), model.train()
+    target = torch.randn(len(graphs), 21, generator=gen)
+    torch.nn.functional.mse_loss(ref.decode(collate(graphs)), target).backward()
+    torch.nn.functional.mse_loss(model(collate(graphs, device=DEV))[0]["elastic_tensor_full"], target.to(DEV)).backward()
+    named = dict(model.named_parameters())
+    for k, p in ref.named_parameters():
+        if p.grad is not None and "layer0_convnet.conv" in k:
+            close(named[k].grad, p.grad, 3e-3, f"grad {k}")
