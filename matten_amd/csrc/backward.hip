@@ -789,15 +789,23 @@ __device__ __forceinline__ void lit_block_4(const LitArgs& a, const int4 blk, co
 }  // namespace
 
 namespace {
-// out[n, c] = sum over k in [ptr[n], ptr[n+1]) of rows[perm[k], c], in k order (fixed: no atomics)
+// out[n, c] = sum over k in [ptr[n], ptr[n+1]) of rows[perm[k], c], in k order (fixed: no atomics).  A thread owns one
+// column of one segment; two rows are in flight per step (the row index of the step after next is fetched early).
 __global__ void rows_segment_sum_kernel(const float* __restrict__ rows, int d, const int32_t* __restrict__ ptr,
                                         const int32_t* __restrict__ perm, int64_t n_seg, float* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_seg * d) return;
     const int64_t n = idx / d;
     const int c = (int)(idx - n * d);
+    const int beg = ptr[n], end = ptr[n + 1];
     float acc = 0.0f;
-    for (int k = ptr[n]; k < ptr[n + 1]; ++k) acc += rows[(int64_t)perm[k] * d + c];
+    int k = beg;
+    for (; k + 4 <= end; k += 4) {   // four independent loads per step, added in k order
+        const float v0 = rows[(int64_t)perm[k] * d + c], v1 = rows[(int64_t)perm[k + 1] * d + c];
+        const float v2 = rows[(int64_t)perm[k + 2] * d + c], v3 = rows[(int64_t)perm[k + 3] * d + c];
+        acc = (((acc + v0) + v1) + v2) + v3;
+    }
+    for (; k < end; ++k) acc += rows[(int64_t)perm[k] * d + c];
     out[idx] = acc;
 }
 

@@ -15,7 +15,9 @@ graphs = [graphs[i % len(graphs)] for i in range(B)]
 b = collate(graphs, device=dev)
 N, E = b["pos"].shape[0], b["edge_index"].shape[1]
 irr = "32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e"
-p = mplan.plan_uvu(irr, Irreps.spherical_harmonics(4), irr)
+# TARGET=view: the last conv layer as inference runs it (dead-output elimination: the head's irreps only)
+target = "32x0e+4x2e+2x4e" if os.environ.get("TARGET") == "view" else irr
+p = mplan.plan_uvu(irr, Irreps.spherical_harmonics(4), target)
 perm, rowptr, src, _ = ops.csr_build(b["edge_index"], N)
 geo = ops.edge_geom(b["pos"], b["edge_index"], b["edge_cell_shift"], b["cell"], b["batch"], perm, 4)
 x = torch.randn(N, p.d_in, device=dev)
