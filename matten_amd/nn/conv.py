@@ -241,6 +241,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
             data = self._view_forward(data, _ag.needs_grad(data[DataKey.NODE_FEATURES], *self.parameters()))
             data[KEPT_ONLY] = True
             return data
+        data.pop(KEPT_ONLY, None)   # (a re-used batch dict may carry the marker of an earlier forward)
         x = data[DataKey.NODE_FEATURES]
         species = data[DataKey.AMD_SPECIES]
         fused = None if _ag.needs_grad(x, self.lin1.weight, self.sc.weight) else self._fused_lin1_sc_tables()
