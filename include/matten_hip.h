@@ -423,6 +423,21 @@ int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim, int64_t n_
                         const int32_t* chan, int64_t n_chan, const float* mean, const float* nu, const float* weight,
                         float eps, float* A, float* B, float* dx, matten_stream_t stream);
 
+/* Instance ("graph") normalisation, reference nn/utils.py:448-588 (the reference's own InstanceNorm: one set of
+ * statistics per crystal, nodes as samples): matten_bn_train_fwd / _bwd with per-crystal statistics, in training and in
+ * evaluation alike (it keeps no running averages).  Rows are grouped per crystal: seg_ptr[n_seg + 1] int64 row offsets,
+ * seg_of_row[n_rows] int64 = the crystal of every row (the batch dict's `ptr` and `batch`).  chan as above, except that
+ * the reference centres and biases every l = 0 channel (0e AND 0o: `ir.l == 0`, nn/utils.py:531,572), so chan[.][2]
+ * is set for both.  mean / nu / A / B are [n_seg, n_chan]. */
+int matten_instance_norm_fwd(const float* x, int64_t dim, int64_t n_rows, const int64_t* seg_ptr, const int64_t* seg_of_row,
+                             int64_t n_seg, const int32_t* col2chan, const int32_t* chan, int64_t n_chan,
+                             const float* weight, const float* bias, float eps, float* mean, float* nu, float* y,
+                             matten_stream_t stream);
+int matten_instance_norm_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows, const int64_t* seg_ptr,
+                             const int64_t* seg_of_row, int64_t n_seg, const int32_t* col2chan, const int32_t* chan,
+                             int64_t n_chan, const float* mean, const float* nu, const float* weight, float eps, float* A,
+                             float* B, float* dx, matten_stream_t stream);
+
 /* adjoint of matten_segment_reduce */
 int matten_segment_reduce_bwd(const float* dy, int64_t dim, const int64_t* ptr, int64_t n_segments, int mean, float* dx,
                               matten_stream_t stream);

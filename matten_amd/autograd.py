@@ -199,6 +199,29 @@ class BatchNormTrainFn(torch.autograd.Function):
         return dx, dweight, dbias, None
 
 
+class InstanceNormFn(torch.autograd.Function):
+    """the reference's InstanceNorm (per-crystal statistics; same arithmetic as BatchNormTrainFn per crystal)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, norm, ptr, batch):
+        dev = x.device
+        y, mean, nu = ops.instance_norm_fwd(x, ptr, batch, norm._tables.get("col2chan", dev), norm._tables.get("chan", dev),
+                                            weight, bias, norm.eps)
+        ctx.norm = norm
+        ctx.save_for_backward(x, weight, mean, nu, ptr, batch)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, mean, nu, ptr, batch = ctx.saved_tensors
+        norm, dev = ctx.norm, g.device
+        dx, A, B = ops.instance_norm_bwd(x, g.contiguous(), ptr, batch, norm._tables.get("col2chan", dev),
+                                         norm._tables.get("chan", dev), mean, nu, weight, norm.eps)
+        dweight = (A * torch.rsqrt(nu + norm.eps)).sum(0)
+        dbias = B.sum(0)[norm._tables.get("scalar_chan", dev)]
+        return dx, dweight, dbias, None, None, None
+
+
 class SegmentReduceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ptr, mean):

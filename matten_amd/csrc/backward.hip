@@ -335,12 +335,23 @@ __global__ void gate_bwd_kernel(const float* __restrict__ x, int d_in, const int
 // centred.  stats: mean[c] (0 for non-scalars), nu[c] = mean_n mean_k (x - mean)^2.
 // chan[C] int4 {offset, d, is_scalar, mean_idx(-1)}
 // ------------------------------------------------------------------------------------------------
-__global__ void bn_stats_kernel(const float* __restrict__ x, int dim, int64_t n_rows, const int4* __restrict__ chan,
-                                float* __restrict__ mean, float* __restrict__ nu) {
+// Segmented form (instance / graph normalisation, reference nn/utils.py:448-588: one set of statistics per crystal):
+// seg_ptr[B+1] != NULL, grid.y = B, rows [seg_ptr[b], seg_ptr[b+1]) -> mean / nu [B, C]; seg_ptr == NULL: the whole batch.
+__global__ void bn_stats_kernel(const float* __restrict__ x, int dim, int64_t n_rows_all, const int4* __restrict__ chan,
+                                float* __restrict__ mean, float* __restrict__ nu, const int64_t* __restrict__ seg_ptr) {
     __shared__ float red[256];
     const int c = blockIdx.x;
     const int4 ch = chan[c];
     const int d = ch.y;
+    const int64_t r0 = seg_ptr ? seg_ptr[blockIdx.y] : 0;
+    const int64_t n_rows = seg_ptr ? seg_ptr[blockIdx.y + 1] - r0 : n_rows_all;
+    x += r0 * dim;
+    mean += (int64_t)blockIdx.y * gridDim.x;
+    nu += (int64_t)blockIdx.y * gridDim.x;
+    if (n_rows <= 0) {   // an empty crystal: no rows will read these
+        if (threadIdx.x == 0) mean[c] = 0.0f, nu[c] = 0.0f;
+        return;
+    }
     float s = 0.0f;
     if (ch.z) {
         for (int64_t n = threadIdx.x; n < n_rows; n += blockDim.x) s += x[n * dim + ch.x];
@@ -376,13 +387,15 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, int dim, int64_t n_
 __global__ void bn_apply_kernel(const float* __restrict__ x, int dim, int64_t n_rows, const int32_t* __restrict__ col2chan,
                                 const int4* __restrict__ chan, const float* __restrict__ mean,
                                 const float* __restrict__ nu, const float* __restrict__ weight,
-                                const float* __restrict__ bias, float eps, float* __restrict__ y) {
+                                const float* __restrict__ bias, float eps, float* __restrict__ y,
+                                const int64_t* __restrict__ seg_of_row, int n_chan) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_rows * dim) return;
     const int col = (int)(idx % dim);
     const int c = col2chan[col];
     const int4 ch = chan[c];
-    float v = (x[idx] - mean[c]) * rsqrtf(nu[c] + eps) * weight[c];
+    const int64_t sc = seg_of_row ? seg_of_row[idx / dim] * n_chan + c : c;   // statistics of the row's crystal
+    float v = (x[idx] - mean[sc]) * rsqrtf(nu[sc] + eps) * weight[c];
     if (ch.z) v += bias[ch.w];
     y[idx] = v;
 }
@@ -390,10 +403,19 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, int dim, int64_t n_
 // reductions of the adjoint: A[c] = sum dy (x - mean), B[c] = sum dy   (over rows and components)
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, int dim, int64_t n_rows,
                                      const int4* __restrict__ chan, const float* __restrict__ mean,
-                                     float* __restrict__ A, float* __restrict__ B) {
+                                     float* __restrict__ A, float* __restrict__ B, const int64_t* __restrict__ seg_ptr) {
     __shared__ float ra[256], rb[256];
     const int c = blockIdx.x;
     const int4 ch = chan[c];
+    if (seg_ptr) {   // segment blockIdx.y (see bn_stats_kernel)
+        const int64_t r0 = seg_ptr[blockIdx.y];
+        n_rows = seg_ptr[blockIdx.y + 1] - r0;
+        x += r0 * dim;
+        dy += r0 * dim;
+        mean += (int64_t)blockIdx.y * gridDim.x;
+        A += (int64_t)blockIdx.y * gridDim.x;
+        B += (int64_t)blockIdx.y * gridDim.x;
+    }
     const float mu = mean[c];
     float a = 0.0f, b = 0.0f;
     for (int64_t n = threadIdx.x; n < n_rows; n += blockDim.x)
@@ -423,16 +445,25 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     const int32_t* __restrict__ col2chan, const int4* __restrict__ chan,
                                     const float* __restrict__ mean, const float* __restrict__ nu,
                                     const float* __restrict__ weight, const float* __restrict__ A,
-                                    const float* __restrict__ B, float eps, float* __restrict__ dx) {
+                                    const float* __restrict__ B, float eps, float* __restrict__ dx,
+                                    const int64_t* __restrict__ seg_of_row, const int64_t* __restrict__ seg_ptr,
+                                    int n_chan) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_rows * dim) return;
     const int col = (int)(idx % dim);
     const int c = col2chan[col];
     const int4 ch = chan[c];
-    const float s = rsqrtf(nu[c] + eps);
-    const float nd = (float)n_rows * (float)ch.y;
-    float v = dy[idx] - (x[idx] - mean[c]) * s * s * A[c] / nd;
-    if (ch.z) v -= B[c] / (float)n_rows;
+    int64_t sc = c;
+    float rows = (float)n_rows;
+    if (seg_of_row) {
+        const int64_t b = seg_of_row[idx / dim];
+        sc = b * n_chan + c;
+        rows = (float)(seg_ptr[b + 1] - seg_ptr[b]);
+    }
+    const float s = rsqrtf(nu[sc] + eps);
+    const float nd = rows * (float)ch.y;
+    float v = dy[idx] - (x[idx] - mean[sc]) * s * s * A[sc] / nd;
+    if (ch.z) v -= B[sc] / rows;
     dx[idx] = weight[c] * s * v;
 }
 
@@ -539,12 +570,56 @@ extern "C" int matten_bn_train_fwd(const float* x, int64_t dim, int64_t n_rows, 
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows <= 0 || dim <= 0 || n_chan <= 0) return MATTEN_EINVAL;
     if (!x || !col2chan || !chan || !weight || !bias || !mean || !nu || !y) return MATTEN_EINVAL;
-    bn_stats_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, (int)dim, n_rows, (const int4*)chan, mean, nu);
+    bn_stats_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, (int)dim, n_rows, (const int4*)chan, mean, nu, nullptr);
     MATTEN_LAUNCH_CHECK();
     const int T = 256;
     bn_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(x, (int)dim, n_rows, col2chan,
                                                                               (const int4*)chan, mean, nu, weight, bias,
-                                                                              eps, y);
+                                                                              eps, y, nullptr, (int)n_chan);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+// Instance (graph) normalisation, reference nn/utils.py:448-588: the statistics of matten_bn_train_fwd per crystal.
+// seg_ptr[n_seg + 1]: the crystals' row ranges (rows grouped per crystal), seg_of_row[n_rows]: crystal of every row;
+// mean / nu [n_seg, n_chan] are outputs (kept for the adjoint).
+extern "C" int matten_instance_norm_fwd(const float* x, int64_t dim, int64_t n_rows, const int64_t* seg_ptr,
+                                        const int64_t* seg_of_row, int64_t n_seg, const int32_t* col2chan,
+                                        const int32_t* chan, int64_t n_chan, const float* weight, const float* bias,
+                                        float eps, float* mean, float* nu, float* y, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows < 0 || dim <= 0 || n_chan <= 0 || n_seg <= 0 || n_seg > 65535) return MATTEN_EINVAL;
+    if (!seg_ptr || !col2chan || !chan || !weight || !bias || !mean || !nu) return MATTEN_EINVAL;
+    if (n_rows > 0 && (!x || !y || !seg_of_row)) return MATTEN_EINVAL;
+    bn_stats_kernel<<<dim3((unsigned)n_chan, (unsigned)n_seg), 256, 0, stream>>>(x, (int)dim, n_rows, (const int4*)chan, mean,
+                                                                                  nu, seg_ptr);
+    MATTEN_LAUNCH_CHECK();
+    if (n_rows == 0) return MATTEN_OK;
+    const int T = 256;
+    bn_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(x, (int)dim, n_rows, col2chan,
+                                                                              (const int4*)chan, mean, nu, weight, bias,
+                                                                              eps, y, seg_of_row, (int)n_chan);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+// adjoint: A, B [n_seg, n_chan] (sum dy (x - mean), sum dy per crystal and channel), dx
+extern "C" int matten_instance_norm_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows, const int64_t* seg_ptr,
+                                        const int64_t* seg_of_row, int64_t n_seg, const int32_t* col2chan,
+                                        const int32_t* chan, int64_t n_chan, const float* mean, const float* nu,
+                                        const float* weight, float eps, float* A, float* B, float* dx,
+                                        matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows <= 0 || dim <= 0 || n_chan <= 0 || n_seg <= 0 || n_seg > 65535) return MATTEN_EINVAL;
+    if (!x || !dy || !seg_ptr || !seg_of_row || !col2chan || !chan || !mean || !nu || !weight || !A || !B || !dx)
+        return MATTEN_EINVAL;
+    bn_bwd_reduce_kernel<<<dim3((unsigned)n_chan, (unsigned)n_seg), 256, 0, stream>>>(x, dy, (int)dim, n_rows,
+                                                                                       (const int4*)chan, mean, A, B, seg_ptr);
+    MATTEN_LAUNCH_CHECK();
+    const int T = 256;
+    bn_bwd_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(
+        x, dy, (int)dim, n_rows, col2chan, (const int4*)chan, mean, nu, weight, A, B, eps, dx, seg_of_row, seg_ptr,
+        (int)n_chan);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }
@@ -556,11 +631,11 @@ extern "C" int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim,
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows <= 0 || dim <= 0 || n_chan <= 0) return MATTEN_EINVAL;
     if (!x || !dy || !col2chan || !chan || !mean || !nu || !weight || !A || !B || !dx) return MATTEN_EINVAL;
-    bn_bwd_reduce_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, dy, (int)dim, n_rows, (const int4*)chan, mean, A, B);
+    bn_bwd_reduce_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, dy, (int)dim, n_rows, (const int4*)chan, mean, A, B, nullptr);
     MATTEN_LAUNCH_CHECK();
     const int T = 256;
     bn_bwd_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(
-        x, dy, (int)dim, n_rows, col2chan, (const int4*)chan, mean, nu, weight, A, B, eps, dx);
+        x, dy, (int)dim, n_rows, col2chan, (const int4*)chan, mean, nu, weight, A, B, eps, dx, nullptr, nullptr, (int)n_chan);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

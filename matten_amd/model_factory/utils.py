@@ -54,7 +54,7 @@ def validate_hparams(hparams: Dict, dataset_hparams: Dict = None) -> None:
       radial_basis_type         bessel                          (reference nn/embedding.py:189-199)
       invariant_layers/neurons  2 x 32  (radial MLP [nb,32,32,W]; nb <= 16)   (nn/utils.py:246-251)
       nonlinearity_type         gate                            (nn/utils.py:96-140)
-      normalization             batch | none                    (nn/utils.py:414-418)
+      normalization             batch | instance | none         (nn/utils.py:414-418, 448-588)
       reduce                    mean | sum                      (nn/nodewise.py:142-148)
       use_atom_feats            false | true (data['atom_feats'] [n_atoms, atom_feats_size])   (nn/embedding.py:59-68,103-105)
       dataset_hparams           allowed_species given
@@ -79,8 +79,8 @@ def validate_hparams(hparams: Dict, dataset_hparams: Dict = None) -> None:
     if str(hparams.get("nonlinearity_type", "gate")).lower() != "gate":
         problems.append(f"nonlinearity_type={hparams['nonlinearity_type']!r}: only 'gate'")
     norm = hparams.get("normalization")
-    if norm is not None and str(norm).lower() not in ("batch", "none"):
-        problems.append(f"normalization={norm!r}: only 'batch' or none")
+    if norm is not None and str(norm).lower() not in ("batch", "instance", "none"):
+        problems.append(f"normalization={norm!r}: only 'batch', 'instance' or none")
     if str(hparams.get("reduce", "mean")).lower() not in ("mean", "sum"):
         problems.append(f"reduce={hparams['reduce']!r}: only 'mean' or 'sum'")
     if hparams.get("use_atom_feats", False) and dataset_hparams is not None and not dataset_hparams.get("atom_feats_size"):

@@ -310,5 +310,5 @@ class PointConvWithActivation(ModuleIrreps, torch.nn.Module):
     def forward(self, data: DataKey.Type) -> DataKey.Type:
         data = self.conv(data)
         # Gate and (eval-mode) BatchNorm run as one elementwise kernel
-        data[DataKey.NODE_FEATURES] = self.act(data[DataKey.NODE_FEATURES], self.norm)
+        data[DataKey.NODE_FEATURES] = self.act(data[DataKey.NODE_FEATURES], self.norm, data)
         return data

@@ -363,8 +363,13 @@ class ActivationLayer(torch.nn.Module):
     def irreps_out(self) -> Irreps:
         return self.plan.irreps_out
 
-    def forward(self, x: Tensor, norm: "NormalizationLayer" = None) -> Tensor:
+    def forward(self, x: Tensor, norm: "NormalizationLayer" = None, data=None) -> Tensor:
         dev = x.device
+        if norm is not None and norm.method == "instance":
+            # Gate, then the per-crystal normalisation (needs the batch dict for `batch` / `ptr`)
+            y = _ag.GateFn.apply(x, self) if _ag.needs_grad(x) else ops.gate_bn(
+                x, self._tables.get("meta", dev), self._tables.get("act_cst", dev))
+            return norm.n(y, data)
         bn = norm.n if (norm is not None and norm.n is not None) else None
         if bn is not None and bn.training:
             # training: Gate, then BatchNorm with batch statistics (and the running-average update)
@@ -408,15 +413,47 @@ class _IrrepBatchNorm(torch.nn.Module):
         return y
 
 
+class _IrrepInstanceNorm(torch.nn.Module):
+    """The reference's own InstanceNorm (nn/utils.py:448-588; "more like a graph normalization": a crystal is the
+    instance, its atoms the samples): scalars (every l = 0 irrep) are centred by their mean over the crystal, every
+    channel is divided by sqrt(mean over the crystal of the mean squared component + eps), times ``weight``, plus
+    ``bias`` on the scalars.  No running statistics: training and evaluation compute the same thing
+    (matten_instance_norm_fwd / _bwd = the BatchNorm kernels with per-crystal statistics)."""
+
+    def __init__(self, irreps: Irreps, eps: float = 1e-5):
+        super().__init__()
+        self.irreps = Irreps(irreps)
+        self.eps = eps
+        n_scalar = sum(m for m, ir in self.irreps if ir.l == 0)
+        self.weight = torch.nn.Parameter(torch.ones(self.irreps.num_irreps))
+        self.bias = torch.nn.Parameter(torch.zeros(n_scalar))
+        chan, col2chan = _plan.plan_batchnorm(self.irreps, odd_scalars_too=True)
+        self._tables = DeviceTables(chan=chan, col2chan=col2chan,
+                                    scalar_chan=np.nonzero(chan[:, 2])[0].astype(np.int64))
+
+    def forward(self, x: Tensor, data) -> Tensor:
+        from ._nequip import with_batch
+
+        with_batch(data)
+        batch = data[DataKey.BATCH]
+        ptr = data.get(DataKey.PTR)
+        if ptr is None:   # (one host sync: the crystal count; collated batches carry `ptr`)
+            n_seg = int(batch[-1]) + 1 if batch.numel() else 1
+            ptr = torch.searchsorted(batch, torch.arange(n_seg + 1, device=batch.device, dtype=batch.dtype))
+        if _ag.needs_grad(x, self.weight, self.bias):
+            return _ag.InstanceNormFn.apply(x, self.weight, self.bias, self, ptr, batch)
+        dev = x.device
+        return ops.instance_norm_fwd(x, ptr, batch, self._tables.get("col2chan", dev), self._tables.get("chan", dev),
+                                     self.weight, self.bias, self.eps)[0]
+
+
 class NormalizationLayer(torch.nn.Module):
     def __init__(self, irreps: Irreps, method: str = None):
         super().__init__()
         self.method = method
-        supported = ("batch", "none", None)
-        if method == "instance":
-            raise NotImplementedError("normalization='instance' is outside the accelerated path")
+        supported = ("batch", "instance", "none", None)
         assert method in supported, f"Unsupported normalization {method}"
-        self.n = _IrrepBatchNorm(irreps) if method == "batch" else None
+        self.n = _IrrepBatchNorm(irreps) if method == "batch" else _IrrepInstanceNorm(irreps) if method == "instance" else None
 
 
 class DetectAnomaly(ModuleIrreps, torch.nn.Module):

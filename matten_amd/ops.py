@@ -694,6 +694,35 @@ def bn_train_fwd(x, col2chan, chan, weight, bias, eps: float):
     return y, mean, nu
 
 
+def instance_norm_fwd(x, seg_ptr, seg_of_row, col2chan, chan, weight, bias, eps: float):
+    """per-crystal statistics (reference InstanceNorm, nn/utils.py:448-588) -> (y, mean [B, C], nu [B, C])"""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    seg_ptr = _need(seg_ptr, torch.int64, "ptr")
+    seg_of_row = _need(seg_of_row, torch.int64, "batch")
+    C, B = chan.shape[0], seg_ptr.shape[0] - 1
+    mean = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    nu = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    _lib.check(lib.matten_instance_norm_fwd(_ptr(x), x.shape[1], x.shape[0], _ptr(seg_ptr), _ptr(seg_of_row), B,
+                                            _ptr(col2chan), _ptr(chan), C, _ptr(weight), _ptr(bias), eps, _ptr(mean),
+                                            _ptr(nu), _ptr(y), _stream()), "matten_instance_norm_fwd")
+    return y, mean, nu
+
+
+def instance_norm_bwd(x, dy, seg_ptr, seg_of_row, col2chan, chan, mean, nu, weight, eps: float):
+    lib = _lib.load()
+    dy = _need(dy, torch.float32, "dy")
+    B, C = mean.shape
+    A = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    Bs = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    _lib.check(lib.matten_instance_norm_bwd(_ptr(x), _ptr(dy), x.shape[1], x.shape[0], _ptr(seg_ptr), _ptr(seg_of_row), B,
+                                            _ptr(col2chan), _ptr(chan), C, _ptr(mean), _ptr(nu), _ptr(weight), eps,
+                                            _ptr(A), _ptr(Bs), _ptr(dx), _stream()), "matten_instance_norm_bwd")
+    return dx, A, Bs
+
+
 def bn_train_bwd(x, dy, col2chan, chan, mean, nu, weight, eps: float):
     lib = _lib.load()
     dy = _need(dy, torch.float32, "dy")

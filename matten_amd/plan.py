@@ -665,15 +665,17 @@ def _scalar_out_parity(act_name: str, p_in: int) -> int:
     return pa
 
 
-def plan_batchnorm(irreps) -> Tuple[np.ndarray, np.ndarray]:
-    """(chan[C,4] int32 {column offset, 2l+1, is_0e, bias/mean index or -1}, col2chan[dim] int32) of e3nn BatchNorm."""
+def plan_batchnorm(irreps, odd_scalars_too: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """(chan[C,4] int32 {column offset, 2l+1, is_0e, bias/mean index or -1}, col2chan[dim] int32) of e3nn BatchNorm.
+    odd_scalars_too: every l = 0 channel is centred and biased, 0o included -- the reference's InstanceNorm tests
+    `ir.l == 0` / `d == 1` (nn/utils.py:531,572) where e3nn's BatchNorm tests `ir.is_scalar()`."""
     irreps = Irreps(irreps)
     chan, col2chan = [], []
     off = 0
     mi = 0
     for mul, ir in irreps:
         for _ in range(mul):
-            is0 = 1 if ir.is_scalar() else 0
+            is0 = 1 if (ir.l == 0 if odd_scalars_too else ir.is_scalar()) else 0
             chan.append((off, ir.dim, is0, mi if is0 else -1))
             col2chan += [len(chan) - 1] * ir.dim
             off += ir.dim

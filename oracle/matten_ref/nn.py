@@ -371,18 +371,62 @@ class UVUTensorProduct(torch.nn.Module):
         return self.irreps_mid.simplify()
 
 
+def _segment_mean(x, batch, n_seg):
+    """nn/utils.py:591-618 global_mean_pool: per-graph mean over the node dimension"""
+    out = torch.zeros((n_seg,) + tuple(x.shape[1:]), dtype=x.dtype).index_add_(0, batch, x)
+    count = torch.zeros(n_seg, dtype=x.dtype).index_add_(0, batch, torch.ones(batch.shape[0], dtype=x.dtype))
+    return out / count.clamp(min=1).reshape((n_seg,) + (1,) * (x.dim() - 1))
+
+
+class InstanceNorm(torch.nn.Module):
+    """nn/utils.py:448-588 (the reference's own graph-wise InstanceNorm; affine=True, reduce='mean',
+    normalization='component', the defaults NormalizationLayer uses)"""
+
+    def __init__(self, irreps, eps=1e-5):
+        super().__init__()
+        self.irreps = Irreps(irreps)
+        self.eps = eps
+        num_scalar = sum(mul for mul, ir in self.irreps if ir.l == 0)
+        self.weight = torch.nn.Parameter(torch.ones(self.irreps.num_irreps))
+        self.bias = torch.nn.Parameter(torch.zeros(num_scalar))
+
+    def forward(self, input, batch):
+        n_seg = int(batch.max()) + 1 if batch.numel() else 1
+        fields, ix, iw, ib = [], 0, 0, 0
+        for mul, ir in self.irreps:
+            d = ir.dim
+            field = input[:, ix: ix + mul * d].reshape(-1, mul, d)
+            ix += mul * d
+            if ir.l == 0:                                                       # :531-538
+                field = field - _segment_mean(field, batch, n_seg).reshape(-1, mul, 1)[batch]
+            field_norm = field.pow(2).mean(-1)                                  # 'component', :545
+            field_norm = _segment_mean(field_norm, batch, n_seg)                # reduce 'mean', :552
+            field_norm = (field_norm + self.eps).pow(-0.5)                      # :560
+            field_norm = field_norm * self.weight[None, iw: iw + mul]           # :562-565
+            iw += mul
+            field = field * field_norm[batch].reshape(-1, mul, 1)               # :567-569
+            if d == 1:                                                          # :571-574
+                field = field + self.bias[ib: ib + mul].reshape(mul, 1)
+                ib += mul
+            fields.append(field.reshape(-1, mul * d))
+        assert ix == input.shape[-1]
+        return torch.cat(fields, dim=-1)
+
+
 class NormalizationLayer(torch.nn.Module):
-    """nn/utils.py:397-437 ('batch' / none)"""
+    """nn/utils.py:397-437"""
 
     def __init__(self, irreps, method: str = None):
         super().__init__()
         self.method = method
-        assert method in ("batch", "none", None), f"Unsupported normalization {method} in the oracle"
-        self.n = BatchNorm(irreps) if method == "batch" else None
+        assert method in ("batch", "instance", "none", None), f"Unsupported normalization {method}"
+        self.n = BatchNorm(irreps) if method == "batch" else InstanceNorm(irreps) if method == "instance" else None
 
     def forward(self, x, batch):
         if self.method == "batch":
             x = self.n(x)
+        elif self.method == "instance":
+            x = self.n(x, batch)
         return x
 
 

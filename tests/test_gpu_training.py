@@ -428,3 +428,43 @@ def test_training_gradients_are_bitwise_reproducible(golden_dir):
     assert runs[0].keys() == runs[1].keys() and len(runs[0]) > 20
     diff = [k for k in runs[0] if not torch.equal(runs[0][k], runs[1][k])]
     assert not diff, diff
+
+
+def test_instance_normalization_forward_and_gradients(golden_dir):
+    """normalization='instance' = the reference's own graph-wise InstanceNorm (nn/utils.py:448-588): per-crystal
+    statistics, every l = 0 channel centred and biased, no running averages -- evaluation and training forward against
+    the oracle, then every parameter gradient (crystals of 1 to 10 atoms in one batch)."""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _graphs(golden_dir, 14)
+    hp = dict(LMAX2, normalization="instance")
+    ref, model = build_pair(hp, ds)
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():   # non-trivial affine parameters on both sides
+        for (k, p), (k2, q) in zip(ref.named_parameters(), model.named_parameters()):
+            if ".norm.n." in k:
+                assert k == k2
+                v = (0.5 + torch.rand(p.shape, generator=gen)) if k.endswith("weight") else 0.1 * torch.randn(p.shape, generator=gen)
+                p.copy_(v)
+                q.copy_(v.to(DEV))
+    assert any(".norm.n.weight" in k for k, _ in model.named_parameters())
+    assert not any("running" in k for k, _ in model.named_buffers())
+    with torch.no_grad():
+        want = ref.decode(collate(graphs))
+        got = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+    _close(got, want, 2e-4, "eval forward with instance normalisation")
+    ref.train(), model.train()
+    target = torch.randn(len(graphs), 21, generator=gen)
+    out_r = ref.decode(collate(graphs))
+    torch.nn.functional.mse_loss(out_r, target).backward()
+    out_m = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+    torch.nn.functional.mse_loss(out_m, target.to(DEV)).backward()
+    _close(out_m, out_r, 5e-4, "train-mode forward (same arithmetic as eval)")
+    named = dict(model.named_parameters())
+    n = 0
+    for k, p in ref.named_parameters():
+        if p.grad is not None:
+            assert named[k].grad is not None, k
+            _close(named[k].grad, p.grad, 3e-3, f"grad {k}")
+            n += 1
+    assert n > 25
