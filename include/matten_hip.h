@@ -423,6 +423,19 @@ int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim, int64_t n_
                         const int32_t* chan, int64_t n_chan, const float* mean, const float* nu, const float* weight,
                         float eps, float* A, float* B, float* dx, matten_stream_t stream);
 
+/* e3nn NormActivation as the reference configures it (nn/utils.py:142-150: nonlinearity_type "norm"; normalize = True,
+ * epsilon = 1e-8, bias = False): every channel c (chan[c] = {column offset, 2l+1, is_0e, mean index}, as for
+ * matten_bn_train_fwd; every column of the row belongs to one channel) is scaled by f(n) / n with
+ * n = sqrt(max(sum_k x_k^2, epsilon^2)) and f the activation code `act` (1 silu, 2 tanh, 3 sigmoid, 4 shifted softplus,
+ * 5 abs) applied as is (no second-moment normalisation).  With bn_weight != NULL the eval-mode BatchNorm that follows
+ * the activation is folded in (weight / sqrt(running_var + bn_eps) per channel, bias - running_mean * scale on 0e).
+ * matten_norm_act_bwd: the adjoint without BatchNorm (a clamped norm is a constant). */
+int matten_norm_act(const float* x, int64_t dim, int64_t n_rows, const int32_t* chan, int64_t n_chan, int act,
+                    float epsilon, const float* running_mean, const float* running_var, const float* bn_weight,
+                    const float* bn_bias, float bn_eps, float* y, matten_stream_t stream);
+int matten_norm_act_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows, const int32_t* chan, int64_t n_chan,
+                        int act, float epsilon, float* dx, matten_stream_t stream);
+
 /* Instance ("graph") normalisation, reference nn/utils.py:448-588 (the reference's own InstanceNorm: one set of
  * statistics per crystal, nodes as samples): matten_bn_train_fwd / _bwd with per-crystal statistics, in training and in
  * evaluation alike (it keeps no running averages).  Rows are grouped per crystal: seg_ptr[n_seg + 1] int64 row offsets,

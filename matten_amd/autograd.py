@@ -175,6 +175,21 @@ class GateFn(torch.autograd.Function):
         return ops.gate_bwd(x, mod._tables.get("meta", dev), mod._tables.get("act_cst", dev), g.contiguous()), None
 
 
+class NormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod):
+        ctx.mod = mod
+        ctx.save_for_backward(x)
+        return ops.norm_act(x, mod._tables.get("chan", x.device), mod.plan.act_code, mod.plan.epsilon)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        mod = ctx.mod
+        return ops.norm_act_bwd(x, g.contiguous(), mod._tables.get("chan", g.device), mod.plan.act_code,
+                                mod.plan.epsilon), None
+
+
 class BatchNormTrainFn(torch.autograd.Function):
     """e3nn BatchNorm with batch statistics; returns (y, mean, nu) so the caller can update the running stats."""
 

@@ -330,6 +330,59 @@ __global__ void gate_bwd_kernel(const float* __restrict__ x, int d_in, const int
 }
 
 // ------------------------------------------------------------------------------------------------
+// e3nn NormActivation (reference nn/utils.py:142-150: nonlinearity_type "norm"; normalize = True, epsilon = 1e-8, no
+// bias, the even-scalar activation used as given): channel c (2l+1 components at chan[c].x) is scaled by f(n) / n,
+// n = sqrt(max(sum_k x_k^2, eps^2)); optionally followed by eval-mode BatchNorm (per-channel scale, shift on 0e).
+// One thread per (row, channel).  chan[C] int4 {offset, d, is_0e, mean index} (plan_batchnorm).
+// ------------------------------------------------------------------------------------------------
+__global__ void norm_act_kernel(const float* __restrict__ x, int dim, int64_t n_rows, const int4* __restrict__ chan,
+                                int n_chan, int act, float eps2, const float* __restrict__ running_mean,
+                                const float* __restrict__ running_var, const float* __restrict__ bn_weight,
+                                const float* __restrict__ bn_bias, float bn_eps, float* __restrict__ y) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * n_chan) return;
+    const int64_t n = idx / n_chan;
+    const int c = (int)(idx - n * n_chan);
+    const int4 ch = chan[c];
+    const float* xp = x + n * dim + ch.x;
+    float n2 = 0.0f;
+    for (int k = 0; k < ch.y; ++k) n2 = fmaf(xp[k], xp[k], n2);
+    const float nn = sqrtf(fmaxf(n2, eps2));
+    float s = act_f(act, nn) / nn;
+    float shift = 0.0f;
+    if (bn_weight) {
+        const float bs = bn_weight[c] / sqrtf(running_var[c] + bn_eps);
+        if (ch.z) shift = bn_bias[ch.w] - running_mean[ch.w] * bs;
+        s *= bs;
+    }
+    float* yp = y + n * dim + ch.x;
+    for (int k = 0; k < ch.y; ++k) yp[k] = fmaf(xp[k], s, shift);
+}
+
+// adjoint (no BatchNorm folded in): dx_k = s g_k + [n^2 >= eps^2] (f'(n) n - f(n)) / n^3 (sum_j g_j x_j) x_k
+__global__ void norm_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int dim, int64_t n_rows,
+                                    const int4* __restrict__ chan, int n_chan, int act, float eps2,
+                                    float* __restrict__ dx) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * n_chan) return;
+    const int64_t n = idx / n_chan;
+    const int c = (int)(idx - n * n_chan);
+    const int4 ch = chan[c];
+    const float* xp = x + n * dim + ch.x;
+    const float* gp = dy + n * dim + ch.x;
+    float n2 = 0.0f, gx = 0.0f;
+    for (int k = 0; k < ch.y; ++k) {
+        n2 = fmaf(xp[k], xp[k], n2);
+        gx = fmaf(gp[k], xp[k], gx);
+    }
+    const float nn = sqrtf(fmaxf(n2, eps2));
+    const float f = act_f(act, nn), s = f / nn;
+    const float t = n2 < eps2 ? 0.0f : (act_df(act, nn) * nn - f) / (nn * nn * nn) * gx;   // clamped norm: constant
+    float* dp = dx + n * dim + ch.x;
+    for (int k = 0; k < ch.y; ++k) dp[k] = fmaf(t, xp[k], s * gp[k]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // e3nn BatchNorm, training mode (reference nn/utils.py:418 -> e3nn BatchNorm.forward with self.training).
 // Channel c = one multiplicity index of one irrep block (d components, offset off[c]); 0e channels are
 // centred.  stats: mean[c] (0 for non-scalars), nu[c] = mean_n mean_k (x - mean)^2.
@@ -560,6 +613,36 @@ extern "C" int matten_gate_bwd(const float* x, int64_t d_in, const int32_t* meta
     const int T = 256;
     gate_bwd_kernel<<<(unsigned)matten_cdiv(n_rows * d_out, T), T, 0, stream>>>(x, (int)d_in, (const int4*)meta,
                                                                                 (int)d_out, act_cst, dy, n_rows, dx);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_norm_act(const float* x, int64_t dim, int64_t n_rows, const int32_t* chan, int64_t n_chan, int act,
+                               float epsilon, const float* running_mean, const float* running_var,
+                               const float* bn_weight, const float* bn_bias, float bn_eps, float* y,
+                               matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows < 0 || dim <= 0 || n_chan <= 0 || act < 1 || act > 5 || !(epsilon > 0.0f)) return MATTEN_EINVAL;
+    if (n_rows == 0) return MATTEN_OK;
+    if (!x || !chan || !y) return MATTEN_EINVAL;
+    if (bn_weight && (!running_var || !running_mean || !bn_bias)) return MATTEN_EINVAL;
+    const int T = 256;
+    norm_act_kernel<<<(unsigned)matten_cdiv(n_rows * n_chan, T), T, 0, stream>>>(
+        x, (int)dim, n_rows, (const int4*)chan, (int)n_chan, act, epsilon * epsilon, running_mean, running_var, bn_weight,
+        bn_bias, bn_eps, y);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_norm_act_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows, const int32_t* chan,
+                                   int64_t n_chan, int act, float epsilon, float* dx, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rows < 0 || dim <= 0 || n_chan <= 0 || act < 1 || act > 5 || !(epsilon > 0.0f)) return MATTEN_EINVAL;
+    if (n_rows == 0) return MATTEN_OK;
+    if (!x || !dy || !chan || !dx) return MATTEN_EINVAL;
+    const int T = 256;
+    norm_act_bwd_kernel<<<(unsigned)matten_cdiv(n_rows * n_chan, T), T, 0, stream>>>(
+        x, dy, (int)dim, n_rows, (const int4*)chan, (int)n_chan, act, epsilon * epsilon, dx);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

@@ -53,7 +53,7 @@ def validate_hparams(hparams: Dict, dataset_hparams: Dict = None) -> None:
       irreps_edge_sh            0e+1o+...+lmax with lmax <= 4, parity (-1)^l
       radial_basis_type         bessel                          (reference nn/embedding.py:189-199)
       invariant_layers/neurons  2 x 32  (radial MLP [nb,32,32,W]; nb <= 16)   (nn/utils.py:246-251)
-      nonlinearity_type         gate                            (nn/utils.py:96-140)
+      nonlinearity_type         gate | norm                     (nn/utils.py:96-150)
       normalization             batch | instance | none         (nn/utils.py:414-418, 448-588)
       reduce                    mean | sum                      (nn/nodewise.py:142-148)
       use_atom_feats            false | true (data['atom_feats'] [n_atoms, atom_feats_size])   (nn/embedding.py:59-68,103-105)
@@ -76,8 +76,8 @@ def validate_hparams(hparams: Dict, dataset_hparams: Dict = None) -> None:
     if int(hparams.get("invariant_layers", 2)) != 2 or int(hparams.get("invariant_neurons", 32)) != 32:
         problems.append(f"invariant_layers={hparams.get('invariant_layers')}, invariant_neurons="
                         f"{hparams.get('invariant_neurons')}: the radial MLP is fixed at 2 hidden layers of 32")
-    if str(hparams.get("nonlinearity_type", "gate")).lower() != "gate":
-        problems.append(f"nonlinearity_type={hparams['nonlinearity_type']!r}: only 'gate'")
+    if str(hparams.get("nonlinearity_type", "gate")).lower() not in ("gate", "norm"):
+        problems.append(f"nonlinearity_type={hparams['nonlinearity_type']!r}: only 'gate' or 'norm'")
     norm = hparams.get("normalization")
     if norm is not None and str(norm).lower() not in ("batch", "instance", "none"):
         problems.append(f"normalization={norm!r}: only 'batch', 'instance' or none")

@@ -347,11 +347,14 @@ class ActivationLayer(torch.nn.Module):
         gat = {1: "ssp", -1: "abs"} if activation_gates is None else {
             key[k]: ACTIVATION[k][v] for k, v in activation_gates.items()
         }
+        self.activation_type = activation_type
+        if activation_type == "norm":   # e3nn NormActivation (reference nn/utils.py:142-150)
+            self.plan = _plan.plan_norm_act(tp_irreps_in1, tp_irreps_in2, tp_irreps_out, scal)
+            self._tables = DeviceTables(chan=self.plan.chan)
+            return
         if activation_type != "gate":
-            supported = ("gate",)
-            raise NotImplementedError(
-                f"matten_amd supports `activation_type` in {supported} (all shipped configs), got {activation_type}"
-            )
+            supported = ("gate", "norm")
+            raise ValueError(f"Support `activation_type` includes {supported}, got {activation_type}")
         self.plan = _plan.plan_gate(tp_irreps_in1, tp_irreps_in2, tp_irreps_out, scal, gat)
         self._tables = DeviceTables(meta=self.plan.meta, act_cst=act_const_table().numpy())
 
@@ -363,8 +366,26 @@ class ActivationLayer(torch.nn.Module):
     def irreps_out(self) -> Irreps:
         return self.plan.irreps_out
 
+    def _forward_norm_act(self, x: Tensor, norm, data) -> Tensor:
+        dev = x.device
+        bn = norm.n if (norm is not None and norm.method == "batch") else None
+        if _ag.needs_grad(x) or (bn is not None and bn.training) or (norm is not None and norm.method == "instance"):
+            y = _ag.NormActFn.apply(x, self) if _ag.needs_grad(x) else ops.norm_act(
+                x, self._tables.get("chan", dev), self.plan.act_code, self.plan.epsilon)
+            if norm is not None and norm.method == "instance":
+                return norm.n(y, data)
+            if bn is None:
+                return y
+            if not bn.training:
+                raise NotImplementedError("gradients through eval-mode BatchNorm: call model.train()")
+            return bn.forward_train(y)
+        return ops.norm_act(x, self._tables.get("chan", dev), self.plan.act_code, self.plan.epsilon,
+                            *((bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps) if bn is not None else ()))
+
     def forward(self, x: Tensor, norm: "NormalizationLayer" = None, data=None) -> Tensor:
         dev = x.device
+        if self.activation_type == "norm":
+            return self._forward_norm_act(x, norm, data)
         if norm is not None and norm.method == "instance":
             # Gate, then the per-crystal normalisation (needs the batch dict for `batch` / `ptr`)
             y = _ag.GateFn.apply(x, self) if _ag.needs_grad(x) else ops.gate_bn(

@@ -694,6 +694,27 @@ def bn_train_fwd(x, col2chan, chan, weight, bias, eps: float):
     return y, mean, nu
 
 
+def norm_act(x, chan, act: int, epsilon: float = 1e-8, running_mean=None, running_var=None, bn_weight=None, bn_bias=None,
+             bn_eps: float = 1e-5) -> torch.Tensor:
+    """e3nn NormActivation (+ optional eval-mode BatchNorm), include/matten_hip.h matten_norm_act"""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    y = torch.empty_like(x)
+    _lib.check(lib.matten_norm_act(_ptr(x), x.shape[1], x.shape[0], _ptr(chan), chan.shape[0], int(act), float(epsilon),
+                                   _ptr(running_mean), _ptr(running_var), _ptr(bn_weight), _ptr(bn_bias), float(bn_eps),
+                                   _ptr(y), _stream()), "matten_norm_act")
+    return y
+
+
+def norm_act_bwd(x, dy, chan, act: int, epsilon: float = 1e-8) -> torch.Tensor:
+    lib = _lib.load()
+    dy = _need(dy, torch.float32, "dy")
+    dx = torch.empty_like(x)
+    _lib.check(lib.matten_norm_act_bwd(_ptr(x), _ptr(dy), x.shape[1], x.shape[0], _ptr(chan), chan.shape[0], int(act),
+                                       float(epsilon), _ptr(dx), _stream()), "matten_norm_act_bwd")
+    return dx
+
+
 def instance_norm_fwd(x, seg_ptr, seg_of_row, col2chan, chan, weight, bias, eps: float):
     """per-crystal statistics (reference InstanceNorm, nn/utils.py:448-588) -> (y, mean [B, C], nu [B, C])"""
     lib = _lib.load()

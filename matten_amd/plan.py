@@ -652,6 +652,27 @@ def plan_gate(tp_irreps_in1, tp_irreps_in2, tp_irreps_out, act_scalars: Dict[int
                     sum(m for m, ir in irreps_out if ir.is_scalar()))
 
 
+@dataclass
+class NormActPlan:
+    """e3nn NormActivation as the reference builds it (nn/utils.py:142-150)"""
+    irreps_in: Irreps
+    irreps_out: Irreps
+    chan: np.ndarray      # int32 [C, 4] as plan_batchnorm
+    act_code: int
+    epsilon: float = 1e-8
+
+
+def plan_norm_act(tp_irreps_in1, tp_irreps_in2, tp_irreps_out, act_scalars: Dict[int, str]) -> NormActPlan:
+    """irreps = (scalars + gated of the reachable, sorted, simplified target).simplify(); the EVEN-scalar activation
+    acts on the norm of every channel ("norm is an even scalar, so activation_scalars[1]", nn/utils.py:145-146)."""
+    tp_irreps_out = Irreps(tp_irreps_out).sort()[0].simplify()
+    scalars = Irreps([(m, ir) for m, ir in tp_irreps_out if ir.l == 0 and tp_path_exists(tp_irreps_in1, tp_irreps_in2, ir)])
+    gated = Irreps([(m, ir) for m, ir in tp_irreps_out if ir.l > 0 and tp_path_exists(tp_irreps_in1, tp_irreps_in2, ir)])
+    irreps = (scalars + gated).simplify()
+    chan, _ = plan_batchnorm(irreps)
+    return NormActPlan(irreps, irreps, chan, ACT_CODE[act_scalars[1]])
+
+
 _ACT_PARITY = {"silu": 0, "ssp": 0, "sigmoid": 0, "tanh": -1, "abs": 1}  # even(+1) / odd(-1) / neither(0)
 
 

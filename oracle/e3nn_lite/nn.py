@@ -217,6 +217,51 @@ class Gate(torch.nn.Module):
         return self._irreps_out
 
 
+class NormActivation(torch.nn.Module):
+    """e3nn.nn.NormActivation (e3nn 0.5.1 nn/_normact.py), restated: every irrep channel is scaled by
+    ``f(|x|) / |x|`` (``normalize=True``), |x| the Euclidean norm over the channel's 2l+1 components
+    (o3.Norm: the 'uuu' product l x l -> 0e with path weight 2l+1 in component normalisation = sum_m x_m^2),
+    squared norms below epsilon^2 clamped to epsilon^2 before the square root (so no gradient flows through the
+    clamped norm), the scaling applied by o3.ElementwiseTensorProduct (0e x l -> l: plain multiplication).
+    ``scalar_nonlinearity`` is used as given (no normalize2mom).  bias=False only (the reference's call,
+    matten nn/utils.py:142-150)."""
+
+    def __init__(self, irreps_in, scalar_nonlinearity: Callable, normalize: bool = True, epsilon: float = None,
+                 bias: bool = False):
+        super().__init__()
+        from .o3 import Irreps
+
+        if bias:
+            raise NotImplementedError("NormActivation(bias=True) is not used by the reference")
+        self.irreps_in = Irreps(irreps_in)
+        self.irreps_out = Irreps(irreps_in)
+        if epsilon is None and normalize:
+            epsilon = 1e-8
+        elif epsilon is not None and not normalize:
+            raise ValueError("epsilon and normalize = False don't make sense together")
+        elif not normalize:
+            epsilon = 0.0
+        self._eps_squared = epsilon * epsilon
+        self.scalar_nonlinearity = scalar_nonlinearity
+        self.normalize = normalize
+
+    def forward(self, features):
+        out, ix = [], 0
+        for mul, ir in self.irreps_in:
+            d = ir.dim
+            field = features[..., ix: ix + mul * d].reshape(features.shape[:-1] + (mul, d))
+            ix += mul * d
+            norms = field.pow(2).sum(-1)
+            if self._eps_squared > 0:
+                norms = torch.where(norms < self._eps_squared, torch.full_like(norms, self._eps_squared), norms)
+                norms = norms.sqrt()
+            scalings = self.scalar_nonlinearity(norms)
+            if self.normalize:
+                scalings = scalings / norms
+            out.append((field * scalings[..., None]).reshape(features.shape[:-1] + (mul * d,)))
+        return torch.cat(out, dim=-1)
+
+
 class BatchNorm(torch.nn.Module):
     """e3nn.nn.BatchNorm (defaults: eps 1e-5, momentum 0.1, affine, reduce mean, component)."""
 

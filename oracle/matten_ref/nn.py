@@ -18,7 +18,7 @@ from torch import Tensor
 
 from ..e3nn_lite import o3
 from ..e3nn_lite.math import soft_one_hot_linspace
-from ..e3nn_lite.nn import BatchNorm, FullyConnectedNet, Gate
+from ..e3nn_lite.nn import BatchNorm, FullyConnectedNet, Gate, NormActivation
 from ..e3nn_lite.o3 import FullyConnectedTensorProduct, Irrep, Irreps, TensorProduct
 from ..e3nn_lite.scatter import scatter
 
@@ -273,7 +273,7 @@ def tp_path_exists(irreps_in1, irreps_in2, ir_out) -> bool:
 
 
 class ActivationLayer(torch.nn.Module):
-    """nn/utils.py:29-167 (activation_type == 'gate')"""
+    """nn/utils.py:29-167"""
 
     def __init__(self, tp_irreps_in1, tp_irreps_in2, tp_irreps_out, *, activation_type="gate",
                  activation_scalars: Dict[str, str] = None, activation_gates: Dict[str, str] = None):
@@ -297,8 +297,15 @@ class ActivationLayer(torch.nn.Module):
         irreps_gated = Irreps(
             [(mul, ir) for mul, ir in tp_irreps_out if ir.l > 0 and tp_path_exists(tp_irreps_in1, tp_irreps_in2, ir)]
         )
+        if activation_type == "norm":   # nn/utils.py:142-150
+            self.activation = NormActivation(
+                irreps_in=(irreps_scalars + irreps_gated).simplify(),
+                scalar_nonlinearity=activation_scalars[1],   # "norm is an even scalar, so activation_scalars[1]"
+                normalize=True, epsilon=1e-8, bias=False,
+            )
+            return
         if activation_type != "gate":
-            raise NotImplementedError("only activation_type='gate' is restated (every shipped config uses it)")
+            raise ValueError(f"Support `activation_type` includes ('gate', 'norm'), got {activation_type}")
         if irreps_gated.dim > 0:
             if tp_path_exists(tp_irreps_in1, tp_irreps_in2, "0e"):
                 ir = "0e"

@@ -468,3 +468,35 @@ def test_instance_normalization_forward_and_gradients(golden_dir):
             _close(named[k].grad, p.grad, 3e-3, f"grad {k}")
             n += 1
     assert n > 25
+
+
+@pytest.mark.parametrize("normalization", ["batch", "instance", None])
+def test_norm_activation_forward_and_gradients(golden_dir, normalization):
+    """nonlinearity_type='norm' = e3nn NormActivation as the reference configures it (nn/utils.py:142-150): every
+    channel scaled by silu(|x|) / |x|.  Evaluation forward (with the eval-mode BatchNorm folded into the kernel),
+    training forward and every parameter gradient against the oracle."""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _graphs(golden_dir, 9)
+    hp = dict(LMAX2, nonlinearity_type="norm", normalization=normalization)
+    ref, model = build_pair(hp, ds, randomize_bn=True)
+    assert type(model.backbone.layer0_convnet.act.plan).__name__ == "NormActPlan"
+    with torch.no_grad():
+        want = ref.decode(collate(graphs))
+        got = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+    _close(got, want, 2e-4, "eval forward with the norm activation")
+    ref.train(), model.train()
+    target = torch.randn(len(graphs), 21, generator=torch.Generator().manual_seed(4))
+    out_r = ref.decode(collate(graphs))
+    torch.nn.functional.mse_loss(out_r, target).backward()
+    out_m = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+    torch.nn.functional.mse_loss(out_m, target.to(DEV)).backward()
+    _close(out_m, out_r, 5e-4, "train-mode forward")
+    named = dict(model.named_parameters())
+    n = 0
+    for k, p in ref.named_parameters():
+        if p.grad is not None:
+            assert named[k].grad is not None, k
+            _close(named[k].grad, p.grad, 3e-3, f"grad {k}")
+            n += 1
+    assert n > 20
