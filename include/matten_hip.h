@@ -318,6 +318,13 @@ int matten_gate_bn(const float* x, int64_t d_in, const int32_t* meta, int64_t d_
  * ------------------------------------------------------------------------------------------ */
 int matten_segment_reduce(const float* x, int64_t dim, const int64_t* ptr, int64_t n_segments, int mean,
                           float* out, matten_stream_t stream);
+/* reduce = min | max (the other two values nn/nodewise.py:131 accepts): per crystal and column the smallest / largest
+ * value and, in arg [n_segments, dim] int64 (optional), the row it came from (an empty crystal: 0 and -1);
+ * _bwd: dx[arg[b, c], c] = dy[b, c], dx zero-initialised */
+int matten_segment_minmax(const float* x, int64_t dim, const int64_t* ptr, int64_t n_segments, int take_max, float* out,
+                          int64_t* arg, matten_stream_t stream);
+int matten_segment_minmax_bwd(const float* dy, int64_t dim, const int64_t* arg, int64_t n_segments, float* dx,
+                              matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Adjoint of the radial MLP (training; reference nn/utils.py:246-251,260 differentiated by autograd there).

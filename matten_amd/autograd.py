@@ -248,5 +248,19 @@ class SegmentReduceFn(torch.autograd.Function):
         return ops.segment_reduce_bwd(g.contiguous(), ctx.ptr, ctx.n, ctx.mean), None, None
 
 
+class SegmentMinMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ptr, take_max):
+        out, arg = ops.segment_minmax(x, ptr, take_max, want_arg=True)
+        ctx.n = x.shape[0]
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        return ops.segment_minmax_bwd(g.contiguous(), arg, ctx.n), None, None
+
+
 def needs_grad(*tensors: Optional[torch.Tensor]) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

@@ -105,6 +105,34 @@ __global__ void segment_reduce_kernel(const float* __restrict__ x, int dim, cons
     out[idx] = s;
 }
 
+// reduce = min | max (torch_scatter.scatter_min / _max): value and the row it came from (first of equals; an empty
+// crystal gives 0 and row -1)
+__global__ void segment_minmax_kernel(const float* __restrict__ x, int dim, const int64_t* __restrict__ ptr, int64_t n_seg,
+                                      int take_max, float* __restrict__ out, int64_t* __restrict__ arg) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_seg * dim) return;
+    const int64_t b = idx / dim;
+    const int c = (int)(idx - b * dim);
+    const int64_t beg = ptr[b], end = ptr[b + 1];
+    float best = 0.0f;
+    int64_t at = -1;
+    for (int64_t n = beg; n < end; ++n) {
+        const float v = x[n * dim + c];
+        if (at < 0 || (take_max ? v > best : v < best)) best = v, at = n;
+    }
+    out[idx] = best;
+    if (arg) arg[idx] = at;
+}
+
+// its adjoint: the gradient of (crystal b, column c) goes to the row the value came from (dx zero-initialised)
+__global__ void segment_minmax_bwd_kernel(const float* __restrict__ dy, int dim, const int64_t* __restrict__ arg,
+                                          int64_t n_seg, float* __restrict__ dx) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_seg * dim) return;
+    const int64_t at = arg[idx];
+    if (at >= 0) dx[at * dim + (idx % dim)] = dy[idx];
+}
+
 __global__ void dense_rows_kernel(const float* __restrict__ x, int n_in, const float* __restrict__ q, int n_out,
                                   int64_t n_rows, float* __restrict__ out) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,6 +175,31 @@ extern "C" int matten_segment_reduce(const float* x, int64_t dim, const int64_t*
     return MATTEN_OK;
 }
 
+extern "C" int matten_segment_minmax(const float* x, int64_t dim, const int64_t* ptr, int64_t n_segments, int take_max,
+                                     float* out, int64_t* arg, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_segments < 0 || dim <= 0) return MATTEN_EINVAL;
+    if (n_segments == 0) return MATTEN_OK;
+    if (!x || !ptr || !out) return MATTEN_EINVAL;
+    const int T = 256;
+    segment_minmax_kernel<<<(unsigned)matten_cdiv(n_segments * dim, T), T, 0, stream>>>(x, (int)dim, ptr, n_segments,
+                                                                                        take_max, out, arg);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_segment_minmax_bwd(const float* dy, int64_t dim, const int64_t* arg, int64_t n_segments, float* dx,
+                                         matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_segments < 0 || dim <= 0) return MATTEN_EINVAL;
+    if (n_segments == 0) return MATTEN_OK;
+    if (!dy || !arg || !dx) return MATTEN_EINVAL;
+    const int T = 256;
+    segment_minmax_bwd_kernel<<<(unsigned)matten_cdiv(n_segments * dim, T), T, 0, stream>>>(dy, (int)dim, arg, n_segments, dx);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
 extern "C" int matten_dense_rows(const float* x, int64_t n_in, const float* q, int64_t n_out, int64_t n_rows,
                                  float* out, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -160,4 +213,4 @@ extern "C" int matten_dense_rows(const float* x, int64_t n_in, const float* q, i
     return MATTEN_OK;
 }
 
-extern "C" int matten_abi_version(void) { return 25; }
+extern "C" int matten_abi_version(void) { return 26; }

@@ -55,7 +55,7 @@ def validate_hparams(hparams: Dict, dataset_hparams: Dict = None) -> None:
       invariant_layers/neurons  2 x 32  (radial MLP [nb,32,32,W]; nb <= 16)   (nn/utils.py:246-251)
       nonlinearity_type         gate | norm                     (nn/utils.py:96-150)
       normalization             batch | instance | none         (nn/utils.py:414-418, 448-588)
-      reduce                    mean | sum                      (nn/nodewise.py:142-148)
+      reduce                    mean | sum | min | max          (nn/nodewise.py:131,142-148)
       use_atom_feats            false | true (data['atom_feats'] [n_atoms, atom_feats_size])   (nn/embedding.py:59-68,103-105)
       dataset_hparams           allowed_species given
     """
@@ -81,8 +81,8 @@ def validate_hparams(hparams: Dict, dataset_hparams: Dict = None) -> None:
     norm = hparams.get("normalization")
     if norm is not None and str(norm).lower() not in ("batch", "instance", "none"):
         problems.append(f"normalization={norm!r}: only 'batch', 'instance' or none")
-    if str(hparams.get("reduce", "mean")).lower() not in ("mean", "sum"):
-        problems.append(f"reduce={hparams['reduce']!r}: only 'mean' or 'sum'")
+    if str(hparams.get("reduce", "mean")).lower() not in ("mean", "sum", "min", "max"):
+        problems.append(f"reduce={hparams['reduce']!r}: one of 'mean', 'sum', 'min', 'max' (nn/nodewise.py:131)")
     if hparams.get("use_atom_feats", False) and dataset_hparams is not None and not dataset_hparams.get("atom_feats_size"):
         problems.append("use_atom_feats=True needs dataset_hparams['atom_feats_size'] (reference nn/embedding.py:60-64)")
     if dataset_hparams is not None and not dataset_hparams.get("allowed_species"):

@@ -86,8 +86,6 @@ class NodewiseReduce(ModuleIrreps, torch.nn.Module):
     def __init__(self, irreps_in: Dict[str, Irreps], field: str, out_field: Optional[str] = None, reduce: str = "sum"):
         super().__init__()
         assert reduce in ("sum", "mean", "min", "max")
-        if reduce not in ("sum", "mean"):
-            raise NotImplementedError("matten_amd pools with sum or mean (shipped configs use mean)")
         self.reduce = reduce
         self.field = field
         self.out_field = f"{reduce}_{field}" if out_field is None else out_field
@@ -107,6 +105,14 @@ class NodewiseReduce(ModuleIrreps, torch.nn.Module):
             ptr = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=batch.device)
             ptr[1:] = torch.cumsum(counts, 0)
         x = data[self.field]
+        if self.reduce in ("min", "max"):
+            if torch.is_grad_enabled() and x.requires_grad:
+                from ..autograd import SegmentMinMaxFn
+
+                data[self.out_field] = SegmentMinMaxFn.apply(x, ptr, self.reduce == "max")
+            else:
+                data[self.out_field] = ops.segment_minmax(x, ptr, self.reduce == "max")
+            return data
         if torch.is_grad_enabled() and x.requires_grad:
             from ..autograd import SegmentReduceFn
 

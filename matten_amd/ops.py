@@ -577,6 +577,28 @@ def segment_reduce(x, ptr, mean: bool) -> torch.Tensor:
     return out
 
 
+def segment_minmax(x, ptr, take_max: bool, want_arg: bool = False):
+    """per crystal and column min / max -> out [B, dim] (and the source rows [B, dim] int64 when want_arg)"""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    ptr = _need(ptr, torch.int64, "ptr")
+    B = ptr.shape[0] - 1
+    out = torch.empty(B, x.shape[1], dtype=torch.float32, device=x.device)
+    arg = torch.empty(B, x.shape[1], dtype=torch.int64, device=x.device) if want_arg else None
+    _lib.check(lib.matten_segment_minmax(_ptr(x), x.shape[1], _ptr(ptr), B, int(take_max), _ptr(out), _ptr(arg), _stream()),
+               "matten_segment_minmax")
+    return (out, arg) if want_arg else out
+
+
+def segment_minmax_bwd(dy, arg, n_rows: int) -> torch.Tensor:
+    lib = _lib.load()
+    dy = _need(dy, torch.float32, "dy")
+    dx = torch.zeros(n_rows, dy.shape[1], dtype=torch.float32, device=dy.device)
+    _lib.check(lib.matten_segment_minmax_bwd(_ptr(dy), dy.shape[1], _ptr(arg), dy.shape[0], _ptr(dx), _stream()),
+               "matten_segment_minmax_bwd")
+    return dx
+
+
 def dense_rows(x, q) -> torch.Tensor:
     lib = _lib.load()
     x = _need(x, torch.float32, "x")

@@ -20,4 +20,9 @@ def scatter(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size: Opti
         count.index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
         count = count.clamp(min=1)
         return out / count.reshape((-1,) + (1,) * (src.dim() - 1))
+    if reduce in ("min", "max"):   # torch_scatter.scatter_min / scatter_max (values; empty groups stay 0)
+        idx = index.reshape((-1,) + (1,) * (src.dim() - 1)).expand_as(src)
+        init = src.new_full((dim_size,) + tuple(src.shape[1:]), float("inf") if reduce == "min" else float("-inf"))
+        red = init.scatter_reduce(0, idx, src, reduce="amin" if reduce == "min" else "amax", include_self=True)
+        return torch.where(torch.isinf(red), torch.zeros_like(red), red)
     raise NotImplementedError(reduce)

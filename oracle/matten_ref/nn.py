@@ -546,7 +546,7 @@ class NodewiseReduce(ModuleIrreps, torch.nn.Module):
 
     def __init__(self, irreps_in, field: str, out_field: Optional[str] = None, reduce: str = "sum"):
         super().__init__()
-        assert reduce in ("sum", "mean")
+        assert reduce in ("sum", "mean", "min", "max")
         self.reduce = reduce
         self.field = field
         self.out_field = f"{reduce}_{field}" if out_field is None else out_field

@@ -500,3 +500,23 @@ def test_norm_activation_forward_and_gradients(golden_dir, normalization):
             _close(named[k].grad, p.grad, 3e-3, f"grad {k}")
             n += 1
     assert n > 20
+
+
+@pytest.mark.parametrize("reduce", ["min", "max"])
+def test_min_max_pooling_forward_and_gradients(golden_dir, reduce):
+    """reduce = min | max (nn/nodewise.py:131,142-148: torch_scatter.scatter with that reduction): forward and all
+    gradients against the oracle (the gradient of a pooled value goes to the atom it came from)."""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _graphs(golden_dir, 8)
+    ref, model = build_pair(dict(LMAX2, reduce=reduce), ds, randomize_bn=True)
+    with torch.no_grad():
+        _close(model(collate(graphs, device=DEV))[0]["elastic_tensor_full"], ref.decode(collate(graphs)), 2e-4, reduce)
+    ref.train(), model.train()
+    target = torch.randn(len(graphs), 21, generator=torch.Generator().manual_seed(4))
+    torch.nn.functional.mse_loss(ref.decode(collate(graphs)), target).backward()
+    torch.nn.functional.mse_loss(model(collate(graphs, device=DEV))[0]["elastic_tensor_full"], target.to(DEV)).backward()
+    named = dict(model.named_parameters())
+    for k, p in ref.named_parameters():
+        if p.grad is not None:
+            _close(named[k].grad, p.grad, 3e-3, f"grad {k}")

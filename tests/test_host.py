@@ -393,7 +393,7 @@ def test_unsupported_configs_fail_up_front_with_the_full_list():
 
     ds = {"allowed_species": [13, 29], "average_num_neighbors": 18.0}
     validate_hparams(PAPER, ds)  # the paper config is inside
-    bad = dict(PAPER, nonlinearity_type="relu", normalization="layer", reduce="max", radial_basis_type="gaussian",
+    bad = dict(PAPER, nonlinearity_type="relu", normalization="layer", reduce="median", radial_basis_type="gaussian",
                invariant_neurons=64, use_atom_feats=True, irreps_edge_sh="0e+1o+2e+3o+4e+5o")
     with pytest.raises(UnsupportedConfig) as ei:
         ScalarTensorModel(backbone_hparams=bad, dataset_hparams=ds)   # (use_atom_feats without atom_feats_size)
