@@ -341,7 +341,9 @@ int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, int n_basis
                           const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden, int w_pad,
                           int w_cols, const void* dw, int64_t dw_ld, int dw_is_bf16, float* h2_scratch,
                           float* part_small, float* part_w2, float scale0, float scale1, float scale2,
-                          matten_stream_t stream);
+                          float* grad_small, float* grad_w2, matten_stream_t stream);
+/* grad_small [nb_pad*32 + 32*32] / grad_w2 [32, w_pad] (both or neither, may be NULL): the partial sums added up in slice
+ * order by a third launch of the same call */
 /* the raw layers (w0 [nb,32], w1 [32,32], w2 [32,W]) -> packed operands w0p = scale0 w0 (rows padded to nb_pad),
  * w1p = scale1 w1, w2p = scale2 w2 (columns padded to w_pad), one launch; matten_radial_mlp_bwd multiplies its partial
  * sums by the same three factors, so they are gradients w.r.t. the RAW layers */
@@ -351,7 +353,9 @@ int matten_radial_pack(const float* w0, const float* w1, const float* w2, int n_
 /* out[i] = src[idx[i]] * scale[(scale_by_source ? idx[i] : i) % scale_period]: the per-species re-packing of a flat e3nn
  * weight (idx = gather table, scale by output position) and its adjoint (idx = inverse permutation, scale by source) */
 int matten_gather_scale(const float* src, const int64_t* idx, const float* scale, int64_t n, int64_t scale_period,
-                        int scale_by_source, float* out, matten_stream_t stream);
+                        int scale_by_source, float* out, const int64_t* perm2, float* out2, matten_stream_t stream);
+/* perm2 [scale_period] / out2 (both or neither): a second output with the columns of every period permuted,
+ * out2[r, q] = out[r, perm2[q]] -- the transposed packed weights of the species linear's adjoint in the same launch */
 int64_t matten_species_linear_wgrad_slices(int64_t n_rows, int64_t n_species);   /* sizes matten_species_linear_wgrad's partial */
 
 /* ------------------------------------------------------------------------------------------
@@ -428,7 +432,8 @@ int matten_bn_train_fwd(const float* x, int64_t dim, int64_t n_rows, const int32
                         float* y, matten_stream_t stream);
 int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows, const int32_t* col2chan,
                         const int32_t* chan, int64_t n_chan, const float* mean, const float* nu, const float* weight,
-                        float eps, float* A, float* B, float* dx, matten_stream_t stream);
+                        float eps, float* A, float* B, float* dx, float* dweight, float* dbias, matten_stream_t stream);
+/* dweight [n_chan] = A rsqrt(nu + eps), dbias [number of 0e channels] = B of the 0e channels (both or neither, may be NULL) */
 
 /* e3nn NormActivation as the reference configures it (nn/utils.py:142-150: nonlinearity_type "norm"; normalize = True,
  * epsilon = 1e-8, bias = False): every channel c (chan[c] = {column offset, 2l+1, is_0e, mean index}, as for

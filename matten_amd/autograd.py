@@ -22,14 +22,20 @@ class PackWeightsFn(torch.autograd.Function):
     module and step); a bijection needs only the inverse permutation."""
 
     @staticmethod
-    def forward(ctx, weight, gather, scale, inverse):
+    def forward(ctx, weight, gather, scale, inverse, perm_t=None):
+        """perm_t: also return the per-path transposed packing (what the species linear's adjoint multiplies by), from
+        the same launch; it is a by-product for SpeciesLinearFn.backward and carries no gradient"""
         ctx.save_for_backward(scale, inverse)
-        return ops.gather_scale(weight, gather, scale)                       # one launch instead of index + multiply
+        if perm_t is None:
+            return ops.gather_scale(weight, gather, scale)                   # one launch instead of index + multiply
+        wp, wpt = ops.gather_scale(weight, gather, scale, perm2=perm_t)
+        ctx.mark_non_differentiable(wpt)
+        return wp, wpt
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, *_):
         scale, inverse = ctx.saved_tensors
-        return ops.gather_scale(g.contiguous(), inverse, scale, scale_by_source=True), None, None, None
+        return ops.gather_scale(g.contiguous(), inverse, scale, scale_by_source=True), None, None, None, None
 
 
 class SpeciesEmbedFn(torch.autograd.Function):
@@ -56,10 +62,11 @@ class SpeciesLinearFn(torch.autograd.Function):
     """out = add + x W_species  (matten_species_linear); adjoints: same kernel with W^T, and the weight-gradient kernel."""
 
     @staticmethod
-    def forward(ctx, x, wp, add, mod, species_order):
+    def forward(ctx, x, wp, add, mod, species_order, wpt=None):
         plan, dev = mod.plan, x.device
         segs = [mod._tables.get(f"meta{i}", dev) for i in range(len(plan.passes))]
         ctx.mod, ctx.species_order = mod, species_order
+        ctx.wpt = wpt   # the transposed packing, when PackWeightsFn produced it alongside
         ctx.save_for_backward(x, wp)
         ctx.has_add = add is not None
         return ops.species_linear(x, species_order, wp, plan.w_stride, segs, plan.d_out, add, plan.fully_covered)
@@ -72,15 +79,16 @@ class SpeciesLinearFn(torch.autograd.Function):
         dx = dwp = None
         if ctx.needs_input_grad[0]:
             segs_t = [mod._tables.get(f"meta_t{i}", dev) for i in range(len(plan.passes_t))]
-            wp2 = wp.reshape(-1, plan.w_stride)
-            wpt = wp2[:, mod._tables.get("perm_t", dev)].contiguous()
+            wpt = ctx.wpt
+            if wpt is None:
+                wpt = wp.reshape(-1, plan.w_stride)[:, mod._tables.get("perm_t", dev)].contiguous()
             dx = ops.species_linear(g, ctx.species_order, wpt, plan.w_stride, segs_t, plan.d_in, None,
                                     plan.input_covered)
         if ctx.needs_input_grad[1]:
             segs = [mod._tables.get(f"meta{i}", dev) for i in range(len(plan.passes))]
             n_species = wp.shape[0] if wp.dim() == 2 else 1
             dwp = ops.species_linear_wgrad(x, g, ctx.species_order, n_species, segs, plan.w_stride).reshape(wp.shape)
-        return dx, dwp, (g if ctx.has_add else None), None, None
+        return dx, dwp, (g if ctx.has_add else None), None, None, None
 
 
 # Storage type of the two per-edge tensors of a training step, the radial weights w[E, W] and their gradient -- at
@@ -207,10 +215,8 @@ class BatchNormTrainFn(torch.autograd.Function):
     def backward(ctx, g, _gm, _gn):
         x, weight, mean, nu = ctx.saved_tensors
         bn, dev = ctx.bn, g.device
-        dx, A, B = ops.bn_train_bwd(x, g.contiguous(), bn._tables.get("col2chan", dev), bn._tables.get("chan", dev),
-                                    mean, nu, weight, bn.eps)
-        dweight = A * torch.rsqrt(nu + bn.eps)
-        dbias = B[bn._tables.get("scalar_chan", dev)]
+        dx, dweight, dbias = ops.bn_train_bwd(x, g.contiguous(), bn._tables.get("col2chan", dev),
+                                              bn._tables.get("chan", dev), mean, nu, weight, bn.eps, bn.bias.numel())
         return dx, dweight, dbias, None
 
 

@@ -456,7 +456,9 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, int dim, int64_t n_
 // reductions of the adjoint: A[c] = sum dy (x - mean), B[c] = sum dy   (over rows and components)
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, int dim, int64_t n_rows,
                                      const int4* __restrict__ chan, const float* __restrict__ mean,
-                                     float* __restrict__ A, float* __restrict__ B, const int64_t* __restrict__ seg_ptr) {
+                                     float* __restrict__ A, float* __restrict__ B, const int64_t* __restrict__ seg_ptr,
+                                     const float* __restrict__ nu, float eps, float* __restrict__ dweight,
+                                     float* __restrict__ dbias) {
     __shared__ float ra[256], rb[256];
     const int c = blockIdx.x;
     const int4 ch = chan[c];
@@ -490,6 +492,10 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* _
     if (threadIdx.x == 0) {
         A[c] = ra[0];
         B[c] = rb[0];
+        if (dweight) {   // whole-batch statistics only: the parameter gradients right here
+            dweight[c] = ra[0] * rsqrtf(nu[c] + eps);
+            if (ch.z) dbias[ch.w] = rb[0];
+        }
     }
 }
 
@@ -697,7 +703,8 @@ extern "C" int matten_instance_norm_bwd(const float* x, const float* dy, int64_t
     if (!x || !dy || !seg_ptr || !seg_of_row || !col2chan || !chan || !mean || !nu || !weight || !A || !B || !dx)
         return MATTEN_EINVAL;
     bn_bwd_reduce_kernel<<<dim3((unsigned)n_chan, (unsigned)n_seg), 256, 0, stream>>>(x, dy, (int)dim, n_rows,
-                                                                                       (const int4*)chan, mean, A, B, seg_ptr);
+                                                                                       (const int4*)chan, mean, A, B, seg_ptr,
+                                                                                       nullptr, 0.0f, nullptr, nullptr);
     MATTEN_LAUNCH_CHECK();
     const int T = 256;
     bn_bwd_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(
@@ -710,11 +717,13 @@ extern "C" int matten_instance_norm_bwd(const float* x, const float* dy, int64_t
 extern "C" int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows,
                                    const int32_t* col2chan, const int32_t* chan, int64_t n_chan, const float* mean,
                                    const float* nu, const float* weight, float eps, float* A, float* B, float* dx,
-                                   matten_stream_t stream_) {
+                                   float* dweight, float* dbias, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows <= 0 || dim <= 0 || n_chan <= 0) return MATTEN_EINVAL;
     if (!x || !dy || !col2chan || !chan || !mean || !nu || !weight || !A || !B || !dx) return MATTEN_EINVAL;
-    bn_bwd_reduce_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, dy, (int)dim, n_rows, (const int4*)chan, mean, A, B, nullptr);
+    if ((dweight == nullptr) != (dbias == nullptr)) return MATTEN_EINVAL;
+    bn_bwd_reduce_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, dy, (int)dim, n_rows, (const int4*)chan, mean, A, B, nullptr,
+                                                               nu, eps, dweight, dbias);
     MATTEN_LAUNCH_CHECK();
     const int T = 256;
     bn_bwd_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(
@@ -1033,21 +1042,29 @@ extern "C" int matten_tp_backward_lit(const float* x, int64_t d_in, const void* 
 namespace {
 __global__ void gather_scale_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
                                     const float* __restrict__ scale, int64_t n, int64_t scale_period, int scale_by_source,
-                                    float* __restrict__ out) {
+                                    float* __restrict__ out, const int64_t* __restrict__ perm2, float* __restrict__ out2) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t j = idx[i];
     out[i] = src[j] * scale[(scale_by_source ? j : i) % scale_period];
+    if (out2) {   // a second copy with the columns of every period permuted: out2[r, q] = out[r, perm2[q]]
+        const int64_t r = i / scale_period, q = i - r * scale_period;
+        const int64_t p = r * scale_period + perm2[q];
+        out2[i] = src[idx[p]] * scale[(scale_by_source ? idx[p] : p) % scale_period];
+    }
 }
 }  // namespace
 
 extern "C" int matten_gather_scale(const float* src, const int64_t* idx, const float* scale, int64_t n, int64_t scale_period,
-                                   int scale_by_source, float* out, matten_stream_t stream_) {
+                                   int scale_by_source, float* out, const int64_t* perm2, float* out2,
+                                   matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || scale_period <= 0) return MATTEN_EINVAL;
     if (n == 0) return MATTEN_OK;
     if (!src || !idx || !scale || !out) return MATTEN_EINVAL;
-    gather_scale_kernel<<<(unsigned)matten_cdiv(n, 256), 256, 0, stream>>>(src, idx, scale, n, scale_period, scale_by_source, out);
+    if ((perm2 == nullptr) != (out2 == nullptr) || (out2 && n % scale_period)) return MATTEN_EINVAL;
+    gather_scale_kernel<<<(unsigned)matten_cdiv(n, 256), 256, 0, stream>>>(src, idx, scale, n, scale_period, scale_by_source,
+                                                                           out, perm2, out2);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

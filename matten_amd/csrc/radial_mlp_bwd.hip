@@ -19,6 +19,8 @@
 //   radial_mlp_bwd_w2      dW2p[k, q] = sum_e h2[e, k] dw[e, q]: a wave owns 16 weight columns and an edge range
 // Both write PARTIAL sums (one slice per wave / per edge range) that the host adds up in a fixed order: no atomics,
 // bit-reproducible.  dw may be fp32 or bf16 (the opt-in bf16 storage of the per-edge tensors).
+#include <algorithm>
+
 #include <hip/hip_bf16.h>
 
 #include "common.h"
@@ -258,6 +260,33 @@ __global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_w2(const float* 
         for (int r = 0; r < 4; ++r) out[(int64_t)(16 * t + 4 * g + r) * w_pad + q0 + c] = acc[t][r] * s2;
 }
 
+// out[i] = sum over the n partial rows part[s][i] in a FIXED order: a workgroup owns 64 columns, its 16 thread groups take
+// every 16th row each (sequentially), and group 0 adds the 16 group sums in group order.  grid.y = 0: the small
+// gradients, 1: dW2.
+__global__ __launch_bounds__(1024) void radial_mlp_bwd_reduce(const float* __restrict__ part_small, int64_t n_small,
+                                                              int small_len, const float* __restrict__ part_w2,
+                                                              int64_t n_rng, int w2_len, float* __restrict__ out_small,
+                                                              float* __restrict__ out_w2) {
+    __shared__ float red[16][64];
+    const float* part = blockIdx.y ? part_w2 : part_small;
+    const int64_t n = blockIdx.y ? n_rng : n_small;
+    const int len = blockIdx.y ? w2_len : small_len;
+    float* out = blockIdx.y ? out_w2 : out_small;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    if (blockIdx.x * 64 >= len) return;
+    float v = 0.0f;
+    if (col < len)
+        for (int64_t s = grp; s < n; s += 16) v += part[s * len + col];
+    red[grp][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (grp == 0 && col < len) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int gq = 1; gq < 16; ++gq) t += red[gq][threadIdx.x];
+        out[col] = t;
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t matten_radial_mlp_bwd_small_slices(int64_t n_edges) {
@@ -269,7 +298,7 @@ extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, 
                                      const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden,
                                      int w_pad, int w_cols, const void* dw, int64_t dw_ld, int dw_is_bf16,
                                      float* h2_scratch, float* part_small, float* part_w2, float scale0, float scale1,
-                                     float scale2, matten_stream_t stream_) {
+                                     float scale2, float* grad_small, float* grad_w2, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || hidden != HID || (w_pad & 15) || w_pad <= 0 || w_cols <= 0 || w_cols > w_pad || (nb_pad & 3) ||
         nb_pad < n_basis || nb_pad > 16 || dw_ld < w_pad || (dw_ld & 3))
@@ -300,6 +329,14 @@ extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, 
         radial_mlp_bwd_w2<false><<<grid2, BW_WAVES * 64, 0, stream>>>(h2_scratch, dw, dw_ld, n_edges, w_pad, part_w2,
                                                                       w2_range(n_edges), scale2);
     MATTEN_LAUNCH_CHECK();
+    if (grad_small || grad_w2) {   // the final, ordered sums in the same call (both or neither)
+        if (!grad_small || !grad_w2) return MATTEN_EINVAL;
+        const int small_len = nb_pad * HID + HID * HID, w2_len = HID * w_pad;
+        radial_mlp_bwd_reduce<<<dim3((unsigned)matten_cdiv(std::max(small_len, w2_len), 64), 2), 1024, 0, stream>>>(
+            part_small, matten_radial_mlp_bwd_small_slices(n_edges), small_len, part_w2,
+            matten_radial_mlp_bwd_w2_ranges(n_edges), w2_len, grad_small, grad_w2);
+        MATTEN_LAUNCH_CHECK();
+    }
     return MATTEN_OK;
 }
 

@@ -229,16 +229,21 @@ def radial_pack(w0, w1, w2, scales):
     return w0p, w1p, w2p
 
 
-def gather_scale(src, idx, scale, scale_by_source: bool = False):
-    """out[i] = src.flat[idx.flat[i]] * scale[(idx.flat[i] if scale_by_source else i) % len(scale)], shaped like idx"""
+def gather_scale(src, idx, scale, scale_by_source: bool = False, perm2=None):
+    """out[i] = src.flat[idx.flat[i]] * scale[(idx.flat[i] if scale_by_source else i) % len(scale)], shaped like idx.
+    perm2 (int64 [len(scale)]): also return out2[r, q] = out[r, perm2[q]] (the same launch)"""
     lib = _lib.load()
     src = _need(src, torch.float32, "src")
     idx = _need(idx, torch.int64, "idx")
     scale = _need(scale, torch.float32, "scale")
     out = torch.empty(idx.shape, dtype=torch.float32, device=src.device)
+    out2 = None
+    if perm2 is not None:
+        perm2 = _need(perm2, torch.int64, "perm2")
+        out2 = torch.empty(idx.shape, dtype=torch.float32, device=src.device)
     _lib.check(lib.matten_gather_scale(_ptr(src), _ptr(idx), _ptr(scale), idx.numel(), scale.numel(), int(scale_by_source),
-                                       _ptr(out), _stream()), "matten_gather_scale")
-    return out
+                                       _ptr(out), _ptr(perm2), _ptr(out2), _stream()), "matten_gather_scale")
+    return out if perm2 is None else (out, out2)
 
 
 def radial_mlp_bwd(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p, w1p, w2p, w_cols: int, dw,
@@ -262,15 +267,17 @@ def radial_mlp_bwd(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p,
     part_w2 = torch.empty(max(n_rng, 1), hidden, w_pad, dtype=torch.float32, device=dev)
     if E == 0:
         return w0p.new_zeros(nb_pad, hidden), w1p.new_zeros(hidden, hidden), w2p.new_zeros(hidden, w_pad)
+    small = torch.empty(nb_pad * hidden + hidden * hidden, dtype=torch.float32, device=dev)
+    d2 = torch.empty(hidden, w_pad, dtype=torch.float32, device=dev)
     with _timed(f"radial_mlp_bwd/w_pad={w_pad}"):
+        # (the per-wave / per-range partial sums are added in a fixed order by the call's last launch: no atomics)
         rc = lib.matten_radial_mlp_bwd(_ptr(geom_sorted), E, n_basis, r_start, r_end, _ptr(w0p), nb_pad, _ptr(w1p),
                                        _ptr(w2p), hidden, w_pad, int(w_cols), _ptr(dw), dw.shape[1],
                                        int(dw.dtype == torch.bfloat16), _ptr(h2), _ptr(part_small), _ptr(part_w2),
-                                       float(scales[0]), float(scales[1]), float(scales[2]), _stream())
+                                       float(scales[0]), float(scales[1]), float(scales[2]), _ptr(small), _ptr(d2),
+                                       _stream())
     _lib.check(rc, "matten_radial_mlp_bwd")
-    small = part_small.sum(0)     # fixed-order reductions of the per-wave / per-range partial sums (no atomics anywhere)
-    return (small[: nb_pad * hidden].reshape(nb_pad, hidden), small[nb_pad * hidden:].reshape(hidden, hidden),
-            part_w2.sum(0))
+    return small[: nb_pad * hidden].reshape(nb_pad, hidden), small[nb_pad * hidden:].reshape(hidden, hidden), d2
 
 
 def tp_scatter(x, w_edge, sh_sorted, rowptr, src_sorted, m_idx, m_coef, out_meta, avg_num_neighbors: float,
@@ -766,17 +773,21 @@ def instance_norm_bwd(x, dy, seg_ptr, seg_of_row, col2chan, chan, mean, nu, weig
     return dx, A, Bs
 
 
-def bn_train_bwd(x, dy, col2chan, chan, mean, nu, weight, eps: float):
+def bn_train_bwd(x, dy, col2chan, chan, mean, nu, weight, eps: float, n_bias: int):
+    """-> (dx, dweight [C], dbias [n_bias]): the parameter gradients come out of the reduction kernel itself"""
     lib = _lib.load()
     dy = _need(dy, torch.float32, "dy")
     C = chan.shape[0]
     A = torch.empty(C, dtype=torch.float32, device=x.device)
     B = torch.empty(C, dtype=torch.float32, device=x.device)
+    dweight = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbias = torch.empty(n_bias, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     _lib.check(lib.matten_bn_train_bwd(_ptr(x), _ptr(dy), x.shape[1], x.shape[0], _ptr(col2chan), _ptr(chan), C,
-                                       _ptr(mean), _ptr(nu), _ptr(weight), eps, _ptr(A), _ptr(B), _ptr(dx), _stream()),
+                                       _ptr(mean), _ptr(nu), _ptr(weight), eps, _ptr(A), _ptr(B), _ptr(dx), _ptr(dweight),
+                                       _ptr(dbias), _stream()),
                "matten_bn_train_bwd")
-    return dx, A, B
+    return dx, dweight, dbias
 
 
 def segment_reduce_bwd(dy, ptr, n_rows: int, mean: bool) -> torch.Tensor:
