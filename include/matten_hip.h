@@ -429,7 +429,9 @@ int matten_gate_bwd(const float* x, int64_t d_in, const int32_t* meta, int64_t d
  *   bwd: dx (A, B are [n_chan] scratch that return sum dy (x-mean) and sum dy: dweight = A rsqrt(nu+eps), dbias = B) */
 int matten_bn_train_fwd(const float* x, int64_t dim, int64_t n_rows, const int32_t* col2chan, const int32_t* chan,
                         int64_t n_chan, const float* weight, const float* bias, float eps, float* mean, float* nu,
-                        float* y, matten_stream_t stream);
+                        float* y, float* running_mean, float* running_var, float momentum, matten_stream_t stream);
+/* running_mean [number of 0e channels] / running_var [n_chan] (both or neither, may be NULL): updated in place by the
+ * statistics kernel, running = (1 - momentum) running + momentum batch (e3nn BatchNorm in training mode) */
 int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows, const int32_t* col2chan,
                         const int32_t* chan, int64_t n_chan, const float* mean, const float* nu, const float* weight,
                         float eps, float* A, float* B, float* dx, float* dweight, float* dbias, matten_stream_t stream);

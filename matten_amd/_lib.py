@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -65,7 +65,7 @@ SIGNATURES = {
     "matten_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float, P]),
     "matten_species_linear_wgrad": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int64, P, c_int64, c_int64, P, P, P]),
     "matten_gate_bwd": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, P, P]),
-    "matten_bn_train_fwd": (c_int, [P, c_int64, c_int64, P, P, c_int64, P, P, c_float, P, P, P, P]),
+    "matten_bn_train_fwd": (c_int, [P, c_int64, c_int64, P, P, c_int64, P, P, c_float, P, P, P, P, P, c_float, P]),
     "matten_bn_train_bwd": (c_int, [P, P, c_int64, c_int64, P, P, c_int64, P, P, P, c_float, P, P, P, P, P, P]),
     "matten_norm_act": (c_int, [P, c_int64, c_int64, P, c_int64, c_int, c_float, P, P, P, P, c_float, P, P]),
     "matten_norm_act_bwd": (c_int, [P, P, c_int64, c_int64, P, c_int64, c_int, c_float, P, P]),

@@ -26,6 +26,7 @@ class PackWeightsFn(torch.autograd.Function):
         """perm_t: also return the per-path transposed packing (what the species linear's adjoint multiplies by), from
         the same launch; it is a by-product for SpeciesLinearFn.backward and carries no gradient"""
         ctx.save_for_backward(scale, inverse)
+        ctx.set_materialize_grads(False)   # (no zero tensors for the by-product's never-defined gradient)
         if perm_t is None:
             return ops.gather_scale(weight, gather, scale)                   # one launch instead of index + multiply
         wp, wpt = ops.gather_scale(weight, gather, scale, perm2=perm_t)
@@ -34,6 +35,8 @@ class PackWeightsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, *_):
+        if g is None:
+            return None, None, None, None, None
         scale, inverse = ctx.saved_tensors
         return ops.gather_scale(g.contiguous(), inverse, scale, scale_by_source=True), None, None, None, None
 
@@ -199,20 +202,20 @@ class NormActFn(torch.autograd.Function):
 
 
 class BatchNormTrainFn(torch.autograd.Function):
-    """e3nn BatchNorm with batch statistics; returns (y, mean, nu) so the caller can update the running stats."""
+    """e3nn BatchNorm with batch statistics; the running averages are updated in place by the statistics kernel
+    (running = (1 - momentum) running + momentum batch), so the step needs no small library launches for them."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, bn):
         dev = x.device
         y, mean, nu = ops.bn_train_fwd(x, bn._tables.get("col2chan", dev), bn._tables.get("chan", dev), weight, bias,
-                                       bn.eps)
+                                       bn.eps, bn.running_mean, bn.running_var, bn.momentum)
         ctx.bn = bn
         ctx.save_for_backward(x, weight, mean, nu)
-        ctx.mark_non_differentiable(mean, nu)
-        return y, mean, nu
+        return y
 
     @staticmethod
-    def backward(ctx, g, _gm, _gn):
+    def backward(ctx, g):
         x, weight, mean, nu = ctx.saved_tensors
         bn, dev = ctx.bn, g.device
         dx, dweight, dbias = ops.bn_train_bwd(x, g.contiguous(), bn._tables.get("col2chan", dev),

@@ -391,7 +391,8 @@ __global__ void norm_act_bwd_kernel(const float* __restrict__ x, const float* __
 // Segmented form (instance / graph normalisation, reference nn/utils.py:448-588: one set of statistics per crystal):
 // seg_ptr[B+1] != NULL, grid.y = B, rows [seg_ptr[b], seg_ptr[b+1]) -> mean / nu [B, C]; seg_ptr == NULL: the whole batch.
 __global__ void bn_stats_kernel(const float* __restrict__ x, int dim, int64_t n_rows_all, const int4* __restrict__ chan,
-                                float* __restrict__ mean, float* __restrict__ nu, const int64_t* __restrict__ seg_ptr) {
+                                float* __restrict__ mean, float* __restrict__ nu, const int64_t* __restrict__ seg_ptr,
+                                float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
     __shared__ float red[256];
     const int c = blockIdx.x;
     const int4 ch = chan[c];
@@ -431,8 +432,13 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, int dim, int64_t n_
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        const float v = red[0] / ((float)n_rows * (float)d);
         mean[c] = mu;
-        nu[c] = red[0] / ((float)n_rows * (float)d);
+        nu[c] = v;
+        if (running_var) {   // e3nn: running = (1 - momentum) running + momentum batch (whole-batch statistics only)
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * v;
+            if (ch.z) running_mean[ch.w] = (1.0f - momentum) * running_mean[ch.w] + momentum * mu;
+        }
     }
 }
 
@@ -655,11 +661,14 @@ extern "C" int matten_norm_act_bwd(const float* x, const float* dy, int64_t dim,
 
 extern "C" int matten_bn_train_fwd(const float* x, int64_t dim, int64_t n_rows, const int32_t* col2chan,
                                    const int32_t* chan, int64_t n_chan, const float* weight, const float* bias,
-                                   float eps, float* mean, float* nu, float* y, matten_stream_t stream_) {
+                                   float eps, float* mean, float* nu, float* y, float* running_mean,
+                                   float* running_var, float momentum, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows <= 0 || dim <= 0 || n_chan <= 0) return MATTEN_EINVAL;
     if (!x || !col2chan || !chan || !weight || !bias || !mean || !nu || !y) return MATTEN_EINVAL;
-    bn_stats_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, (int)dim, n_rows, (const int4*)chan, mean, nu, nullptr);
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MATTEN_EINVAL;
+    bn_stats_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, (int)dim, n_rows, (const int4*)chan, mean, nu, nullptr,
+                                                          running_mean, running_var, momentum);
     MATTEN_LAUNCH_CHECK();
     const int T = 256;
     bn_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(x, (int)dim, n_rows, col2chan,
@@ -681,7 +690,7 @@ extern "C" int matten_instance_norm_fwd(const float* x, int64_t dim, int64_t n_r
     if (!seg_ptr || !col2chan || !chan || !weight || !bias || !mean || !nu) return MATTEN_EINVAL;
     if (n_rows > 0 && (!x || !y || !seg_of_row)) return MATTEN_EINVAL;
     bn_stats_kernel<<<dim3((unsigned)n_chan, (unsigned)n_seg), 256, 0, stream>>>(x, (int)dim, n_rows, (const int4*)chan, mean,
-                                                                                  nu, seg_ptr);
+                                                                                  nu, seg_ptr, nullptr, nullptr, 0.0f);
     MATTEN_LAUNCH_CHECK();
     if (n_rows == 0) return MATTEN_OK;
     const int T = 256;

@@ -433,12 +433,8 @@ class _IrrepBatchNorm(torch.nn.Module):
                                     scalar_chan=np.nonzero(chan[:, 2])[0].astype(np.int64))
 
     def forward_train(self, x: Tensor) -> Tensor:
-        y, mean, nu = _ag.BatchNormTrainFn.apply(x, self.weight, self.bias, self)
-        with torch.no_grad():  # e3nn: running = (1 - momentum) * running + momentum * batch
-            sc = self._tables.get("scalar_chan", x.device)
-            self.running_mean.mul_(1 - self.momentum).add_(self.momentum * mean[sc])
-            self.running_var.mul_(1 - self.momentum).add_(self.momentum * nu)
-        return y
+        # e3nn: running = (1 - momentum) * running + momentum * batch -- done by the statistics kernel itself
+        return _ag.BatchNormTrainFn.apply(x, self.weight, self.bias, self)
 
 
 class _IrrepInstanceNorm(torch.nn.Module):

@@ -711,15 +711,20 @@ def gate_bwd(x, meta, act_cst, dy) -> torch.Tensor:
     return dx
 
 
-def bn_train_fwd(x, col2chan, chan, weight, bias, eps: float):
+def bn_train_fwd(x, col2chan, chan, weight, bias, eps: float, running_mean=None, running_var=None, momentum: float = 0.0):
+    """batch statistics -> (y, mean, nu); running_mean / running_var (optional) are updated in place by the same launch"""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
     C = chan.shape[0]
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     nu = torch.empty(C, dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
+    if running_var is not None:
+        running_mean = _need(running_mean, torch.float32, "running_mean")
+        running_var = _need(running_var, torch.float32, "running_var")
     _lib.check(lib.matten_bn_train_fwd(_ptr(x), x.shape[1], x.shape[0], _ptr(col2chan), _ptr(chan), C, _ptr(weight),
-                                       _ptr(bias), eps, _ptr(mean), _ptr(nu), _ptr(y), _stream()), "matten_bn_train_fwd")
+                                       _ptr(bias), eps, _ptr(mean), _ptr(nu), _ptr(y), _ptr(running_mean),
+                                       _ptr(running_var), float(momentum), _stream()), "matten_bn_train_fwd")
     return y, mean, nu
 
 
