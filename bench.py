@@ -428,7 +428,9 @@ def run_rank(args):
     for _ in range(args.warmup):
         step()
     barrier()
-    ops.enable_event_timing(True)
+    # HIP events around the dominant kernel (roofline) and the radial-MLP kernel (mfma) only: an event pair costs a few
+    # microseconds of queue time, the timed region should not pay it for every launch
+    ops.enable_event_timing(True, only=("tp_scatter", "tp_lin2", "radial_hidden"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()

@@ -20,11 +20,15 @@ from . import _lib
 
 # ---- optional HIP-event timing of individual launches (used by bench.py for the roofline line) ----
 _EVENTS = None  # name -> list of (start_event, end_event) recorded on the launch stream
+_EVENTS_ONLY = None  # name prefixes to time, or None: every timed launch
 
 
-def enable_event_timing(flag: bool = True) -> None:
-    global _EVENTS
+def enable_event_timing(flag: bool = True, only=None) -> None:
+    """only: time just the launches whose name starts with one of these prefixes (an event pair costs a few us of queue
+    time per launch: a benchmark that needs one kernel's duration should not pay for nine)"""
+    global _EVENTS, _EVENTS_ONLY
     _EVENTS = {} if flag else None
+    _EVENTS_ONLY = tuple(only) if (flag and only) else None
 
 
 def event_timings_ms():
@@ -39,13 +43,14 @@ class _timed:
         self.name = name
 
     def __enter__(self):
-        if _EVENTS is not None:
+        self.on = _EVENTS is not None and (_EVENTS_ONLY is None or self.name.startswith(_EVENTS_ONLY))
+        if self.on:
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record(torch.cuda.current_stream())
         return self
 
     def __exit__(self, *exc):
-        if _EVENTS is not None:
+        if self.on and _EVENTS is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record(torch.cuda.current_stream())
             _EVENTS.setdefault(self.name, []).append((self.a, b))

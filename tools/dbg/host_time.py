@@ -1,26 +1,30 @@
-#!/usr/bin/env python3
-"""Host-side enqueue time of one forward (input checks off: no sync) against its wall time, at 1 and 1000 crystals."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 from __graft_entry__ import PAPER_HPARAMS
 from matten_amd.data import synthetic
 from matten_amd.data.graph import collate
 from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
-dev = "cuda:0"
+B = int(os.environ.get("B", "1000"))
+graphs = synthetic.fcc64_graphs(B)
 ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
-model = ScalarTensorModel(backbone_hparams=dict(PAPER_HPARAMS), dataset_hparams=ds).to(dev).eval()
-for B in (1, 1000):
-    batch = collate(synthetic.fcc64_graphs(B), device=dev)
+model = ScalarTensorModel(backbone_hparams=dict(PAPER_HPARAMS), dataset_hparams=ds).to("cuda:0").eval()
+batch = collate(graphs, device="cuda:0")
+model.set_input_checks("deferred")
+def step():
     with torch.no_grad():
-        for _ in range(5): model(dict(batch))
-        torch.cuda.synchronize()
-        for m in model.modules():
-            if hasattr(m, "check_species"): m.check_species = False   # no host sync: pure enqueue time
-        t = time.perf_counter()
-        for _ in range(20): model(dict(batch))
-        t_enq = (time.perf_counter() - t) / 20
-        torch.cuda.synchronize()
-        t_all = (time.perf_counter() - t) / 20
-        for m in model.modules():
-            if hasattr(m, "check_species"): m.check_species = True
-    print(f"B={B}: host enqueue {t_enq*1e3:.3f} ms per forward, wall {t_all*1e3:.3f} ms")
+        return model(dict(batch))[0]["elastic_tensor_full"]
+for _ in range(5): step()
+torch.cuda.synchronize()
+ts = []
+for _ in range(10):
+    torch.cuda.synchronize(); t = time.perf_counter(); step(); ts.append(time.perf_counter() - t)
+print("host enqueue time per forward (GPU idle at start): median %.2f ms, min %.2f ms" % (sorted(ts)[5] * 1e3, min(ts) * 1e3))
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(50): step()
+torch.cuda.synchronize(); print("50 back-to-back forwards: %.2f ms per forward" % ((time.perf_counter() - t) / 50 * 1e3))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(20): step()
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
