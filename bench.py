@@ -617,6 +617,25 @@ def run_rank(args):
                                 "weight_columns_full": lastf.tp.plan.weight_numel, "weight_columns_run": laste.tp.plan.weight_numel,
                                 "d_mid_full": lastf.tp.plan.d_mid, "d_mid_run": laste.tp.plan.d_mid},
         }
+        if world == 1 and not distributed and not args.no_extras:
+            # the same forward as ONE hipGraph replay per step (all ~45 launches, CSR build included, captured once for this
+            # batch shape): what the step costs without a host in the loop
+            from matten_amd.graphs import GraphedForward
+
+            with torch.no_grad():
+                gf = GraphedForward(model, batch)
+                for _ in range(3):
+                    gf(batch)
+                barrier()
+                tg = time.perf_counter()
+                for _ in range(20):
+                    gf(batch)
+                barrier()
+                ms_graph = 1e3 * (time.perf_counter() - tg) / 20
+            result["hipgraph_replay"] = {"ms_per_step": ms_graph, "value": n_edges * n_layers / (ms_graph * 1e-3), "steps": 20,
+                                         "warmup": 3, "note": "matten_amd.graphs.GraphedForward on the bench workload; the "
+                                         "headline `value` above is the eager loop"}
+            del gf
         if laste is not lastf and world == 1 and not distributed and not args.no_extras:
             # the same workload with the full last layer, timed by the same loop (shorter: 3 + 10 forwards)
             pconv.DEAD_PATH_ELIMINATION = False
