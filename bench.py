@@ -617,7 +617,7 @@ def run_rank(args):
                                 "weight_columns_full": lastf.tp.plan.weight_numel, "weight_columns_run": laste.tp.plan.weight_numel,
                                 "d_mid_full": lastf.tp.plan.d_mid, "d_mid_run": laste.tp.plan.d_mid},
         }
-        if world == 1 and not distributed and not args.no_extras:
+        if world == 1 and not distributed and not args.no_extras and os.environ.get("MATTEN_BENCH_NO_GRAPH") != "1":
             # the same forward as ONE hipGraph replay per step (all ~45 launches, CSR build included, captured once for this
             # batch shape): what the step costs without a host in the loop
             from matten_amd.graphs import GraphedForward
