@@ -287,7 +287,7 @@ def extras(dev):
         opt_l.step()
         return loss
 
-    t_l, _ = timed(large_step, 3, 10)
+    t_l, _ = timed(large_step, 5, 10)
     El = int(tbl["edge_index"].shape[1])
     del m_l, opt_l, tbl
     Et, Nt = int(tb["edge_index"].shape[1]), int(tb["pos"].shape[0])
@@ -636,6 +636,10 @@ def run_rank(args):
                                          "warmup": 3, "note": "matten_amd.graphs.GraphedForward on the bench workload; the "
                                          "headline `value` above is the eager loop"}
             del gf
+            import gc
+
+            gc.collect()               # the captured graph and its private memory pool go NOW, not at some collection
+            torch.cuda.empty_cache()   # inside a later timed loop (a one-off ~100 ms stall in the extras otherwise)
         if laste is not lastf and world == 1 and not distributed and not args.no_extras:
             # the same workload with the full last layer, timed by the same loop (shorter: 3 + 10 forwards)
             pconv.DEAD_PATH_ELIMINATION = False
