@@ -171,6 +171,58 @@ class TensorProductScatterFn(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+class FusedTensorProductFn(torch.autograd.Function):
+    """The training tensor product on the PRODUCTION kernel (MATTEN_TRAIN_TP=fused): forward = matten_tp_fused -- the last
+    radial layer on the matrix cores inside the kernel, the per-edge weights w[E, W] never reach memory -- and nothing
+    per-edge is kept for the backward except what the batch already holds (geometry, harmonics).  The backward
+    re-evaluates w for THIS layer with matten_radial_mlp (0.1 ms per layer at 290 k edges), runs the literal adjoint and
+    the radial MLP's adjoint, and drops w again: w exists for one layer at a time, inside the backward only (at batch
+    2048 that is 4 x 1 GB less live memory between the passes).  Opt-in because it is slower today -- batch 2048: 8.8 vs
+    7.1 ms per step: the fused kernel's operands (weights in fused column order, fp16 hi/lo fragments, range scale) are
+    re-derived from the changed parameters every step by the inference path's library-op code (~200 small launches),
+    which a training-side packing kernel would replace -- and not capturable in a hipGraph."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1, w2, mod, data, avg, num_neigh):
+        from .data.irreps import DataKey
+
+        dev = x.device
+        p, mlp = mod.plan, mod.weight_nn
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("MATTEN_TRAIN_TP=fused re-packs the radial weights with library ops that read values on the "
+                               "host: it cannot be captured in a hipGraph (use the default training path there)")
+        nb, r0, r1 = data[DataKey.AMD_RBF].tolist()
+        ctx.mod, ctx.avg, ctx.num_neigh = mod, avg, num_neigh
+        ctx.rbf = (int(nb), float(r0), float(r1))
+        ctx.graph = (data[DataKey.AMD_GEOM], data[DataKey.AMD_SH], data[DataKey.AMD_SRC], data["_amd_dst_sorted"])
+        ctx.out_csr = data.get("_amd_out_csr")
+        ctx.save_for_backward(x, w0, w1, w2)
+        h2p, w2p = mlp.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, None)
+        return ops.tp_fused(x, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
+                            mod._tables.get("gentries", dev), mod._tables.get("gumap", dev), len(p.fused_unit_map),
+                            p.fused_lds_floats_per_wave, p.d_mid, avg, num_neigh, a_split=mod.a_split(r0, r1))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w0, w1, w2 = ctx.saved_tensors
+        mod, dev = ctx.mod, g.device
+        mlp = mod.weight_nn
+        geom, sh, src, dst = ctx.graph
+        scales = mlp.pack_scales()
+        w0p, w1p, w2p = ops.radial_pack(w0, w1, w2, scales)                       # reference column order
+        w_edge = ops.radial_mlp(geom, *ctx.rbf, w0p, w1p, w2p, out_dtype=EDGE_STORAGE_DTYPE)   # transient
+        out_csr = ctx.out_csr if os.environ.get("MATTEN_TP_BWD_DX", "ordered") != "atomic" else None
+        dx, dw = ops.tp_backward_lit(x, w_edge, sh, src, dst, mod._tables.get("bw_blocks", dev),
+                                     mod._tables.get("bw_paths", dev), mod.plan.bw_max_mul, g.contiguous(), ctx.avg,
+                                     ctx.num_neigh, out_csr=out_csr,
+                                     blocks_cover_input=int(mod.plan.bw_blocks[:, 1].dot(2 * mod.plan.bw_blocks[:, 2] + 1))
+                                     == mod.plan.d_in)
+        del w_edge
+        nb, W = mlp.hs[0], mlp.hs[3]
+        d0, d1, d2 = ops.radial_mlp_bwd(geom, *ctx.rbf, w0p, w1p, w2p, W, dw, scales=scales)
+        return dx, d0[:nb], d1, d2[:, :W], None, None, None, None
+
+
 class GateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod):

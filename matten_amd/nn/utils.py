@@ -303,6 +303,11 @@ class UVUTensorProduct(torch.nn.Module):
             from ._nequip import ensure_training_edge_tensors
 
             ensure_training_edge_tensors(data)
+            if self.impl == "fused" and os.environ.get("MATTEN_TRAIN_TP", "paths") == "fused":
+                # opt-in: forward on the production kernel, w[E, W] re-evaluated per layer inside the backward only
+                mlp = self.weight_nn
+                return _ag.FusedTensorProductFn.apply(node_feats, mlp.layer0.weight, mlp.layer1.weight, mlp.layer2.weight,
+                                                      self, data, avg, num_neigh)
             w_edge = self.weight_nn.forward_train(data[DataKey.AMD_GEOM], int(nb), r0, r1)
             return _ag.TensorProductScatterFn.apply(node_feats, w_edge, self, data, avg, num_neigh)
         if self.impl == "fused":

@@ -520,3 +520,28 @@ def test_min_max_pooling_forward_and_gradients(golden_dir, reduce):
     for k, p in ref.named_parameters():
         if p.grad is not None:
             _close(named[k].grad, p.grad, 3e-3, f"grad {k}")
+
+
+def test_training_on_the_production_tensor_product_kernel(golden_dir, monkeypatch):
+    """MATTEN_TRAIN_TP=fused: the training forward runs matten_tp_fused (w[E, W] never materialised in the forward, nothing
+    per-edge saved for the backward); the backward re-evaluates w per layer.  Forward, every gradient and the parameters
+    against the oracle; same gradients as the default path (the forward differs by the fp16-split rounding)."""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _graphs(golden_dir, 12)
+    target = torch.randn(len(graphs), 21, generator=torch.Generator().manual_seed(7))
+    grads = {}
+    for mode in ("fused", "paths"):
+        monkeypatch.setenv("MATTEN_TRAIN_TP", mode)
+        ref, model = build_pair(LMAX2, ds, randomize_bn=True)
+        ref.train(), model.train()
+        torch.nn.functional.mse_loss(ref.decode(collate(graphs)), target).backward()
+        out = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+        torch.nn.functional.mse_loss(out, target.to(DEV)).backward()
+        named = dict(model.named_parameters())
+        for k, p in ref.named_parameters():
+            if p.grad is not None:
+                _close(named[k].grad, p.grad, 3e-3, f"[{mode}] grad {k}")
+        grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters()}
+    for k in grads["fused"]:
+        _close(grads["fused"][k], grads["paths"][k], 2e-3, f"fused vs default grad {k}")
