@@ -185,6 +185,20 @@ int matten_agg_linear(const float* agg, int64_t ld, const int32_t* order, const 
                       const float* wtab, int64_t w_stride, const int32_t* io_table, int64_t n_io,
                       const int32_t* blocks, int64_t n_blocks, const float* add, int64_t add_ld, int64_t d_out,
                       int64_t n_rows, float* out, matten_stream_t stream);
+/* matten_agg_linear with the conv layer's Gate (reference nn/utils.py:134-140) and eval-mode BatchNorm (:418,432)
+ * applied in the epilogue: out [n_rows, d_act] is the ACTIVATED row, the conv output row [n_rows, d_out] never exists.
+ *   cmeta[d_out, 4] int32 per column of lin2's output {type | act << 8, column in the activated row, gate lane, gate set}:
+ *     type 1 activated scalar, 2 gate scalar (kept in registers: set < matten_agg_linear_gate_sets(), lane = its position
+ *     in the table row that produced it), 3 gated component; gates are produced by table rows that precede their users
+ *     (host: plan.plan_agg_gate);  act codes and act_cst[8] as matten_gate_bn;
+ *   bn_scale / bn_shift [d_act] (both or NULL): weight / sqrt(running_var + eps) and, on 0e columns,
+ *     bias - running_mean * scale */
+int matten_agg_linear_gate(const float* agg, int64_t ld, const int32_t* order, const int32_t* seg, int64_t n_species,
+                           const float* wtab, int64_t w_stride, const int32_t* io_table, int64_t n_io,
+                           const int32_t* blocks, int64_t n_blocks, const float* add, int64_t add_ld, int64_t d_out,
+                           int64_t n_rows, const int32_t* cmeta, const float* act_cst, const float* bn_scale,
+                           const float* bn_shift, int64_t d_act, float* out, matten_stream_t stream);
+int matten_agg_linear_gate_sets(void);
 /* ------------------------------------------------------------------------------------------
  * Fused production path of one conv layer's edge work (reference nn/utils.py:246-251,260,263 +
  * nn/conv.py:113-120): the per-edge radial weights are never written to memory.

@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -40,6 +40,9 @@ SIGNATURES = {
     "matten_agg_linear_max_lds_bytes": (c_size_t, []),
     "matten_agg_linear": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int64,
                                   c_int64, P, P]),
+    "matten_agg_linear_gate": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int64,
+                                       c_int64, P, P, P, P, c_int64, P, P]),
+    "matten_agg_linear_gate_sets": (c_int, []),
     "matten_radial_hidden": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, c_int, P, P, P]),
     "matten_tp_max_cols": (c_int, []),
     "matten_tp_max_cols_l0": (c_int, []),

@@ -61,13 +61,37 @@ struct Args {
     float* out;           // [n_rows, d_out]
     int64_t ld;           // agg row stride (floats)
     int n_species, w_stride, n_io, n_blk, add_ld, d_out, n_rows;
+    // Gate (+ eval BatchNorm) applied in the epilogue (agg_linear_kernel<true>): out then holds the ACTIVATED row
+    const int4* cmeta;      // [d_out of lin2] per conv-output column {type | act << 8, column in the activated row, gate lane, gate set}
+    const float* act_cst;   // normalize2mom constants by activation code
+    const float* bn_scale;  // [out_ld] weight / sqrt(running_var + eps) per activated column, or NULL
+    const float* bn_shift;  // [out_ld] bias - running_mean * scale on 0e columns, 0 elsewhere
+    int out_ld;             // row stride of out
 };
+
+__device__ __forceinline__ float al_act(int code, float v) {
+    switch (code) {
+        case 1: return v / (1.0f + expf(-v));                          // silu
+        case 2: return tanhf(v);                                       // tanh
+        case 3: return 1.0f / (1.0f + expf(-v));                       // sigmoid
+        case 4: return (v > 20.0f ? v : log1pf(expf(v))) - 0.6931471805599453f;  // shifted softplus
+        case 5: return fabsf(v);                                       // abs
+        default: return v;
+    }
+}
+constexpr int AL_GATE_SETS = 3;   // table rows that may hold gate scalars (32 each): up to 96 gated channels per layer
 
 #ifdef AL_WAVES_PER_EU
 #define AL_OCC __attribute__((amdgpu_waves_per_eu(AL_WAVES_PER_EU, AL_WAVES_PER_EU)))
 #else
 #define AL_OCC
 #endif
+// GATE: the e3nn Gate (reference nn/utils.py:134-140) and the eval-mode BatchNorm that follow lin2 are applied while a
+// table row leaves the wave (reference nn/conv.py:209-213: conv -> Gate -> BatchNorm).  The gate scalars are lin2 outputs
+// of earlier table rows of the SAME 16 nodes: their activated values stay in the registers of the lanes that flushed
+// them (8 rows per lane and table row) and reach the gated channels' lanes through ds_bpermute -- no memory, no LDS
+// footprint.  Saves the conv output's write + read (150 MB per layer) and the gate kernel's launch.
+template <bool GATE>
 __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linear_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     AggIo* io_l = reinterpret_cast<AggIo*>(lds + a.w_stride);
@@ -185,10 +209,46 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
             }
         }
     };
+    float gate_reg[GATE ? AL_GATE_SETS : 1][8];
     auto flush_row = [&]() {
         const int w = mo * d3;
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the stage is written (LDS is in order per wave)
         __builtin_amdgcn_wave_barrier();
+        if constexpr (GATE) {
+            // per column of the conv output: what happens to it.  type 0: dropped (an irrep the Gate does not take), 1:
+            // activated scalar, 2: gate scalar (kept in gate_reg[set] of THIS lane), 3: gated component
+            const int4 cm = a.cmeta[out_off + min(fcol, w - 1)];
+            const int type = cm.x & 255, code = (cm.x >> 8) & 255;
+            const float cst = code ? a.act_cst[code] : 1.0f;
+            float bsc = 1.0f, bsh = 0.0f;
+            if (a.bn_scale && (type == 1 || type == 3)) bsc = a.bn_scale[cm.y], bsh = a.bn_shift[cm.y];
+            const int src_lane = (cm.z & 31) | (frow << 5);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int r = 2 * p + frow;
+                const int rid = rowid[r];
+                float v = stage[r * AL_STAGE_RS + min(fcol, w - 1)] + addv[p];
+                // every lane takes part in the exchanges; the set is per lane
+                float gv = __shfl(gate_reg[0][p], src_lane);
+#pragma unroll
+                for (int st = 1; st < AL_GATE_SETS; ++st) {
+                    const float o = __shfl(gate_reg[st][p], src_lane);
+                    gv = cm.w == st ? o : gv;
+                }
+                if (type == 2) {
+                    const float act = (code ? al_act(code, v) : v) * cst;
+#pragma unroll
+                    for (int st = 0; st < AL_GATE_SETS; ++st)
+                        if (cm.w == st && fcol < w) gate_reg[st][p] = act;
+                } else if (fcol < w && rid >= 0 && type != 0) {
+                    if (type == 1) v = (code ? al_act(code, v) : v) * cst;
+                    else v = v * gv;
+                    a.out[(int64_t)rid * a.out_ld + cm.y] = fmaf(v, bsc, bsh);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int r = 2 * p + frow;
@@ -271,6 +331,10 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
             }
         }
     };
+#pragma unroll
+    for (int st = 0; st < (GATE ? AL_GATE_SETS : 1); ++st)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) gate_reg[st][p] = 0.0f;
     f32x4 bufa[AL_BLK], bufb[AL_BLK];
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();   // rowid is visible to the wave
@@ -295,25 +359,29 @@ extern "C" size_t matten_agg_linear_max_lds_bytes(void) { return AL_MAX_LDS; }
 extern "C" int matten_agg_linear_max_mt(void) { return AL_MAX_MT; }   // (a table row is also at most 32 output floats wide)
 extern "C" int matten_agg_linear_block_chunks(void) { return AL_BLK; }
 
-extern "C" int matten_agg_linear(const float* agg, int64_t ld, const int32_t* order, const int32_t* seg,
-                                 int64_t n_species, const float* wtab, int64_t w_stride, const int32_t* io_table,
-                                 int64_t n_io, const int32_t* blocks, int64_t n_blocks, const float* add,
-                                 int64_t add_ld, int64_t d_out, int64_t n_rows, float* out, matten_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int agg_linear_launch(const float* agg, int64_t ld, const int32_t* order, const int32_t* seg, int64_t n_species,
+                             const float* wtab, int64_t w_stride, const int32_t* io_table, int64_t n_io,
+                             const int32_t* blocks, int64_t n_blocks, const float* add, int64_t add_ld, int64_t d_out,
+                             int64_t n_rows, float* out, const int32_t* cmeta, const float* act_cst, const float* bn_scale,
+                             const float* bn_shift, int64_t out_ld, hipStream_t stream) {
     if (n_rows < 0 || ld <= 0 || (ld & 3) || n_species <= 0 || w_stride <= 0 || (w_stride & 3) || n_io <= 0 ||
-        n_blocks <= 0 || d_out <= 0)
+        n_blocks <= 0 || d_out <= 0 || out_ld <= 0)
         return MATTEN_EINVAL;
     if (n_rows == 0) return MATTEN_OK;
     if (!agg || !wtab || !io_table || !blocks || !out) return MATTEN_EINVAL;
     if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
     if (!order && n_species != 1) return MATTEN_EINVAL;
     if (add && add_ld < d_out) return MATTEN_EINVAL;
+    if (cmeta && !act_cst) return MATTEN_EINVAL;
+    if ((bn_scale == nullptr) != (bn_shift == nullptr)) return MATTEN_EINVAL;
     const size_t lds = matten_agg_linear_lds_bytes(w_stride, n_io, n_blocks);
     if (lds > AL_MAX_LDS) return MATTEN_EINVAL;
     if (lds > 64 * 1024) {   // gfx950: 160 KB of LDS per CU, a workgroup may take more than the default 64 KB on request
         static bool raised = false;
         if (!raised) {
-            if (hipFuncSetAttribute((const void*)agg_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)agg_linear_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)AL_MAX_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)agg_linear_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)AL_MAX_LDS) != hipSuccess)
                 return MATTEN_ELAUNCH;
             raised = true;
@@ -323,8 +391,32 @@ extern "C" int matten_agg_linear(const float* agg, int64_t ld, const int32_t* or
     const int64_t grid = matten_cdiv(n_rows, AL_WAVES * AL_ROWS) + n_species;
     if (grid >= ((int64_t)1 << 31) || n_rows >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
     Args a{agg, order, seg, wtab, (const AggIo*)io_table, (const AggBlk*)blocks, add, out, ld, (int)n_species,
-           (int)w_stride, (int)n_io, (int)n_blocks, (int)add_ld, (int)d_out, (int)n_rows};
-    agg_linear_kernel<<<(unsigned)grid, AL_WAVES * 64, lds, stream>>>(a);
+           (int)w_stride, (int)n_io, (int)n_blocks, (int)add_ld, (int)d_out, (int)n_rows, (const int4*)cmeta, act_cst,
+           bn_scale, bn_shift, (int)out_ld};
+    if (cmeta) agg_linear_kernel<true><<<(unsigned)grid, AL_WAVES * 64, lds, stream>>>(a);
+    else agg_linear_kernel<false><<<(unsigned)grid, AL_WAVES * 64, lds, stream>>>(a);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
+}
+
+extern "C" int matten_agg_linear(const float* agg, int64_t ld, const int32_t* order, const int32_t* seg,
+                                 int64_t n_species, const float* wtab, int64_t w_stride, const int32_t* io_table,
+                                 int64_t n_io, const int32_t* blocks, int64_t n_blocks, const float* add,
+                                 int64_t add_ld, int64_t d_out, int64_t n_rows, float* out, matten_stream_t stream_) {
+    return agg_linear_launch(agg, ld, order, seg, n_species, wtab, w_stride, io_table, n_io, blocks, n_blocks, add, add_ld,
+                             d_out, n_rows, out, nullptr, nullptr, nullptr, nullptr, d_out, (hipStream_t)stream_);
+}
+
+extern "C" int matten_agg_linear_gate_sets(void) { return AL_GATE_SETS; }
+
+// matten_agg_linear followed by the layer's Gate and eval-mode BatchNorm in the same launch (see agg_linear_kernel<true>)
+extern "C" int matten_agg_linear_gate(const float* agg, int64_t ld, const int32_t* order, const int32_t* seg,
+                                      int64_t n_species, const float* wtab, int64_t w_stride, const int32_t* io_table,
+                                      int64_t n_io, const int32_t* blocks, int64_t n_blocks, const float* add,
+                                      int64_t add_ld, int64_t d_out, int64_t n_rows, const int32_t* cmeta,
+                                      const float* act_cst, const float* bn_scale, const float* bn_shift, int64_t d_act,
+                                      float* out, matten_stream_t stream_) {
+    if (!cmeta || d_act <= 0) return MATTEN_EINVAL;
+    return agg_linear_launch(agg, ld, order, seg, n_species, wtab, w_stride, io_table, n_io, blocks, n_blocks, add, add_ld,
+                             d_out, n_rows, out, cmeta, act_cst, bn_scale, bn_shift, d_act, (hipStream_t)stream_);
 }

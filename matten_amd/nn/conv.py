@@ -22,6 +22,9 @@ from .utils import ActivationLayer, NormalizationLayer, SpeciesLinear, UVUTensor
 
 import os as _os
 
+GATE_APPLIED = "_amd_gate_applied"    # batch-dict marker: the conv layer's lin2 kernel already applied Gate (+ BatchNorm)
+# Gate + eval BatchNorm inside the lin2 kernel's epilogue (matten_agg_linear_gate); MATTEN_GATE_FUSE=0 keeps them separate
+GATE_FUSE = _os.environ.get("MATTEN_GATE_FUSE", "1") != "0"
 KEPT_ONLY = "_amd_kept_irreps_only"   # batch-dict marker: node_features hold the irreps of the inference view only
 # inference: skip the output irreps of the last conv layer nothing reads (PointConv.build_inference_view); 0 = run them
 DEAD_PATH_ELIMINATION = _os.environ.get("MATTEN_DEAD_PATH_ELIMINATION", "1") != "0"
@@ -265,6 +268,14 @@ class PointConv(ModuleIrreps, torch.nn.Module):
                 and not _ag.needs_grad(x1, self_connection, self.lin2.weight, *self.tp.weight_nn.parameters())):
             ap, t, dev = self.agg_plan, self._agg_tables, x1.device
             agg = self.tp(x1, data, self.avg_num_neighbors, out_layout=(t.get("entries", dev), ap.ld))
+            gate = self.__dict__.get("_gate_fuse")   # set per call by PointConvWithActivation: (cmeta, act_cst, d_act, bn)
+            if gate is not None:
+                cmeta, act_cst, d_act, bn_scale, bn_shift = gate
+                data[DataKey.NODE_FEATURES] = ops.agg_linear_gate(
+                    agg, species, self._agg_wtab.get(self.lin2.weight), t.get("io", dev), t.get("blocks", dev), ap.d_out,
+                    cmeta, act_cst, d_act, add=self_connection, bn_scale=bn_scale, bn_shift=bn_shift)
+                data[GATE_APPLIED] = True
+                return data
             data[DataKey.NODE_FEATURES] = ops.agg_linear(agg, species, self._agg_wtab.get(self.lin2.weight),
                                                          t.get("io", dev), t.get("blocks", dev), ap.d_out,
                                                          add=self_connection)
@@ -307,8 +318,54 @@ class PointConvWithActivation(ModuleIrreps, torch.nn.Module):
         self.norm = NormalizationLayer(self.act.irreps_out, method=normalization)
         self.irreps_out[DataKey.NODE_FEATURES] = self.act.irreps_out
 
+    def _gate_fuse_args(self, dev):
+        """(cmeta, act_cst, d_act, bn_scale, bn_shift) for matten_agg_linear_gate, or None when this layer / mode keeps
+        the separate Gate kernel: training-mode BatchNorm, instance normalisation, the norm activation, or a layer
+        whose gates do not fit the kernel's register sets (plan.plan_agg_gate)."""
+        if not GATE_FUSE or self.conv.agg_plan is None or getattr(self.act, "activation_type", "gate") != "gate":
+            return None
+        if self.norm.method not in ("batch", "none", None):
+            return None
+        bn = self.norm.n
+        if bn is not None and bn.training:
+            return None
+        fuse = self.__dict__.get("_fuse_tables")
+        if fuse is None:
+            from .. import plan as _plan
+
+            cm = _plan.plan_agg_gate(self.conv.agg_plan, self.act.plan)
+            fuse = False if cm is None else DeviceTables(cmeta=cm)
+            self.__dict__["_fuse_tables"] = fuse
+            self.__dict__["_fuse_bn"] = DerivedWeight(self._fold_bn)
+        if fuse is False:
+            return None
+        scale = shift = None
+        if bn is not None:
+            scale, shift = self._fuse_bn.get(bn.running_mean, bn.running_var, bn.weight, bn.bias)
+        return (fuse.get("cmeta", dev), self.act._tables.get("act_cst", dev), self.act.plan.irreps_out.dim, scale, shift)
+
+    def _fold_bn(self, rm, rv, w, b):
+        """eval-mode BatchNorm as per-column (scale, shift) of the activated row (same folding as matten_gate_bn)"""
+        meta = torch.as_tensor(np.asarray(self.act.plan.meta).reshape(-1, 4)[:, 3].astype(np.int64), device=w.device)
+        bn_idx, mean_idx = meta & 0xFFFF, (meta >> 16) & 0xFFFF
+        scale = (w / torch.sqrt(rv + self.norm.n.eps))[bn_idx]
+        has_mean = mean_idx != 0xFFFF
+        mi = torch.where(has_mean, mean_idx, torch.zeros_like(mean_idx))
+        shift = torch.where(has_mean, b[mi] - rm[mi] * scale, torch.zeros_like(scale))
+        return scale.contiguous(), shift.contiguous()
+
     def forward(self, data: DataKey.Type) -> DataKey.Type:
-        data = self.conv(data)
+        x = data[DataKey.NODE_FEATURES]
+        fuse = None
+        if not _ag.needs_grad(x, *self.conv.parameters()) and x.shape[0] >= AGG_KM_MIN_ROWS:
+            fuse = self._gate_fuse_args(x.device)
+        self.conv.__dict__["_gate_fuse"] = fuse
+        try:
+            data = self.conv(data)
+        finally:
+            self.conv.__dict__["_gate_fuse"] = None
+        if data.pop(GATE_APPLIED, False):
+            return data   # lin2's kernel wrote the activated (and normalised) row
         # Gate and (eval-mode) BatchNorm run as one elementwise kernel
         data[DataKey.NODE_FEATURES] = self.act(data[DataKey.NODE_FEATURES], self.norm, data)
         return data

@@ -529,6 +529,38 @@ def agg_linear(agg, species_order, wtab, io_table, blocks, d_out: int, add=None)
     return out
 
 
+def agg_linear_gate(agg, species_order, wtab, io_table, blocks, d_out: int, cmeta, act_cst, d_act: int, add=None,
+                    bn_scale=None, bn_shift=None) -> torch.Tensor:
+    """agg_linear + the layer's Gate (+ eval-mode BatchNorm as per-column scale / shift) in one launch ->
+    the activated row [N, d_act] (include/matten_hip.h matten_agg_linear_gate; cmeta from plan.plan_agg_gate)"""
+    lib = _lib.load()
+    from .plan import AGG_BLOCK, AGG_GATE_SETS, AGG_MAX_MT
+    if (lib.matten_agg_linear_block_chunks() != AGG_BLOCK or lib.matten_agg_linear_max_mt() != AGG_MAX_MT
+            or lib.matten_agg_linear_gate_sets() != AGG_GATE_SETS):
+        raise _lib.MattenHipError("plan.AGG_BLOCK / AGG_MAX_MT / AGG_GATE_SETS do not match the library")
+    agg = _need(agg, torch.float32, "agg")
+    wtab = _need(wtab, torch.float32, "A fragments")
+    n_rows, ld = agg.shape
+    order, seg = species_order if species_order is not None else (None, None)
+    n_species = wtab.shape[0] if wtab.dim() == 2 else 1
+    if add is not None:
+        add = _need_rows(add, torch.float32, "add")
+    if cmeta.shape != (d_out, 4):
+        raise ValueError("cmeta must be [d_out, 4]")
+    if bn_scale is not None:
+        bn_scale, bn_shift = _need(bn_scale, torch.float32, "bn_scale"), _need(bn_shift, torch.float32, "bn_shift")
+        if bn_scale.numel() != d_act or bn_shift.numel() != d_act:
+            raise ValueError("bn_scale / bn_shift must have one value per activated column")
+    out = torch.empty(n_rows, d_act, dtype=torch.float32, device=agg.device)
+    with _timed(f"agg_linear/ld={ld}"):
+        rc = lib.matten_agg_linear_gate(_ptr(agg), ld, _ptr(order), _ptr(seg), n_species, _ptr(wtab), wtab.shape[-1],
+                                        _ptr(io_table), io_table.shape[0], _ptr(blocks), blocks.shape[0], _ptr(add),
+                                        add.stride(0) if add is not None else d_out, d_out, n_rows, _ptr(cmeta),
+                                        _ptr(act_cst), _ptr(bn_scale), _ptr(bn_shift), d_act, _ptr(out), _stream())
+    _lib.check(rc, "matten_agg_linear_gate")
+    return out
+
+
 _SL_ROWS_LDS_BYTES = 52 * 1024  # three workgroups of matten_species_linear_rows per CU
 
 

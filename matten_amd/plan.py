@@ -1023,6 +1023,58 @@ class AggLinearPlan:
     max_mt: int
 
 
+AGG_GATE_SETS = 3   # == matten_agg_linear_gate_sets(): table rows of lin2 that may hold gate scalars
+
+
+def plan_agg_gate(ap: "AggLinearPlan", gate: "GatePlan") -> Optional[np.ndarray]:
+    """Per column of lin2's output row (= the Gate's input row) what matten_agg_linear_gate's epilogue does with it:
+    cmeta[d_conv, 4] int32 {type | act << 8, column in the activated row, gate lane, gate set}; type 1 = activated scalar,
+    2 = gate scalar (its activated value stays in register set `gate set` of lane `gate lane` = its position inside the
+    table row that produced it), 3 = gated component (multiplied by the gate found there).  None when the layer does
+    not fit: more table rows with gates than the kernel has register sets, or a gate produced after a row that needs it."""
+    meta = np.asarray(gate.meta).reshape(-1, 4)
+    d_conv = int(ap.d_out)
+    rows = [(int(r[5]), int(r[6]) * int(r[3] & 255)) for r in np.asarray(ap.io_table).reshape(-1, 8)]   # (out_off, width)
+
+    def row_of(col):
+        for ii, (o, w) in enumerate(rows):
+            if o <= col < o + w:
+                return ii, col - o
+        return None
+
+    cm = np.zeros((d_conv, 4), dtype=np.int64)
+    gate_cols = {}
+    for o, (src, gcol, codes, _bn) in enumerate(meta):
+        act, gact = int(codes) & 255, (int(codes) >> 8) & 255
+        if gcol < 0:
+            cm[src] = (1 | (act << 8), o, 0, 0)
+        else:
+            gate_cols.setdefault(int(gcol), gact)
+            cm[src] = (3, o, int(gcol), -1)     # gate lane / set filled in below
+    set_of_row = {}
+    for gcol in sorted(gate_cols):
+        where = row_of(gcol)
+        if where is None:
+            return None
+        ii, lane = where
+        st = set_of_row.setdefault(ii, len(set_of_row))
+        if st >= AGG_GATE_SETS or lane >= 32:
+            return None
+        cm[gcol] = (2 | (gate_cols[gcol] << 8), 0, lane, st)
+    first_user = {}
+    for src in range(d_conv):
+        if cm[src][0] & 255 == 3:
+            gcol = int(cm[src][2])
+            g_row = row_of(gcol)[0]
+            u_row = row_of(src)
+            if u_row is None or u_row[0] <= g_row:
+                return None          # the gate must have left the wave before the first row that uses it
+            cm[src][2], cm[src][3] = cm[gcol][2], cm[gcol][3]
+    if any((cm[c][0] & 255) == 0 for c in range(d_conv)):
+        return None                  # (every column of a Gate input is a scalar, a gate or gated)
+    return cm.astype(np.int32)
+
+
 def plan_agg_linear(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[AggLinearPlan]:
     """None when an output irrep of lin2 has no input path (the mul_ir path handles those layers)."""
     irreps_out = Irreps(irreps_out).simplify()

@@ -484,6 +484,7 @@ def test_component_major_conv_matches_mul_ir_path(monkeypatch, golden_dir):
     gf, dsf = _fcc(5)
     import matten_amd.nn.conv as conv_mod
     monkeypatch.setattr(conv_mod, "AGG_KM_MIN_ROWS", 0)      # production takes the new path from 8192 rows: force it here
+    monkeypatch.setattr(conv_mod, "GATE_FUSE", False)        # (this test looks at lin2's own output, before the Gate)
     # (EQUIV_TEST: the reference's own test hparams -- 8 / 4-channel high-l blocks incl. 4x4o, no BatchNorm, Cartesian output)
     for graphs, ds, hp in ((gf, dsf, PAPER), (g100, ds100, PAPER), (g100, ds100, LMAX2), (g100, ds100, EQUIV_TEST)):
         torch.manual_seed(11)
@@ -509,6 +510,56 @@ def test_component_major_conv_matches_mul_ir_path(monkeypatch, golden_dir):
             close_blocks(y_new, y_old, rtol=5e-6, what="end to end", floor=5e-7)
         else:
             close(y_new, y_old, 2e-6, "end to end (Cartesian)")
+
+
+@pytest.mark.parametrize("hp_name", ["paper", "lmax2", "equiv"])
+def test_gate_and_batchnorm_inside_the_lin2_kernel(monkeypatch, golden_dir, hp_name):
+    """matten_agg_linear_gate: the conv layer's Gate and eval-mode BatchNorm applied in lin2's epilogue (gate scalars kept
+    in registers, exchanged by ds_bpermute) against the separate lin2 + gate kernels, per gated layer and end to end,
+    with randomised BatchNorm statistics / without BatchNorm; ragged species groups, groups smaller than one wave."""
+    from matten_amd.data.graph import average_num_neighbors, collate, crystal_graph
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+    from oracle.matten_ref.data import structures_from_json
+    import matten_amd.nn.conv as conv_mod
+
+    hp = {"paper": PAPER, "lmax2": LMAX2, "equiv": EQUIV_TEST}[hp_name]
+    structs = structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))[:40]
+    graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
+    ds = {"allowed_species": sorted({int(z) for s in structs for z in s["atomic_numbers"]}),
+          "average_num_neighbors": average_num_neighbors(graphs)}
+    monkeypatch.setattr(conv_mod, "AGG_KM_MIN_ROWS", 0)
+    torch.manual_seed(5)
+    model = ScalarTensorModel(backbone_hparams=dict(hp), dataset_hparams=ds).to(DEV).eval()
+    gen = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for k, b in model.named_buffers():
+            if k.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=gen))
+            if k.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=gen))
+        for k, p in model.named_parameters():
+            if ".norm.n.weight" in k:
+                p.copy_(0.5 + torch.rand(p.shape, generator=gen))
+            if ".norm.n.bias" in k:
+                p.copy_(0.1 * torch.randn(p.shape, generator=gen))
+    layers = [m for m in model.modules() if type(m).__name__ == "PointConvWithActivation"]
+    assert layers and all(m._gate_fuse_args(torch.device(DEV)) is not None for m in layers)
+    feats = {}
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(conv_mod, "GATE_FUSE", fused)
+        hooks = [m.register_forward_hook(lambda mod, inp, out, key=(fused, i): feats.__setitem__(key, out["node_features"].clone()))
+                 for i, m in enumerate(layers)]
+        with torch.no_grad():
+            outs[fused] = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+        for h in hooks:
+            h.remove()
+    for i in range(len(layers)):
+        close(feats[(True, i)], feats[(False, i)], 2e-6, f"{hp_name}: activated features of gated layer {i}")
+    if outs[True].dim() == 2:
+        close_blocks(outs[True], outs[False], rtol=5e-6, floor=5e-7, what=f"{hp_name}: end to end")
+    else:
+        close(outs[True], outs[False], 2e-6, f"{hp_name}: end to end (Cartesian)")
 
 
 def test_huge_radial_weights_stay_inside_the_fp16_split_range():
