@@ -334,19 +334,7 @@ __global__ __launch_bounds__(SL_WAVES * 64, SL_MIN_BLOCKS) void species_linear_k
     int b = blockIdx.x, s = 0, blo = 0, bhi = 0;
     constexpr int BR = SL_ROWS * SL_WAVES;
     if (seg) {
-        bool found = false;
-        for (s = 0; s < n_species; ++s) {
-            const int beg = seg[s], end = seg[s + 1];
-            const int nb = (end - beg + BR - 1) / BR;
-            if (b < nb) {
-                blo = beg + b * BR;
-                bhi = min(end, blo + BR);
-                found = true;
-                break;
-            }
-            b -= nb;
-        }
-        if (!found) return;
+        if (!matten_block_species<SL_WAVES * 64>(seg, n_species, BR, b, reinterpret_cast<int*>(lds), s, blo, bhi)) return;
     } else {
         blo = b * BR;
         bhi = min(n_rows, blo + BR);

@@ -134,19 +134,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void species_linear_rows_kernel(
     // ---- block -> (species, 16 rows) ----
     int b = blockIdx.x, s = 0, lo = 0, hi = 0;
     if (seg) {
-        bool found = false;
-        for (s = 0; s < n_species; ++s) {
-            const int beg = seg[s], end = seg[s + 1];
-            const int nb = (end - beg + TPB * ROWS - 1) / (TPB * ROWS);
-            if (b < nb) {
-                lo = beg + b * TPB * ROWS;
-                hi = min(end, lo + TPB * ROWS);
-                found = true;
-                break;
-            }
-            b -= nb;
-        }
-        if (!found) return;
+        // (the LDS is not in use yet: its first words serve as the look-up's scratch)
+        if (!matten_block_species<WAVES * 64>(seg, n_species, TPB * ROWS, b, reinterpret_cast<int*>(lds), s, lo, hi)) return;
     } else {
         lo = b * TPB * ROWS;
         hi = min(n_rows, lo + TPB * ROWS);
@@ -280,7 +269,8 @@ extern "C" int matten_species_linear_rows(const float* x, int64_t d_in, const in
     if (add && add_ld < d_out) return MATTEN_EINVAL;
     if (!add) add_ld = d_out;
     const int xs_stride = (int)(d_in | 1);  // odd row stride: the 16 rows of a column fall into 16 different LDS banks
-    const size_t lds = sizeof(float) * ((size_t)ROWS * xs_stride + (size_t)((w_stride + 3) & ~3) + 8 * (size_t)n_segs);
+    size_t lds = sizeof(float) * ((size_t)ROWS * xs_stride + (size_t)((w_stride + 3) & ~3) + 8 * (size_t)n_segs);
+    lds = lds < sizeof(int) * (WAVES * 64 + 4) ? sizeof(int) * (WAVES * 64 + 4) : lds;   // (the species look-up's scratch)
     if (lds > 64 * 1024) return MATTEN_EINVAL;  // rows or weight table too large for this variant: use matten_species_linear
     const int64_t blocks = matten_cdiv(n_rows, TPB * ROWS) + (order ? n_species : 0);
     species_linear_rows_kernel<<<(unsigned)blocks, WAVES * 64, lds, stream>>>(
