@@ -364,6 +364,20 @@ int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, int n_basis
 int matten_radial_pack(const float* w0, const float* w1, const float* w2, int n_basis, int nb_pad, int w_cols, int w_pad,
                        float scale0, float scale1, float scale2, float* w0p, float* w1p, float* w2p,
                        matten_stream_t stream);
+/* Operands of matten_tp_fused derived from the RAW radial layers by kernels (training on the production kernel):
+ * matten_radial_pack_cols: as matten_radial_pack, the last layer gathered through cols[n_cols] int64 (fused column order
+ *   of plan.fused_cols, -1 = zero column), zero up to w_pad;
+ * matten_radial_h_scale: out2 = [s, 1/s], the power of two <= 1 that keeps the hidden features inside the fp16 range
+ *   (bound from the two layers' column-sum norms, as nn/utils.py RadialMLP._fp16_scale);
+ * matten_split_a_tiles: w2p [32, w_pad] -> the fp16 hi / lo A fragments of every group entry (word 5 = first column,
+ *   6 = first tile, 7 = tile count) + scale_inv[n_entries] = 1 / (entry scale) * h_scale[1] (h_scale may be NULL). */
+int matten_radial_pack_cols(const float* w0, const float* w1, const float* w2, int n_basis, int nb_pad, int w_cols,
+                            const int64_t* cols, int n_cols, int w_pad, float scale0, float scale1, float scale2, float* w0p,
+                            float* w1p, float* w2p, matten_stream_t stream);
+int matten_radial_h_scale(const float* w0, const float* w1, int n_basis, float r_start, float r_end, float act_cst,
+                          float* out2, matten_stream_t stream);
+int matten_split_a_tiles(const float* w2p, int64_t w_pad, const int32_t* group_entries, int64_t n_entries,
+                         const float* h_scale, uint16_t* frag, float* scale_inv, matten_stream_t stream);
 /* out[i] = src[idx[i]] * scale[(scale_by_source ? idx[i] : i) % scale_period]: the per-species re-packing of a flat e3nn
  * weight (idx = gather table, scale by output position) and its adjoint (idx = inverse permutation, scale by source) */
 int matten_gather_scale(const float* src, const int64_t* idx, const float* scale, int64_t n, int64_t scale_period,

@@ -177,10 +177,9 @@ class FusedTensorProductFn(torch.autograd.Function):
     per-edge is kept for the backward except what the batch already holds (geometry, harmonics).  The backward
     re-evaluates w for THIS layer with matten_radial_mlp (0.1 ms per layer at 290 k edges), runs the literal adjoint and
     the radial MLP's adjoint, and drops w again: w exists for one layer at a time, inside the backward only (at batch
-    2048 that is 4 x 1 GB less live memory between the passes).  Opt-in because it is slower today -- batch 2048: 8.8 vs
-    7.1 ms per step: the fused kernel's operands (weights in fused column order, fp16 hi/lo fragments, range scale) are
-    re-derived from the changed parameters every step by the inference path's library-op code (~200 small launches),
-    which a training-side packing kernel would replace -- and not capturable in a hipGraph."""
+    2048 that is 4 x 1 GB less live memory between the passes).  The fused kernel's operands (weights in fused column
+    order, range scale, fp16 hi/lo fragments) come from the raw layers through three small kernels
+    (ops.fused_operands), so the step stays capturable."""
 
     @staticmethod
     def forward(ctx, x, w0, w1, w2, mod, data, avg, num_neigh):
@@ -188,19 +187,21 @@ class FusedTensorProductFn(torch.autograd.Function):
 
         dev = x.device
         p, mlp = mod.plan, mod.weight_nn
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("MATTEN_TRAIN_TP=fused re-packs the radial weights with library ops that read values on the "
-                               "host: it cannot be captured in a hipGraph (use the default training path there)")
         nb, r0, r1 = data[DataKey.AMD_RBF].tolist()
         ctx.mod, ctx.avg, ctx.num_neigh = mod, avg, num_neigh
         ctx.rbf = (int(nb), float(r0), float(r1))
         ctx.graph = (data[DataKey.AMD_GEOM], data[DataKey.AMD_SH], data[DataKey.AMD_SRC], data["_amd_dst_sorted"])
         ctx.out_csr = data.get("_amd_out_csr")
         ctx.save_for_backward(x, w0, w1, w2)
-        h2p, w2p = mlp.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, None)
-        return ops.tp_fused(x, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
-                            mod._tables.get("gentries", dev), mod._tables.get("gumap", dev), len(p.fused_unit_map),
-                            p.fused_lds_floats_per_wave, p.d_mid, avg, num_neigh, a_split=mod.a_split(r0, r1))
+        # the fused kernel's operands from the raw layers: four small launches, nothing read on the host (the inference
+        # path derives them once with library ops and caches them; here the parameters change every step)
+        gent = mod._tables.get("gentries", dev)
+        w0p, w1p, w2p, hs, frag, inv = ops.fused_operands(w0, w1, w2, mlp.pack_scales(), mod._tables.get("fused_cols", dev),
+                                                          gent, p.fused_a_tiles, r0, r1, mlp.act_cst)
+        h2p = ops.radial_hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, w0p, w1p, hs)
+        return ops.tp_fused(x, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC], gent,
+                            mod._tables.get("gumap", dev), len(p.fused_unit_map), p.fused_lds_floats_per_wave, p.d_mid, avg,
+                            num_neigh, a_split=(frag, inv))
 
     @staticmethod
     def backward(ctx, g):

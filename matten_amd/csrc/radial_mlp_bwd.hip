@@ -371,3 +371,131 @@ extern "C" int matten_radial_pack(const float* w0, const float* w1, const float*
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }
+
+// ---- operands of matten_tp_fused derived from the RAW radial layers by kernels (training on the production kernel: the
+// parameters change every step, the inference path's cached library-op derivations would run every step) --------------
+namespace {
+
+// as radial_pack_kernel, the last layer's columns gathered through `cols` (fused column order; -1 = structural zero)
+__global__ void radial_pack_cols_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                        const float* __restrict__ w2, int nb, int nb_pad, int W,
+                                        const int64_t* __restrict__ cols, int n_cols, int w_pad, float s0, float s1, float s2,
+                                        float* __restrict__ w0p, float* __restrict__ w1p, float* __restrict__ w2p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n0 = nb_pad * HID, n1 = HID * HID, n2 = HID * w_pad;
+    if (i < n0) {
+        w0p[i] = (i / HID) < nb ? w0[i] * s0 : 0.0f;
+    } else if (i < n0 + n1) {
+        w1p[i - n0] = w1[i - n0] * s1;
+    } else if (i < n0 + n1 + n2) {
+        const int j = i - n0 - n1, k = j / w_pad, q = j - k * w_pad;
+        const int64_t src = q < n_cols ? cols[q] : -1;
+        w2p[j] = src >= 0 ? w2[(int64_t)k * W + src] * s2 : 0.0f;
+    }
+}
+
+// [s, 1 / s]: the power of two the hidden features are multiplied by so that |s h2| < 2^15 for every edge length
+// (nn/utils.py RadialMLP._fp16_scale, same bound: |h2| <= sqrt(2/c) sqrt(nb) pi / c * n0 * n1 with the column-sum norms
+// n0 = max_col sum_k |W0[k,col]| (k+1) / sqrt(nb), n1 = max_col sum_k |W1[k,col]| act_cst / sqrt(h))
+__global__ void radial_h_scale_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int nb, float c,
+                                      float act_cst, float* __restrict__ out) {
+    __shared__ float red[2][HID];
+    const int col = threadIdx.x;   // 32 threads
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int k = 0; k < nb; ++k) a0 += fabsf(w0[k * HID + col]) * (float)(k + 1);
+    for (int k = 0; k < HID; ++k) a1 += fabsf(w1[k * HID + col]);
+    red[0][col] = a0 / sqrtf((float)nb);
+    red[1][col] = a1 * (act_cst / sqrtf((float)HID));
+    __syncthreads();
+    if (col == 0) {
+        float n0 = 0.0f, n1 = 0.0f;
+        for (int i = 0; i < HID; ++i) n0 = fmaxf(n0, red[0][i]), n1 = fmaxf(n1, red[1][i]);
+        const float bound = sqrtf(2.0f / c) * sqrtf((float)nb) * 3.141592653589793f / c * n0 * n1;
+        float s = 1.0f;
+        if (bound > 32768.0f) s = exp2f(floorf(log2f(16384.0f / fmaxf(bound, 1e-30f))));
+        if (!(s > 0.0f) || isinf(s) || isnan(s)) s = exp2f(-100.0f);
+        out[0] = s;
+        out[1] = 1.0f / s;
+    }
+}
+
+// group entries' weight blocks as the fp16 hi / lo MFMA fragments matten_tp_fused consumes (same values as
+// ops.split_a_tiles): per entry a power-of-two scale that puts its largest magnitude in [2^13, 2^14).
+// frag[(a_tile + mt) * 64 + lane][16 halves: hi(kk 0..7) | lo(kk 0..7)], lane = 16 g + c:
+//   value = W2p[pi(kk, g)][w_base + 16 mt + c] * scale,  pi(kk, g) = 16 (kk >> 2) + 4 g + (kk & 3)
+// scale_inv[entry] = 2^-(scale exponent) * h_scale_inv
+__global__ void split_a_tiles_kernel(const float* __restrict__ w2p, int w_pad, const int32_t* __restrict__ entries,
+                                     const float* __restrict__ h_scale, _Float16* __restrict__ frag,
+                                     float* __restrict__ scale_inv) {
+    __shared__ float red[256];
+    const int e = blockIdx.x;
+    const int32_t* ge = entries + (int64_t)e * 32;
+    const int w_base = ge[5], a_tile = ge[6], n_mt = ge[7];
+    const int ncol = 16 * n_mt;
+    float amax = 0.0f;
+    for (int i = threadIdx.x; i < HID * ncol; i += blockDim.x) {
+        const int k = i / ncol, q = i - k * ncol;
+        amax = fmaxf(amax, fabsf(w2p[(int64_t)k * w_pad + w_base + q]));
+    }
+    red[threadIdx.x] = amax;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    amax = red[0];
+    int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+    ex = amax > 0.0f ? max(-100, min(100, ex)) : 13;
+    const float sc = __uint_as_float((unsigned)(127 + 13 - ex) << 23);
+    if (threadIdx.x == 0) scale_inv[e] = __uint_as_float((unsigned)(127 - 13 + ex) << 23) * (h_scale ? h_scale[1] : 1.0f);
+    const float tiny = 6.103515625e-05f;
+    for (int i = threadIdx.x; i < n_mt * 64; i += blockDim.x) {
+        const int mt = i >> 6, lane = i & 63, g = lane >> 4, c = lane & 15;
+        _Float16* dst = frag + ((int64_t)(a_tile + mt) * 64 + lane) * 16;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+            const float v = w2p[(int64_t)k * w_pad + w_base + 16 * mt + c] * sc;
+            const float hi = fabsf(v) < tiny ? 0.0f : (float)(_Float16)v;
+            float lo = (v - hi) * 2048.0f;
+            lo = fabsf(lo) < tiny ? 0.0f : lo;
+            dst[kk] = (_Float16)hi;
+            dst[8 + kk] = (_Float16)lo;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int matten_radial_pack_cols(const float* w0, const float* w1, const float* w2, int n_basis, int nb_pad, int w_cols,
+                                       const int64_t* cols, int n_cols, int w_pad, float scale0, float scale1, float scale2,
+                                       float* w0p, float* w1p, float* w2p, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_basis <= 0 || nb_pad < n_basis || w_cols <= 0 || n_cols <= 0 || w_pad < n_cols) return MATTEN_EINVAL;
+    if (!w0 || !w1 || !w2 || !cols || !w0p || !w1p || !w2p) return MATTEN_EINVAL;
+    const int n = nb_pad * HID + HID * HID + HID * w_pad;
+    radial_pack_cols_kernel<<<(unsigned)matten_cdiv(n, 256), 256, 0, stream>>>(w0, w1, w2, n_basis, nb_pad, w_cols, cols,
+                                                                              n_cols, w_pad, scale0, scale1, scale2, w0p,
+                                                                              w1p, w2p);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_radial_h_scale(const float* w0, const float* w1, int n_basis, float r_start, float r_end, float act_cst,
+                                     float* out2, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_basis <= 0 || !(r_end > r_start) || !w0 || !w1 || !out2) return MATTEN_EINVAL;
+    radial_h_scale_kernel<<<1, HID, 0, stream>>>(w0, w1, n_basis, r_end - r_start, act_cst, out2);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_split_a_tiles(const float* w2p, int64_t w_pad, const int32_t* group_entries, int64_t n_entries,
+                                    const float* h_scale, uint16_t* frag, float* scale_inv, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_entries <= 0 || w_pad <= 0 || !w2p || !group_entries || !frag || !scale_inv) return MATTEN_EINVAL;
+    split_a_tiles_kernel<<<(unsigned)n_entries, 256, 0, stream>>>(w2p, (int)w_pad, group_entries, h_scale, (_Float16*)frag,
+                                                                 scale_inv);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}

@@ -269,6 +269,7 @@ class UVUTensorProduct(torch.nn.Module):
             bw_col_meta=self.plan.bw_col_meta, bw_nnz_ijk=self.plan.bw_nnz_ijk, bw_nnz_c=self.plan.bw_nnz_c,
             bw_in_ptr=self.plan.bw_in_ptr, bw_in_cols=self.plan.bw_in_cols,
             bw_blocks=self.plan.bw_blocks, bw_paths=self.plan.bw_paths,
+            fused_cols=self.plan.fused_cols,
         )
 
         self._a_split = DerivedWeight(self._split_last_layer)

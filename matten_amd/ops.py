@@ -234,6 +234,35 @@ def radial_pack(w0, w1, w2, scales):
     return w0p, w1p, w2p
 
 
+def fused_operands(w0, w1, w2, scales, cols, group_entries, n_tiles: int, r_start: float, r_end: float, act_cst: float):
+    """Everything matten_radial_hidden + matten_tp_fused need, derived from the RAW radial layers by four small launches
+    and no host reads (capturable): -> (w0p, w1p, w2p in fused column order, h_scale [2], a_split fragments, a_scale_inv)"""
+    lib = _lib.load()
+    w0, w1, w2 = (_need(w, torch.float32, n) for w, n in ((w0, "layer0.weight"), (w1, "layer1.weight"), (w2, "layer2.weight")))
+    cols = _need(cols, torch.int64, "fused_cols")
+    group_entries = _need(group_entries, torch.int32, "group_entries")
+    nb, h = w0.shape
+    W, n_cols = w2.shape[1], cols.numel()
+    nb_pad, w_pad = (nb + 3) // 4 * 4, (n_cols + 15) // 16 * 16 + 16   # +16: whole tiles may start at any entry
+    dev = w0.device
+    w0p = torch.empty(nb_pad, h, dtype=torch.float32, device=dev)
+    w1p = torch.empty(h, h, dtype=torch.float32, device=dev)
+    w2p = torch.empty(h, w_pad, dtype=torch.float32, device=dev)
+    hs = torch.empty(2, dtype=torch.float32, device=dev)
+    n_ent = group_entries.shape[0]
+    frag = torch.empty(n_tiles, 64, 16, dtype=torch.float16, device=dev)
+    inv = torch.empty(n_ent, dtype=torch.float32, device=dev)
+    st = _stream()
+    _lib.check(lib.matten_radial_pack_cols(_ptr(w0), _ptr(w1), _ptr(w2), nb, nb_pad, W, _ptr(cols), n_cols, w_pad,
+                                           float(scales[0]), float(scales[1]), float(scales[2]), _ptr(w0p), _ptr(w1p),
+                                           _ptr(w2p), st), "matten_radial_pack_cols")
+    _lib.check(lib.matten_radial_h_scale(_ptr(w0), _ptr(w1), nb, float(r_start), float(r_end), float(act_cst), _ptr(hs), st),
+               "matten_radial_h_scale")
+    _lib.check(lib.matten_split_a_tiles(_ptr(w2p), w_pad, _ptr(group_entries), n_ent, _ptr(hs), _ptr(frag), _ptr(inv), st),
+               "matten_split_a_tiles")
+    return w0p, w1p, w2p, hs, frag, inv
+
+
 def gather_scale(src, idx, scale, scale_by_source: bool = False, perm2=None):
     """out[i] = src.flat[idx.flat[i]] * scale[(idx.flat[i] if scale_by_source else i) % len(scale)], shaped like idx.
     perm2 (int64 [len(scale)]): also return out2[r, q] = out[r, perm2[q]] (the same launch)"""

@@ -545,3 +545,17 @@ def test_training_on_the_production_tensor_product_kernel(golden_dir, monkeypatc
         grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters()}
     for k in grads["fused"]:
         _close(grads["fused"][k], grads["paths"][k], 2e-3, f"fused vs default grad {k}")
+    # capturable: the kernel's operands are derived by kernels, nothing is read on the host
+    from matten_amd.graphs import GraphedTrainStep
+
+    monkeypatch.setenv("MATTEN_TRAIN_TP", "fused")
+    _, model = build_pair(LMAX2, ds, randomize_bn=True)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
+    batch, tgt = collate(graphs, device=DEV), target.to(DEV)
+    gs = GraphedTrainStep(model, opt, lambda preds, t: torch.nn.functional.mse_loss(preds["elastic_tensor_full"], t), batch, tgt,
+                          warmup=2)
+    l0 = float(gs.step(batch, tgt))
+    for _ in range(5):
+        l1 = float(gs.step(batch, tgt))
+    assert np.isfinite(l1) and l1 < l0
