@@ -1182,3 +1182,29 @@ def test_atom_feats_ride_behind_the_species_embedding(golden_dir):
     for k, p in ref.named_parameters():
         if p.grad is not None and "layer0_convnet.conv" in k:
             close(named[k].grad, p.grad, 3e-3, f"grad {k}")
+
+
+def test_kernel_path_switch_at_the_streaming_threshold():
+    """Batches just below / at / above nn.conv.AGG_KM_MIN_ROWS nodes take different lin2 / Gate kernels (row-resident +
+    gate kernel vs streaming lin2 with the Gate in its epilogue): the same crystals give the same predictions (2e-6 per
+    irrep block) whichever side of the switch their batch falls on, and the oracle's on the crystals it is run for."""
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import batch_graphs_gpu, collate, crystal_graph
+    import matten_amd.nn.conv as conv_mod
+
+    assert conv_mod.AGG_KM_MIN_ROWS == 8192
+    structs = synthetic.fcc64_structures(130)
+    triples = [(s["cart_coords"], s["lattice"], s["atomic_numbers"]) for s in structs]
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    ref, model = build_pair(PAPER, ds, randomize_bn=True)
+    outs = {}
+    with torch.no_grad():
+        for n in (127, 128, 129):   # 8128 / 8192 / 8256 nodes
+            outs[n] = model.decode(dict(batch_graphs_gpu(triples[:n], 5.0, DEV)))["elastic_tensor_full"]
+        want = ref.decode(collate([crystal_graph(*triples[i], 5.0) for i in (0, 63, 126)]))
+    close_blocks(outs[128][:127], outs[127], rtol=2e-6, floor=2e-6, what="8192-node batch vs 8128-node batch")
+    close_blocks(outs[129][:128], outs[128], rtol=2e-6, floor=2e-6, what="8256-node batch vs 8192-node batch")
+    close_blocks(outs[127][[0, 63, 126]], want, what="8128-node batch vs oracle",
+                 want64=_want64(ref, [crystal_graph(*triples[i], 5.0) for i in (0, 63, 126)]))
+    close_blocks(outs[129][[0, 63, 126]], want, what="8256-node batch vs oracle",
+                 want64=_want64(ref, [crystal_graph(*triples[i], 5.0) for i in (0, 63, 126)]))
