@@ -1130,6 +1130,12 @@ def plan_agg_linear(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[AggLin
             ib = blk_of_slot[pth.slot]
             for uu in range(mul_c):
                 slot_src.append((ib, uoff_of_slot[pth.slot] + uvu.group_entry_u0[e] + uu))
+        if any(sb < 0 for sb, _ in slot_src):
+            # alignment holes inside the region (a piece whose channel count is not a power of two): nobody writes those
+            # slots of agg, and the reader only masks the slots PAST the region's end -- 0 x garbage is NaN when the
+            # garbage is.  Such layers keep the mul_ir row and matten_species_linear.  (Found by the model fuzzer with
+            # NaN-filled buffers; every shipped configuration has power-of-two multiplicities.)
+            return None
         K = len(slot_src)
         T = -(-K // AGG_CHUNK)
         Kpad = T * AGG_CHUNK

@@ -14,6 +14,15 @@ from matten_amd.data.graph import collate, crystal_graph
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 GRAD = len(sys.argv) > 3 and sys.argv[3] == "grad"
+if os.environ.get("NAN_EMPTY"):   # debugging aid: uninitialised output buffers hold NaN instead of whatever was there
+    _empty, _empty_like = torch.empty, torch.empty_like
+    def _nan_empty(*a, **k):
+        t = _empty(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+    def _nan_empty_like(*a, **k):
+        t = _empty_like(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+    torch.empty, torch.empty_like = _nan_empty, _nan_empty_like
 bad = 0
 for case in range(n_cases):
     lmax = int(rng.integers(1, 5))

@@ -1208,3 +1208,25 @@ def test_kernel_path_switch_at_the_streaming_threshold():
                  want64=_want64(ref, [crystal_graph(*triples[i], 5.0) for i in (0, 63, 126)]))
     close_blocks(outs[129][[0, 63, 126]], want, what="8256-node batch vs oracle",
                  want64=_want64(ref, [crystal_graph(*triples[i], 5.0) for i in (0, 63, 126)]))
+
+
+def test_non_power_of_two_multiplicities_keep_the_mul_ir_row(monkeypatch):
+    """A piece of the component-major neighbour-sum row whose channel count is not a power of two would leave alignment
+    holes that no kernel writes and the streaming lin2 multiplies by structural-zero weights (0 x garbage): such layers
+    must not get an AggLinearPlan.  Forced onto the streaming path's batch size with NaN-filled buffers the model still
+    matches the oracle (found by tests/fuzz_models.py with NAN_EMPTY=1)."""
+    from matten_amd.data import synthetic
+    from matten_amd.data.graph import collate
+    import matten_amd.nn.conv as conv_mod
+
+    monkeypatch.setattr(conv_mod, "AGG_KM_MIN_ROWS", 0)
+    _empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: (lambda t: t.fill_(float("nan")) if t.is_floating_point() and t.is_cuda else t)(_empty(*a, **k)))
+    hp = dict(PAPER, conv_layer_irreps="5x0o+3x0e+17x1o+8x3o+32x3e+4x4e", num_layers=2)
+    graphs, ds = _fcc(2)
+    ref, model = build_pair(hp, ds, randomize_bn=True)
+    convs = [m for m in model.modules() if type(m).__name__ == "PointConv"]
+    assert any(m.agg_plan is None for m in convs)          # 5, 3, 17 channels: holes -> no component-major plan
+    got, want = _run_pair(ref, model, graphs)
+    assert torch.isfinite(got).all()
+    close_blocks(got, want, what="odd multiplicities at the streaming batch size", want64=_want64(ref, graphs))
