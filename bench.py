@@ -55,6 +55,13 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1] / configs[3] / predict() extras")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL path (init, barrier, all_gather) even with one rank (same as MATTEN_FORCE_DIST=1)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend of the N > 1 path: nccl (= RCCL, the real one) or gloo (REHEARSAL only: "
+                         "the [B,21] predictions are gathered through host tensors)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL only: every local rank runs on cuda:0 (RCCL refuses two ranks on one device, so this "
+                         "needs --backend gloo); exercises the N > 1 branch on a 1-GPU box, measures nothing")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the fixed VALU / copy calibration kernels")
     return ap.parse_args()
 
 
@@ -90,6 +97,60 @@ def _pmc_traffic(kernel: str, field: str = "hbm_bytes_mean_launch"):
                                                     "rocprofv3 --pmc run of bench.py --steps 2, not this run")
     except Exception:
         return None, None
+
+
+def calibrate(dev, copy_floats: int = 1 << 28, valu_iters: int = 4096, reps: int = 5):
+    """Fixed, model-independent work timed with HIP events on the current stream (csrc/calib.hip): what THIS box at THIS
+    moment sustains.  Two lines of the same commit taken on different pool machines (or DVFS states) differ in these
+    numbers the way their ms_per_step differ; a kernel change shows in ms_per_step only.
+      valu: 8 waves per SIMD of dependent fp32 FMA chains on every CU -> ns per wave64 VALU instruction and SIMD, and the
+            effective shader clock under that load (s_memtime ticks per 100 MHz s_memrealtime tick)
+      copy: 1 GiB read + 1 GiB written, 16 bytes per lane -> GB/s"""
+    import ctypes
+
+    from matten_amd import _lib, ops
+
+    lib = _lib.load()
+    stream = ops._stream()
+    src = torch.empty(copy_floats, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    scratch = torch.zeros(4, dtype=torch.float32, device=dev)
+    clocks = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def timed(fn):
+        fn()                                   # untimed first launch (code object load, clocks ramp)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        return ms[len(ms) // 2]
+
+    valu_ms = timed(lambda: _lib.check(lib.matten_calib_valu(valu_iters, scratch.data_ptr(), clocks.data_ptr(), stream),
+                                       "matten_calib_valu"))
+    ticks, ref100 = (int(v) for v in clocks.tolist())
+    copy_ms = timed(lambda: _lib.check(lib.matten_calib_copy(src.data_ptr(), dst.data_ptr(), copy_floats, stream),
+                                       "matten_calib_copy"))
+    insts = int(lib.matten_calib_valu_insts_per_simd(valu_iters))
+    del src, dst
+    return {
+        "valu": {"wave_insts_per_simd": insts, "ms": valu_ms, "ns_per_wave_inst_per_simd": 1e6 * valu_ms / insts,
+                 "sclk_mhz_under_valu_load": 100.0 * ticks / ref100 if ref100 else None,
+                 "cycles_per_wave_inst": (ticks / (insts / 8.0)) / 8.0 if insts else None},
+        "copy": {"bytes_moved": 8 * copy_floats, "ms": copy_ms, "GBps": 8 * copy_floats / (copy_ms * 1e-3) / 1e9},
+    }
+
+
+def _valu_profile():
+    """per-launch SQ instruction counts of tp_fused_kernel from the committed rocprofv3 PMC run (profiles/tp_fused_valu.json,
+    written by tools/collect_valu.sh: separate --pmc passes of this command with --steps 2), or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "tp_fused_valu.json")) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def _cpu_model() -> str:
@@ -382,14 +443,22 @@ def run_rank(args):
     # one process per GPU under torch.distributed.run; --force-dist exercises the RCCL path with a
     # single rank too (init, barrier, all_gather) so it can be smoke-tested on a 1-GPU box
     distributed = world > 1 or (args.force_dist and "RANK" in os.environ)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.share_gpu and args.backend != "gloo":
+        raise SystemExit("--share-gpu is a rehearsal of the N > 1 branch on one device: RCCL refuses two ranks per GPU, "
+                         "add --backend gloo")
+    dev_index = 0 if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    via_host = distributed and args.backend == "gloo"   # rehearsal: predictions gathered through host tensors
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if via_host:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from __graft_entry__ import PAPER_HPARAMS
     from matten_amd import ops
@@ -398,22 +467,22 @@ def run_rank(args):
     from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
 
     B = args.crystals
-    # rank r owns crystals [r*B, (r+1)*B) of the global synthetic set (seed offset per shard)
-    graphs = synthetic.fcc64_graphs(B, seed=synthetic.FCC_SEED + rank)
+    # one GPU: the config-3 set; N > 1: rank r owns crystals [r*B, (r+1)*B) of ONE set of N*B crystals
+    graphs = synthetic.fcc64_shard(rank, world, B)
     ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
     torch.manual_seed(35)
     model = ScalarTensorModel(backbone_hparams=dict(PAPER_HPARAMS), dataset_hparams=ds).to(dev).eval()
     batch = collate(graphs, device=dev)
     n_edges = int(batch["edge_index"].shape[1])
     n_nodes = int(batch["pos"].shape[0])
-    gathered = torch.empty(world * B, 21, dtype=torch.float32, device=dev) if distributed else None
+    gathered = torch.empty(world * B, 21, dtype=torch.float32, device="cpu" if via_host else dev) if distributed else None
 
     def step():
         with torch.no_grad():
             preds, _ = model(dict(batch))
             out = preds["elastic_tensor_full"]
             if distributed:
-                dist.all_gather_into_tensor(gathered, out)
+                dist.all_gather_into_tensor(gathered, out.cpu() if via_host else out)
                 return gathered
             return out
 
@@ -428,6 +497,12 @@ def run_rank(args):
     for _ in range(args.warmup):
         step()
     barrier()
+    calibration = None
+    if rank == 0 and not args.no_calibration and not args.share_gpu:
+        calibration = {"before": calibrate(dev)}
+        for _ in range(2):          # the calibration kernels evicted the caches the warm-up filled
+            step()
+    barrier()
     # HIP events around the dominant kernel (roofline) and the radial-MLP kernel (mfma) only: an event pair costs a few
     # microseconds of queue time, the timed region should not pay it for every launch
     ops.enable_event_timing(True, only=("tp_scatter", "tp_lin2", "radial_hidden"))
@@ -441,8 +516,10 @@ def run_rank(args):
     ops.enable_event_timing(False)
     assert os.environ.get("MATTEN_BENCH_NO_CHECK") == "1" or torch.isfinite(out).all()  # the env is for ablation builds only
 
+    if calibration is not None:
+        calibration["after"] = calibrate(dev)
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if via_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -465,7 +542,9 @@ def run_rank(args):
         "dtype": "f32",
         "data": "synthetic",
         "crystals_per_sec": crystals_per_s,
-        "rccl_ranks": dist.get_world_size() if distributed else 0,   # 0: no process group (plain single-GPU run)
+        "rccl_ranks": dist.get_world_size() if (distributed and not via_host) else 0,   # 0: no RCCL process group
+        "backend": ("gloo (REHEARSAL: host-side gather" + (", all ranks on cuda:0" if args.share_gpu else "") + "; not a "
+                    "measurement)") if via_host else ("nccl (RCCL)" if distributed else None),
         "config": {
             "workload": "configs[2]: synthetic fcc-64 crystals (64 atoms, cutoff 5 A, 1152 edges each), "
                         "paper hparams lmax=4, eval forward backbone+out_layer, one batch per step per GPU",
@@ -473,7 +552,8 @@ def run_rank(args):
             "nodes_per_gpu": n_nodes,
             "edges_per_gpu": n_edges,
             "conv_layers": n_layers,
-            "sharding": f"batch-index x{world}, one all_gather of [B,21] per step" if distributed else "single GPU",
+            "sharding": f"batch-index x{world}: rank r owns crystals [r*{B}, (r+1)*{B}) of one {world * B}-crystal set, one "
+                        f"all_gather of [B,21] per step" if distributed else "single GPU",
             "input_checks": "species / edge_index range flags computed every step, read back one step late (pinned "
                             "memory + event), all verified inside the timed region (model.set_input_checks('deferred'))",
         },
@@ -565,6 +645,45 @@ def run_rank(args):
                                        "the whole layer's contract bytes over both",
             }
         result["kernel_ms_per_launch"] = per_kernel
+        if calibration is not None:
+            result["calibration"] = dict(calibration, what=(
+                "fixed kernels (csrc/calib.hip) timed with HIP events right before and right after the timed region: "
+                "VALU issue rate + effective shader clock, HBM copy rate.  Compare ms_per_step / kernel_ms_per_launch "
+                "of two BENCH lines only after dividing by these (a box or DVFS state that runs the VALU loop x % slower "
+                "runs the VALU-bound tp_fused kernel about x % slower)"))
+        # ---- what binds tp_fused_kernel physically: fp32 VALU issue (the contract figure above charges bytes the kernel
+        # never moves).  Instruction counts per launch from the committed PMC run, issue rate from THIS run's calibration.
+        if dom and dom_name == "tp_fused_kernel":
+            from matten_amd.o3 import wigner_3j
+
+            nnz = lambda l1, l2, l3: int((np.abs(wigner_3j(l1, l2, l3)) > 1e-9).sum())
+            cg_flops = [2.0 * sum(pt.mul * nnz(pt.l1, pt.l2, pt.l3) for pt in m.tp.plan.paths) * n_edges for m in convs]
+            cg_mean = sum(cg_flops) / len(cg_flops)
+            vp = _valu_profile()
+            n_simd = 256 * 4
+            ns_ideal = 2.0 / 2.4                       # 2 cycles per wave64 fp32 instruction at 2.4 GHz (guide)
+            ns_meas = calibration["before"]["valu"]["ns_per_wave_inst_per_simd"] if calibration else None
+            valu = {
+                "algorithmic_cg_flops_per_launch": cg_mean,
+                "flop_count": "nnz-sparse Clebsch-Gordan contraction, 2 x mul x nnz(l1,l2,l3) per path and edge (SURVEY "
+                              "Appendix B 'nnz' column: 800 / 15060 / 25948 / 26972 per edge for the full layers), layers "
+                              "as launched; the radial MLP and the x*w products are not counted",
+                "fp32_vector_peak_TFLOPs": MFMA_F32_PEAK / 1e12,
+                "achieved_TFLOPs": cg_mean / (avg_ms * 1e-3) / 1e12,
+                "frac_of_fp32_vector_peak": cg_mean / (avg_ms * 1e-3) / MFMA_F32_PEAK,
+            }
+            if vp is not None:
+                wi = float(vp["kernels"]["tp_fused_kernel"]["SQ_INSTS_VALU_mean_launch"])
+                valu.update({
+                    "valu_wave_insts_per_launch": wi,
+                    "insts_source": f"profiles/tp_fused_valu.json (tag {vp.get('tag', '?')}, commit {vp.get('commit', '?')}): "
+                                    "separate rocprofv3 --pmc passes of this command, not this run",
+                    "issue_frac_at_2_cycles_2p4GHz": wi / n_simd * ns_ideal * 1e-9 / (avg_ms * 1e-3),
+                    "issue_frac_at_calibrated_rate": None if ns_meas is None else wi / n_simd * ns_meas * 1e-9 / (avg_ms * 1e-3),
+                    "other_insts_per_launch": {k: v for k, v in vp["kernels"]["tp_fused_kernel"].items()
+                                               if k.endswith("_mean_launch") and k != "SQ_INSTS_VALU_mean_launch"},
+                })
+            result["roofline"]["valu"] = valu
         # ---- matrix-core use of the radial MLP (the only GEMM of the path): hidden layers nb -> 32 -> 32 in
         # radial_hidden_kernel (fp32 MFMA), last layer 32 -> W inside the tensor-product kernels (three fp16-split products) ----
         rh_key = next((k for k in ("radial_hidden_multi", "radial_hidden") if k in per_kernel), None)

@@ -420,6 +420,17 @@ int matten_tp_backward(const float* x, int64_t d_in, const void* w_edge, int64_t
 int matten_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* step,
                      float lr, float beta1, float beta2, float eps, float weight_decay, matten_stream_t stream);
 
+/* Calibration work for the benchmark harness (bench.py "calibration"; nothing of the reference corresponds -- there the
+ * host's wall clock is the only timer): fixed, model-independent kernels timed next to the benchmark so that lines taken
+ * on different machines / DVFS states can be compared.
+ *   matten_calib_valu: `iters` x 128 dependent-chain fp32 FMAs per lane at 8 waves per SIMD on every CU
+ *     (matten_calib_valu_insts_per_simd(iters) wave64 instructions per SIMD); clocks[0] = shader-clock ticks (s_memtime),
+ *     clocks[1] = 100 MHz reference ticks (s_memrealtime) the first wave spent in the loop.  out: one float, never written.
+ *   matten_calib_copy: dst[0..n) = src[0..n), 16 bytes per lane (n a multiple of 4, pointers 16-byte aligned). */
+int64_t matten_calib_valu_insts_per_simd(int64_t iters);
+int matten_calib_valu(int64_t iters, float* out, uint64_t* clocks, matten_stream_t stream);
+int matten_calib_copy(const float* src, float* dst, int64_t n_floats, matten_stream_t stream);
+
 /* the same adjoint with the literal-coefficient coupling code of the forward kernels (cg_gen.h): a thread owns (edge,
  * channel of one input block) and walks the block's paths; one atomic per (edge, channel, component) into dx.
  *   blocks[n_blocks,4] int32 {x_off, mul, l1, first path | n_paths << 16}; paths[n_paths,4] {l1*25+l2*5+l3, w_off, out_off, 0};

@@ -15,6 +15,8 @@
 // vmcnt counts stay exact) are in flight while block j is multiplied: 4-8 KB per wave, 24 waves per CU.
 // Results leave through a wave-private LDS stage, one 128-byte line per row and table row (see the kernel).
 // Bound: HBM (each 17 KB row is read once; ~1100 matrix instructions per 16 rows, a quarter of the stream time).
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -377,14 +379,19 @@ static int agg_linear_launch(const float* agg, int64_t ld, const int32_t* order,
     const size_t lds = matten_agg_linear_lds_bytes(w_stride, n_io, n_blocks);
     if (lds > AL_MAX_LDS) return MATTEN_EINVAL;
     if (lds > 64 * 1024) {   // gfx950: 160 KB of LDS per CU, a workgroup may take more than the default 64 KB on request
-        static bool raised = false;
-        if (!raised) {
+        // the attribute is per DEVICE: one bit per device ordinal, set after the call succeeded (two threads racing here
+        // both make the idempotent call)
+        static std::atomic<uint64_t> raised{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0) return MATTEN_ELAUNCH;
+        const uint64_t bit = dev < 64 ? (uint64_t)1 << dev : 0;
+        if (!bit || !(raised.load(std::memory_order_acquire) & bit)) {
             if (hipFuncSetAttribute((const void*)agg_linear_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)AL_MAX_LDS) != hipSuccess ||
                 hipFuncSetAttribute((const void*)agg_linear_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)AL_MAX_LDS) != hipSuccess)
                 return MATTEN_ELAUNCH;
-            raised = true;
+            raised.fetch_or(bit, std::memory_order_release);
         }
     }
     // species-major workgroups of AL_WAVES x 16 rows: at most one partly filled workgroup per species

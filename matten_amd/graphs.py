@@ -22,6 +22,8 @@ from typing import Callable, Dict
 
 import torch
 
+from .nn._tables import bump_weights_epoch
+
 
 # rocPRIM's radix sort switches algorithm above 2^20 keys and that path does not survive a capture on this ROCm (memory
 # aperture violation at replay; eager is fine -- most likely its hipMemsetAsync nodes: a memset captured by
@@ -121,6 +123,7 @@ class GraphedTrainStep:
         if target.data_ptr() != self._target.data_ptr():
             self._target.copy_(target, non_blocking=True)
         self.graph.replay()
+        bump_weights_epoch()   # the replayed optimiser step (and BatchNorm's running statistics) moved no _version counter
         if validate:
             _raise_for_flags(self._embeds, self._static)
         return self._loss

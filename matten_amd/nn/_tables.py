@@ -22,8 +22,24 @@ class DeviceTables:
         return t
 
 
+# Writes that torch's version counters cannot see: FlatAdam updates every parameter through the raw pointer of its flat
+# buffer, a hipGraph replay re-runs a captured optimiser step, matten_bn_train_fwd updates the running statistics in
+# place.  Each of them bumps this process-wide epoch, which is part of every cache key below, so an eval forward after a
+# training step never reuses packs derived from the previous weights.
+_WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch() -> None:
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def weights_epoch() -> int:
+    return _WEIGHTS_EPOCH[0]
+
+
 class DerivedWeight:
-    """Caches f(*params) until any parameter changes (optimizer step, load_state_dict, .to())."""
+    """Caches f(*params) until any parameter changes (optimizer step, load_state_dict, .to(), or a raw in-place write
+    announced through ``bump_weights_epoch``)."""
 
     def __init__(self, fn: Callable[..., torch.Tensor]):
         self._fn = fn
@@ -31,7 +47,7 @@ class DerivedWeight:
         self._val = None
 
     def get(self, *params: torch.Tensor):
-        key = tuple((p.data_ptr(), p._version, p.device, p.dtype) for p in params)
+        key = (_WEIGHTS_EPOCH[0],) + tuple((p.data_ptr(), p._version, p.device, p.dtype) for p in params)
         if key != self._key:
             with torch.no_grad():
                 self._val = self._fn(*params)
@@ -59,7 +75,7 @@ class WeightSlice:
         return w.index_select(self._dim, self._idx.get("idx", w.device))
 
     def get(self, w: torch.Tensor) -> torch.Tensor:
-        key = (w.data_ptr(), w._version, w.device, w.dtype)
+        key = (_WEIGHTS_EPOCH[0], w.data_ptr(), w._version, w.device, w.dtype)
         if key != self._key:
             with torch.no_grad():
                 new = w.detach().index_select(self._dim, self._idx.get("idx", w.device))

@@ -273,6 +273,7 @@ class UVUTensorProduct(torch.nn.Module):
         )
 
         self._a_split = DerivedWeight(self._split_last_layer)
+        self._a_split_c = None
 
     def _split_last_layer(self, w0: Tensor, w1: Tensor, w2: Tensor):
         """the last radial layer as the fp16 hi/lo MFMA fragments of matten_tp_fused, with 1 / (entry scale x hidden
@@ -285,6 +286,10 @@ class UVUTensorProduct(torch.nn.Module):
         """(fragments, a_scale_inv) for matten_tp_fused / matten_tp_lin2, consistent with weight_nn.hidden()"""
         mlp = self.weight_nn
         mlp.h_scale(r_start, r_end)   # fixes the cutoff range the bound is taken for
+        c = float(r_end - r_start)
+        if c != self._a_split_c:     # the folded 1 / h_scale belongs to ONE cutoff range: a new range, new fragments' factor
+            self._a_split_c = c
+            self._a_split._key = None
         return self._a_split.get(mlp.layer0.weight, mlp.layer1.weight, mlp.layer2.weight)
 
     @property

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .nn._tables import bump_weights_epoch
 
 
 # ---- optional HIP-event timing of individual launches (used by bench.py for the roofline line) ----
@@ -594,11 +595,14 @@ _SL_ROWS_LDS_BYTES = 52 * 1024  # three workgroups of matten_species_linear_rows
 
 
 def species_linear(x, species_order, wp, w_stride: int, item_tables, d_out: int, add=None,
-                   fully_covered: bool = True) -> torch.Tensor:
+                   fully_covered: bool = True, variant: Optional[str] = None) -> torch.Tensor:
     """species_order: None (plain linear) or (order[N] i32, seg[S+1] i32) = nodes sorted by species.
-    item_tables: list of int32 [n_items,8] tensors (passes).  out = add + sum_passes."""
+    item_tables: list of int32 [n_items,8] tensors (passes).  out = add + sum_passes.
+    variant: None = choose (row-resident kernel when rows + weights fit LDS), "rows" / "stream" force one (self-check)."""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
+    from . import selfcheck
+    selfcheck.check_species_linear(x.device)   # first call per device: both inline-asm MFMA kernels on exact integer cases
     wp = _need(wp, torch.float32, "packed weights")
     n_rows, d_in = x.shape
     order, seg = species_order if species_order is not None else (None, None)
@@ -611,8 +615,10 @@ def species_linear(x, species_order, wp, w_stride: int, item_tables, d_out: int,
     else:  # irreps without an input path stay zero (e3nn output_mask semantics)
         out = cur_add.clone() if cur_add is not None else torch.zeros(n_rows, d_out, dtype=torch.float32, device=x.device)
     # short rows (node features: lin1 / self-connection, first-layer lin2, read-out): rows and weights resident in LDS
-    rows_variant = (len(item_tables) == 1 and 4 * (16 * (d_in | 1) + w_stride + 8 * item_tables[0].shape[0] + 4) <= _SL_ROWS_LDS_BYTES
-                    and os.environ.get("MATTEN_SL_ROWS", "1") != "0")
+    rows_fits = len(item_tables) == 1 and 4 * (16 * (d_in | 1) + w_stride + 8 * item_tables[0].shape[0] + 4) <= _SL_ROWS_LDS_BYTES
+    rows_variant = rows_fits and os.environ.get("MATTEN_SL_ROWS", "1") != "0"
+    if variant is not None:
+        rows_variant = rows_fits and variant == "rows"
     for items in item_tables:
         fn = lib.matten_species_linear_rows if rows_variant else lib.matten_species_linear
         _lib.check(
@@ -791,6 +797,8 @@ def bn_train_fwd(x, col2chan, chan, weight, bias, eps: float, running_mean=None,
     _lib.check(lib.matten_bn_train_fwd(_ptr(x), x.shape[1], x.shape[0], _ptr(col2chan), _ptr(chan), C, _ptr(weight),
                                        _ptr(bias), eps, _ptr(mean), _ptr(nu), _ptr(y), _ptr(running_mean),
                                        _ptr(running_var), float(momentum), _stream()), "matten_bn_train_fwd")
+    if running_var is not None:
+        bump_weights_epoch()   # the running statistics were updated through raw pointers (caches of the folded BatchNorm)
     return y, mean, nu
 
 

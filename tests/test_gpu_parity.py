@@ -1230,3 +1230,53 @@ def test_non_power_of_two_multiplicities_keep_the_mul_ir_row(monkeypatch):
     got, want = _run_pair(ref, model, graphs)
     assert torch.isfinite(got).all()
     close_blocks(got, want, what="odd multiplicities at the streaming batch size", want64=_want64(ref, graphs))
+
+
+def test_species_linear_selfcheck_runs_and_detects_a_wrong_result(monkeypatch):
+    """matten_amd/selfcheck.py: the first species-linear call on a device runs both inline-asm MFMA kernels on
+    integer-valued cases whose fp32 result is exact and compares bit for bit with an int64 evaluation on the host; a
+    library whose kernels miscompute (the stale-accumulator miscompile of a build without
+    -mllvm -simplifycfg-sink-common=false, csrc/Makefile) must be refused, not used."""
+    from matten_amd import _lib, selfcheck
+
+    selfcheck._done.clear()
+    selfcheck.check_species_linear(DEV)            # the real kernels: exact
+    assert selfcheck._done[0] is True
+    # every case of both variants really went through the kernels and matched
+    gen = torch.Generator().manual_seed(1)
+    from matten_amd import ops, plan as mplan
+
+    for variant in ("rows", "stream"):
+        got, want = selfcheck._case(ops, mplan, "8x0e", "33x0e", 2, 37, DEV, gen, variant)
+        assert torch.equal(got.cpu(), want.float())
+    real_case = selfcheck._case
+
+    def broken(*a, **k):                           # one stale accumulator element in one case
+        got, want = real_case(*a, **k)
+        if a[2] == "8x0e" and a[3] == "78x0e":
+            got = got.clone()
+            got[5, 70] += 1.0
+        return got, want
+
+    monkeypatch.setattr(selfcheck, "_case", broken)
+    selfcheck._done.clear()
+    with pytest.raises(_lib.MattenHipError, match="self-check FAILED"):
+        selfcheck.check_species_linear(DEV)
+    assert not selfcheck._done.get(0)
+    monkeypatch.setattr(selfcheck, "_case", real_case)
+    selfcheck.check_species_linear(DEV)
+
+
+def test_fuzzed_models_on_poisoned_buffers_with_the_streaming_lin2_forced():
+    """tests/fuzz_models.py (random irreps / multiplicities / depth / normalisation on random small crystals, product vs
+    oracle) with every torch.empty buffer starting as NaN (NAN_EMPTY=1) and the component-major neighbour-sum row + the
+    streaming lin2 forced for every batch size (MATTEN_AGG_KM_MIN_ROWS=0): the mode that found the alignment holes of
+    non-power-of-two multiplicities (plan.plan_agg_linear); part of the regular GPU suite since round 4."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, NAN_EMPTY="1", MATTEN_AGG_KM_MIN_ROWS="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_models.py"), "24", "4"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

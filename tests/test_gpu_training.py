@@ -364,6 +364,100 @@ def test_flat_adam_follows_torch_adam(golden_dir):
     assert l < l0 and float(o3.step_count) == 6.0
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_eval_after_flat_adam_steps_uses_the_updated_weights(golden_dir, graphed):
+    """The Trainer.fit loop: eval (packs the weights: species-linear tables, radial MLP fragments, folded BatchNorm) ->
+    optimiser steps through raw pointers (FlatAdam, eager or replayed from a hipGraph; BatchNorm running statistics
+    updated in place by the training kernels) -> eval.  No parameter's ``_version`` moves in between, so the caches hang
+    on the process-wide weights epoch (nn/_tables.py): the second eval must match the oracle evaluated with the model's
+    CURRENT state, and differ from the first."""
+    from matten_amd.data.graph import collate
+    from matten_amd.graphs import GraphedTrainStep
+    from matten_amd.optim import FlatAdam
+
+    graphs, ds = _graphs(golden_dir, 8)
+    ref, model = build_pair(LMAX2, ds, randomize_bn=True)
+    batch, target = collate(graphs, device=DEV), torch.randn(8, 21, generator=torch.Generator().manual_seed(9)).to(DEV)
+
+    def loss_fn(preds, t):
+        return torch.nn.functional.mse_loss(preds["elastic_tensor_full"], t)
+
+    with torch.no_grad():
+        before = model(dict(batch))[0]["elastic_tensor_full"].clone()
+    _close(before, ref.decode(collate(graphs))["elastic_tensor_full"], 2e-5, "eval before training")
+    model.train()
+    opt = FlatAdam(model.parameters(), lr=1e-2, weight_decay=1e-5)
+    if graphed:
+        step = GraphedTrainStep(model, opt, loss_fn, batch, target, warmup=1)
+        for _ in range(3):
+            step.step(batch, target)
+    else:
+        for _ in range(3):
+            loss = loss_fn(model(dict(batch))[0], target)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+    model.eval()
+    with torch.no_grad():
+        after = model(dict(batch))[0]["elastic_tensor_full"].clone()
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref.load_state_dict(state, strict=False)
+    with torch.no_grad():
+        want = ref.eval().decode(collate(graphs))["elastic_tensor_full"]
+    assert (after - before).abs().max().item() > 1e-3 * before.abs().max().item(), "the training steps changed nothing"
+    _close(after, want, 2e-5, "eval after FlatAdam steps (stale weight packs?)")
+
+
+def test_flat_adam_state_dict_round_trip():
+    """load_state_dict restores the LIVE flat moments and step count (torch's loader would park copies that step()
+    never reads): resume from this class's own state_dict and from torch.optim.Adam's, then follow torch.optim.Adam."""
+    from matten_amd import _lib
+    from matten_amd.optim import FlatAdam
+
+    g = torch.Generator().manual_seed(4)
+    shapes = [(5,), (4, 3), (1,), (17, 2)]
+
+    def fresh(vals):
+        return [torch.nn.Parameter(v.clone().to(DEV)) for v in vals]
+
+    init = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(6)]
+
+    def run(opt, ps, its):
+        for it in its:
+            opt.zero_grad()
+            for p, gr in zip(ps, grads[it]):
+                (p * gr.to(DEV)).sum().backward()
+            opt.step()
+
+    ps_t = fresh(init)
+    opt_t = torch.optim.Adam(ps_t, lr=1e-2, weight_decay=1e-5)
+    run(opt_t, ps_t, range(3))
+    mid_params = [p.detach().clone() for p in ps_t]
+    sd_torch = copy.deepcopy(opt_t.state_dict())
+    run(opt_t, ps_t, range(3, 6))
+
+    ps_a = fresh(init)
+    opt_a = FlatAdam(ps_a, lr=1e-2, weight_decay=1e-5)
+    run(opt_a, ps_a, range(3))
+    sd_flat = copy.deepcopy(opt_a.state_dict())
+    for sd, what in ((sd_flat, "own state_dict"), (sd_torch, "torch.optim.Adam state_dict")):
+        ps = fresh(mid_params)
+        opt = FlatAdam(ps, lr=1e-3)                       # hyper-parameters come back from the saved group too
+        opt.load_state_dict(sd)
+        assert float(opt.step_count) == 3.0 and opt.param_groups[0]["lr"] == 1e-2
+        assert opt.state[ps[0]]["exp_avg"].data_ptr() == opt.exp_avg.data_ptr()
+        run(opt, ps, range(3, 6))
+        for p, r in zip(ps, ps_t):
+            _close(p, r, 2e-6, f"parameter after resuming from {what}")
+    ps = fresh(init)
+    opt = FlatAdam(ps, lr=1e-2)
+    ps[1].data = ps[1].data.clone()                        # what model.to() / .double() after construction does
+    ps[1].grad = torch.zeros_like(ps[1])
+    with pytest.raises(_lib.MattenHipError, match="flat buffer"):
+        opt.step()
+
+
 @pytest.mark.parametrize("irreps_in,irreps_out,S,N", [
     ("32x0e+16x1o+4x2e", "32x0e+16x1o+4x2e", 3, 7),          # a handful of rows: one slice, mostly idle row quads
     ("32x0e+16x1o+4x2e+2x3o+2x4e", "16x0e+8x1o+4x2e+2x3o+1x4e", 4, 301),

@@ -607,6 +607,55 @@ def test_bench_launches_its_ranks_as_a_child_process(monkeypatch):
     assert ran["args"].gpus == 8 and not seen
 
 
+def test_bench_shards_are_contiguous_slices_of_one_set():
+    """SURVEY.md 8d config 5 / DESIGN.md section 6: with N > 1 ranks, rank r owns crystals [r B, (r + 1) B) of ONE set of
+    N B crystals (seed FCC_SEED + 1), not N differently seeded sets; one rank runs the config-3 set (seed FCC_SEED).
+    Checked on the structures (the graphs are a deterministic function of them) and on bench.py's call."""
+    import inspect
+
+    import bench
+    from matten_amd.data import synthetic as S
+
+    whole = S.fcc64_structures(12, S.FCC_SEED + 1)
+    for r in range(3):
+        part = S.fcc64_structures(4, S.FCC_SEED + 1, start=4 * r)
+        for a, b in zip(whole[4 * r: 4 * r + 4], part):
+            assert all(np.array_equal(a[k], b[k]) for k in ("lattice", "cart_coords", "atomic_numbers"))
+    g_whole = S.fcc64_graphs(3, S.FCC_SEED + 1)
+    g_shard = S.fcc64_shard(1, 3, 1)
+    assert len(g_shard) == 1 and all(torch.equal(g_whole[1][k], g_shard[0][k]) for k in ("pos", "edge_index", "atomic_numbers"))
+    one = S.fcc64_shard(0, 1, 2)
+    ref = S.fcc64_graphs(2)
+    assert all(torch.equal(a["pos"], b["pos"]) for a, b in zip(one, ref))
+    src = inspect.getsource(bench.run_rank)
+    assert "fcc64_shard(rank, world, B)" in src and "FCC_SEED + rank" not in src
+
+
+def test_bench_rehearsal_flags(monkeypatch):
+    """--backend gloo --share-gpu: the N > 1 branch of bench.py rehearsed on one device (RCCL refuses two ranks per GPU);
+    the flags reach the ranks through the child launch, and --share-gpu without gloo is refused before any GPU call."""
+    import importlib
+    import subprocess
+    import sys
+
+    import bench
+
+    importlib.reload(bench)
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.setdefault("cmd", cmd) and 0)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MATTEN_FORCE_DIST"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--backend", "gloo", "--share-gpu", "--no-extras"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert seen["cmd"][-6:] == ["--gpus", "2", "--backend", "gloo", "--share-gpu", "--no-extras"]
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--share-gpu"])
+    with pytest.raises(SystemExit, match="gloo"):
+        bench.main()
+
+
 def test_reference_training_script_call_sequence_under_the_matten_alias(golden_dir):
     """scripts/train_materials_tensor.py:11-14,34-52 of the reference, line by line, with `import matten` resolving to
     this package: data module -> get_to_model_info -> ScalarTensorModel(tasks=TensorRegressionTask(...), ...) ->

@@ -327,6 +327,46 @@ def test_real_spherical_harmonics_match_sympy():
                 assert np.allclose(got[:, l * l + l - m], c * val.imag, atol=1e-12), (l, -m)
 
 
+def test_real_w3j_matches_gaunt_integrals():
+    """Ties the one e3nn-specific step that sympy has not pinned -- the real-basis change on top of the su(2)
+    coefficients -- to the harmonics that ARE pinned: for every triple (l1, l2, l3), l <= 4, with l1 + l2 + l3 even, the
+    oracle's real ``wigner_3j`` must be proportional, entry for entry, to the Gaunt integral of its own real harmonics
+        G_ijk = (1 / 4 pi) Int Y_{l1,i} Y_{l2,j} Y_{l3,k} dOmega
+    with ONE positive factor per triple (the invariant 3-tensor of three irreps is unique up to scale; the sign is the
+    convention SURVEY appendix A.2 records: c > 0 for every even-sum triple).  Product quadrature, exact for the
+    polynomial degree <= 12 involved: 16-point Gauss-Legendre in cos(theta) x 32 uniform azimuths, fp64.  Odd-sum triples
+    have a vanishing Gaunt integral (parity); they stay on the rotation-equivariance tests."""
+    nodes, weights = np.polynomial.legendre.leggauss(16)
+    nphi = 32
+    phi = 2 * np.pi * np.arange(nphi) / nphi
+    ct, ph = np.meshgrid(nodes, phi, indexing="ij")
+    st = np.sqrt(1 - ct**2)
+    # any orthonormal frame does: the integral is over the whole sphere
+    pts = torch.as_tensor(np.stack([st * np.cos(ph), st * np.sin(ph), ct], -1).reshape(-1, 3))
+    w = torch.as_tensor((weights[:, None] * np.full((1, nphi), 1.0 / nphi) / 2.0).reshape(-1))   # sums to 1 = dOmega / 4 pi
+    Y = o3.spherical_harmonics([0, 1, 2, 3, 4], pts, True, "norm")
+    assert abs(w.sum().item() - 1.0) < 1e-14
+    # the quadrature reproduces the harmonics' orthogonality: (1/4pi) Int Y_a Y_b = delta_ab / (2l+1) in 'norm'
+    gram = torch.einsum("p,pa,pb->ab", w, Y, Y)
+    want = torch.diag(torch.cat([torch.full((2 * l + 1,), 1.0 / (2 * l + 1), dtype=torch.float64) for l in range(5)]))
+    assert torch.allclose(gram, want, atol=1e-13)
+    n = 0
+    for l1 in range(5):
+        for l2 in range(5):
+            for l3 in range(abs(l1 - l2), min(4, l1 + l2) + 1):
+                G = torch.einsum("p,pi,pj,pk->ijk", w, Y[:, l1 * l1:(l1 + 1) ** 2], Y[:, l2 * l2:(l2 + 1) ** 2],
+                                 Y[:, l3 * l3:(l3 + 1) ** 2])
+                if (l1 + l2 + l3) % 2:
+                    assert G.abs().max().item() < 1e-13, (l1, l2, l3)
+                    continue
+                C = o3.wigner_3j(l1, l2, l3, dtype=torch.float64)
+                c = (C * G).sum() / (G * G).sum()
+                assert c.item() > 0, (l1, l2, l3, c.item())
+                assert torch.allclose(C, c * G, atol=1e-12), (l1, l2, l3, (C - c * G).abs().max().item())
+                n += 1
+    assert n == 42   # even-sum triples with l <= 4 (of 65)
+
+
 def test_oracle_matches_e3nn_golden(golden_dir):
     """tests/golden/e3nn_golden.npz is written by tests/golden/make_golden_e3nn.py where REAL e3nn 0.5.1 and the
     reference run (neither exists in the build container nor on the GPU box).  When the file is there, every e3nn-held

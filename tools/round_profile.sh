@@ -10,5 +10,6 @@ f=$(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$f" $R/gpurun_out/${TAG}_kernel_stats.csv
 python3 $R/bench.py 2>/dev/null | tail -1 > $R/gpurun_out/${TAG}_bench.json
 bash $R/tools/collect_traffic.sh $TAG
+bash $R/tools/collect_valu.sh $TAG
 head -8 $R/gpurun_out/${TAG}_kernel_stats.csv
 cat $R/gpurun_out/${TAG}_bench.json | cut -c1-600
