@@ -138,7 +138,8 @@ def calibrate(dev, copy_floats: int = 1 << 28, valu_iters: int = 4096, reps: int
     return {
         "valu": {"wave_insts_per_simd": insts, "ms": valu_ms, "ns_per_wave_inst_per_simd": 1e6 * valu_ms / insts,
                  "sclk_mhz_under_valu_load": 100.0 * ticks / ref100 if ref100 else None,
-                 "cycles_per_wave_inst": (ticks / (insts / 8.0)) / 8.0 if insts else None},
+                 # the first wave's own view: ticks it spent / instructions it issued, over the 8 waves that share its SIMD
+                 "cycles_per_wave_inst_per_simd": ticks / float(insts) if insts else None},
         "copy": {"bytes_moved": 8 * copy_floats, "ms": copy_ms, "GBps": 8 * copy_floats / (copy_ms * 1e-3) / 1e9},
     }
 
@@ -505,7 +506,7 @@ def run_rank(args):
     barrier()
     # HIP events around the dominant kernel (roofline) and the radial-MLP kernel (mfma) only: an event pair costs a few
     # microseconds of queue time, the timed region should not pay it for every launch
-    ops.enable_event_timing(True, only=("tp_scatter", "tp_lin2", "radial_hidden"))
+    ops.enable_event_timing(True, only=("tp_scatter", "conv_tile", "agg_linear", "radial_hidden"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -577,41 +578,29 @@ def run_rank(args):
 
         layers = []
         for m in convs:
-            p, fp = m.tp.plan, m.fused_plan
-            ent = np.asarray(p.group_entries).reshape(-1, 32)
-            cols = lambda ids: float(sum(int(ent[e][2]) * len(p.group_entry_paths[e]) for e in ids))
-
-            def blocks(ids):  # floats of the input blocks a set of entries reads
-                seen = {}
-                for e in ids:
-                    pth = p.paths[next(iter(p.group_entry_paths[e].values()))]
-                    seen[pth.i_in1] = pth.mul * (2 * pth.l1 + 1)
-                return float(sum(seen.values()))
-
-            if fp is not None:
-                lk = f"tp_lin2/d_out={fp.d_out}/d_in={p.d_in}"
-                hk = f"tp_scatter/d_mid={fp.d_rest}/d_in={p.d_in}"
-                rec = {"d_mid": p.d_mid, "weight_numel": p.weight_numel, "light_ms": per_kernel.get(lk),
-                       "heavy_ms": per_kernel.get(hk, 0.0) if fp.rest is not None else 0.0,
-                       "light_bytes": contract_bytes(p, cols(fp.light_ids), blocks(fp.light_ids), p.d_mid - fp.d_rest),
-                       "heavy_bytes": contract_bytes(p, cols(fp.heavy_ids), blocks(fp.heavy_ids), fp.d_rest)
-                       if fp.rest is not None else 0.0}
+            p = m.tp.plan
+            tiled = (m.tile_plan is not None and pconv.CONV_TILE != "0" and n_nodes >= pconv.CONV_TILE_MIN_ROWS
+                     and p.d_mid >= pconv.CONV_TILE_MIN_DMID)
+            if tiled:
+                k, kern = f"conv_tile/d_out={m.tile_plan.d_out}/d_in={p.d_in}", "conv_tile_kernel"
             else:
                 # the row stride of the neighbour sums names the launch: component-major rows are padded (plan_agg_linear)
                 k = f"tp_scatter/d_mid={m.agg_plan.ld if getattr(m, 'agg_plan', None) is not None else p.d_mid}/d_in={p.d_in}"
-                rec = {"d_mid": p.d_mid, "weight_numel": p.weight_numel, "light_ms": None, "heavy_ms": per_kernel.get(k),
-                       "light_bytes": 0.0, "heavy_bytes": contract_bytes(p, p.weight_numel, p.d_in, p.d_mid)}
-            rec["ms"] = (rec["light_ms"] or 0.0) + (rec["heavy_ms"] or 0.0)
-            rec["algorithmic_bytes"] = algorithmic_bytes_tp_kernel(p, deg) * n_edges
+                kern = "tp_fused_kernel"
+            rec = {"kernel": kern, "d_mid": p.d_mid, "weight_numel": p.weight_numel, "ms": per_kernel.get(k),
+                   "algorithmic_bytes": contract_bytes(p, p.weight_numel, p.d_in, p.d_mid)}
             rec["achieved_GBps"] = rec["algorithmic_bytes"] / (rec["ms"] * 1e-3) / 1e9 if rec["ms"] else None
             layers.append(rec)
-        light = [r for r in layers if r["light_ms"]]
         avg_ms = None
-        # dominant kernel, averaged over its launches of the timed region like rocprofv3 --stats does: tp_fused_kernel
-        # (default), or tp_lin2_kernel when the opt-in conv-fused variant is on (MATTEN_CONV_FUSED=1)
-        dom = [(r["light_ms"], r["light_bytes"]) for r in light] if light else \
-              [(r["heavy_ms"], r["heavy_bytes"]) for r in layers if r["heavy_ms"]]
-        dom_name = "tp_lin2_kernel" if light else "tp_fused_kernel"
+        # dominant kernel = the one with the most time per forward, averaged over ITS launches of the timed region like
+        # rocprofv3 --stats does: conv_tile_kernel (tensor product + neighbour sum + lin2 + Gate on 16-node tiles) for the
+        # layers that run it, tp_fused_kernel (tensor product + neighbour sum, agg to HBM) for the others
+        by_kernel = {}
+        for r in layers:
+            if r["ms"]:
+                by_kernel.setdefault(r["kernel"], []).append((r["ms"], r["algorithmic_bytes"]))
+        dom_name = max(by_kernel, key=lambda kn: sum(m for m, _ in by_kernel[kn])) if by_kernel else None
+        dom = by_kernel.get(dom_name, [])
         if dom:
             bytes_per_launch = sum(b for _, b in dom) / len(dom)
             avg_ms = sum(m for m, _ in dom) / len(dom)
@@ -619,8 +608,8 @@ def run_rank(args):
             traffic, traffic_source = _pmc_traffic(dom_name)
             result["roofline"] = {
                 "kernel": f"{dom_name} (last radial-MLP layer on MFMA + CG paths + neighbour sum"
-                          f"{' + lin2 of the l1<=1 input blocks' if light else ''}; mean over its {len(dom)} launches per "
-                          "forward, one per conv layer)",
+                          f"{' + lin2 + Gate per 16-node tile, agg never written' if dom_name == 'conv_tile_kernel' else ''}; "
+                          f"mean over its {len(dom)} launches per forward)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK / 1e9,
@@ -630,19 +619,16 @@ def run_rank(args):
                 # NOT measured in this run: PMC counters need their own rocprofv3 passes (separate FETCH_SIZE / WRITE_SIZE
                 # runs of this same command, tools/collect_traffic.sh); the summary they produced is committed and read here
                 "traffic_source": traffic_source,
-                # `achieved` / `frac` price the CONTRACT bytes of the launch (SURVEY 8d two-kernel architecture restricted
-                # to the input blocks this kernel takes: radial weights w[E, W] and agg[N, d_mid] that never exist here).
-                # What the memory system really moves:
+                # `achieved` / `frac` price the CONTRACT bytes of the tensor-product share of the launch (SURVEY 8d
+                # two-kernel architecture: ids, edge vector, radial weights w[E, W] read once, node rows over the degree --
+                # w and, in conv_tile_kernel, agg never exist here).  What the memory system really moves:
                 "measured_GBps": None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9,
                 "measured_frac": None if traffic is None else traffic / (avg_ms * 1e-3) / HBM_PEAK,
-                "physical_bound": "fp32 VALU issue at 3 waves/SIMD (DESIGN.md section 4); HBM is the bound of the "
-                                  "contract figure only",
+                "physical_bound": "fp32 VALU issue at 3 waves/SIMD (DESIGN.md section 4; `valu` below); HBM is the bound "
+                                  "of the contract figure only",
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms,
                 "per_layer": layers,
-                "edge_work_per_layer": "heavy_ms = tp_fused_kernel; light_ms = tp_lin2_kernel (only with MATTEN_CONV_FUSED=1, "
-                                       "then heavy_ms covers the l1>=2 blocks only); algorithmic_bytes / achieved_GBps = "
-                                       "the whole layer's contract bytes over both",
             }
         result["kernel_ms_per_launch"] = per_kernel
         if calibration is not None:
@@ -653,11 +639,12 @@ def run_rank(args):
                 "runs the VALU-bound tp_fused kernel about x % slower)"))
         # ---- what binds tp_fused_kernel physically: fp32 VALU issue (the contract figure above charges bytes the kernel
         # never moves).  Instruction counts per launch from the committed PMC run, issue rate from THIS run's calibration.
-        if dom and dom_name == "tp_fused_kernel":
+        if dom:
             from matten_amd.o3 import wigner_3j
 
             nnz = lambda l1, l2, l3: int((np.abs(wigner_3j(l1, l2, l3)) > 1e-9).sum())
-            cg_flops = [2.0 * sum(pt.mul * nnz(pt.l1, pt.l2, pt.l3) for pt in m.tp.plan.paths) * n_edges for m in convs]
+            cg_flops = [2.0 * sum(pt.mul * nnz(pt.l1, pt.l2, pt.l3) for pt in m.tp.plan.paths) * n_edges
+                        for m, r in zip(convs, layers) if r["kernel"] == dom_name and r["ms"]]
             cg_mean = sum(cg_flops) / len(cg_flops)
             vp = _valu_profile()
             n_simd = 256 * 4
@@ -672,15 +659,15 @@ def run_rank(args):
                 "achieved_TFLOPs": cg_mean / (avg_ms * 1e-3) / 1e12,
                 "frac_of_fp32_vector_peak": cg_mean / (avg_ms * 1e-3) / MFMA_F32_PEAK,
             }
-            if vp is not None:
-                wi = float(vp["kernels"]["tp_fused_kernel"]["SQ_INSTS_VALU_mean_launch"])
+            if vp is not None and dom_name in vp.get("kernels", {}):
+                wi = float(vp["kernels"][dom_name]["SQ_INSTS_VALU_mean_launch"])
                 valu.update({
                     "valu_wave_insts_per_launch": wi,
                     "insts_source": f"profiles/tp_fused_valu.json (tag {vp.get('tag', '?')}, commit {vp.get('commit', '?')}): "
                                     "separate rocprofv3 --pmc passes of this command, not this run",
                     "issue_frac_at_2_cycles_2p4GHz": wi / n_simd * ns_ideal * 1e-9 / (avg_ms * 1e-3),
                     "issue_frac_at_calibrated_rate": None if ns_meas is None else wi / n_simd * ns_meas * 1e-9 / (avg_ms * 1e-3),
-                    "other_insts_per_launch": {k: v for k, v in vp["kernels"]["tp_fused_kernel"].items()
+                    "other_insts_per_launch": {k: v for k, v in vp["kernels"][dom_name].items()
                                                if k.endswith("_mean_launch") and k != "SQ_INSTS_VALU_mean_launch"},
                 })
             result["roofline"]["valu"] = valu
@@ -694,7 +681,7 @@ def run_rank(args):
             hid_flops = 2.0 * (nb * 32 + 32 * 32) * n_edges * n_mlps
             hid_ms = per_kernel[rh_key]
             last_flops = [2.0 * 32 * r["weight_numel"] * n_edges for r in layers]
-            tp_ms = sum(r["ms"] for r in layers) / len(layers)
+            tp_ms = sum(r["ms"] or 0.0 for r in layers) / len(layers)
             result["mfma"] = {
                 "radial_hidden_kernel": {
                     "kernel": rh_key + ("_kernel (hidden layers of all %d conv layers' radial MLPs per launch)" % n_mlps
@@ -706,7 +693,7 @@ def run_rank(args):
                 "last_layer_in_tp_kernels": {
                     "algorithmic_flops_per_layer": sum(last_flops) / len(last_flops),
                     "issued_f16_flops_per_layer": 3.0 * sum(last_flops) / len(last_flops),
-                    "note": "evaluated as hi.hi + 2^-11 (hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16 inside tp_lin2_kernel / "
+                    "note": "evaluated as hi.hi + 2^-11 (hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16 inside conv_tile_kernel / "
                             "tp_fused_kernel; matrix-pipe busy fraction from PMC in DESIGN.md section 4",
                     "f16_TFLOPs_over_kernel_time": 3.0 * sum(last_flops) / len(last_flops) / (tp_ms * 1e-3) / 1e12,
                     "peak_f16_TFLOPs": MFMA_F16_PEAK / 1e12,

@@ -247,42 +247,57 @@ int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const flo
                     const float* num_neigh, const uint16_t* a_split, const float* a_scale_inv,
                     float* agg /*[N,d_mid]*/, matten_stream_t stream);
 
-/* ------------------------------------------------------------------------------------------
- * Conv-fused kernel: tensor product + neighbour sum + lin2 + self-connection of the light input blocks in one launch
- * (reference nn/conv.py:113-123:  scatter(tp(x[src], Y, w)) / sqrt(avg)  ->  lin2(., species) + sc).
- * A workgroup owns matten_tp_lin2_group_nodes() = 8 destination nodes and walks `light_entries` (group entries with
- * 8 lanes per node, l1 <= 1) four per ROUND; after a round the four waves' neighbour sums sit in LDS
- * ([wave][coupling][node, k][channel 8], matten_tp_lin2_t_wave_floats() floats per wave) and lin2 is applied there:
- *   rounds[n_rounds, 4]      : entry per wave, -1 = no entry (the wave only feeds the shared stage)
- *   light_entries[n, 32]     : group entries as matten_tp_fused; words 8..19 = accumulator offset of coupling c in
- *                              the wave's LDS region (present couplings packed)
- *   slot_index[n_rounds,4,2] : (first slot, count) of (round, wave)
- *   slots[n_slots, 8]        : {d3, n_pairs = mul_out * d3, out_off, pair_base, magic, first item, item count, 0}: a SLOT is
- *                              8 consecutive (v, k) pairs of the output irrep at out_off; the 8 lanes of a node take
- *                              the pairs pair_base .. pair_base+7 (v = (pair * magic) >> 16 = pair / d3)
- *   items[n_items, 4]        : {t_off, a_off, n_chunks <= 4, a_stride}: the channel chunks of one path that feeds the
- *                              slot's irrep: chunk c = the [node, k][channel 8] block at float offset
- *                              t_off + c * t_wave_floats of the LDS area (consecutive waves) times the [mul_out][8]
- *                              weight block at float offset a_off + c * a_stride of a species' row of atab
- *   atab[n_species, a_numel] : lin2 weights W[u, s, v] * fan_in^-1/2 in that layout (zero for channels past the entry)
- *   species[N] int32, add[N, add_ld] (self-connection) or NULL, out[N, d_out] = add + lin2(light blocks)
- * a_split / a_scale_inv as matten_tp_fused (required here), a_scale_inv indexed like light_entries.
- * Host tables: matten_amd/plan.py plan_conv_fused.  The remaining (heavy) entries go through matten_tp_fused into a
- * compact agg_rest and matten_species_linear(agg_rest, add = out).
- * ------------------------------------------------------------------------------------------ */
-int matten_tp_max_cols(void);   /* weight columns (mul * couplings) a group entry of matten_tp_fused / matten_tp_lin2 may have */
+int matten_tp_max_cols(void);   /* weight columns (mul * couplings) a group entry of matten_tp_fused / matten_conv_tile may have */
 int matten_tp_max_cols_l0(void);   /* the same for entries of scalar (l1 = 0) input blocks */
 int matten_tp_max_cols_l1(void);   /* ... and of vector (l1 = 1) input blocks */
-int matten_tp_lin2_group_nodes(void);
-int matten_tp_lin2_t_wave_floats(void);
-int matten_tp_lin2(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
-                   const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
-                   int64_t n_nodes, const int32_t* light_entries, int64_t n_entries, const int32_t* rounds,
-                   int64_t n_rounds, const int32_t* slot_index, const int32_t* slots, int64_t n_slots,
-                   const int32_t* items, int64_t n_items, const float* atab, int64_t a_numel, int64_t n_species,
-                   const int32_t* species, float avg_num_neighbors, const float* num_neigh, const uint16_t* a_split,
-                   const float* a_scale_inv, const float* add, int64_t add_ld, int64_t d_out, float* out,
-                   matten_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conv layer on 16-node single-species tiles: tensor product + neighbour sum + lin2 + self-connection (+ Gate + eval
+ * BatchNorm) in ONE launch; the neighbour sums agg[N, d_mid] never reach memory
+ * (reference nn/conv.py:113-123:  scatter(tp(x[src], Y, w)) / sqrt(avg)  ->  lin2(., species) + sc;  :209-213 Gate, norm).
+ *
+ * matten_species_tiles: cuts the batch into blocks of `block_nodes` consecutive nodes (a multiple of 16; whole crystals
+ *   are not required), groups every block's nodes by species and emits 16-node tiles of ONE species each:
+ *   tile_nodes[n_slots, 16] (node ids, -1 = padding), tile_species[n_slots] (-1 = unused slot), block b owning the
+ *   slots [b spb, (b + 1) spb), spb = matten_species_tiles_slots_per_block(block_nodes, n_species) = block_nodes/16 +
+ *   n_species, n_slots = ceil(N / block_nodes) spb.  species[N] int32 species indices (clamped to [0, n_species)).
+ *   The order of the nodes inside a species run is unspecified (a node's result does not depend on its tile mates).
+ * matten_conv_tile: one workgroup per tile walks `entries` (group entries as matten_tp_fused: words 0..7 used) in
+ *   rounds of four and applies lin2 on the matrix cores after each round (csrc/conv_tile.hip; host tables
+ *   matten_amd/plan_conv.py plan_conv_tile):
+ *   quads[n_quads, 8]     : {e0, e1, e2, e3 (entry per wave, -1 = the wave only feeds the shared stage), class lanes
+ *                            per node (log2), passes, node groups of the tile, base index into wave_units}
+ *   wave_units[.., 2]     : {first unit, count} of (quad, pass, wave) at base + 4 pass + wave
+ *   units[n_units, 8]     : {output column of (v = 16 mt, k = 0), d3, valid v <= 16, first column tile, column tiles <= 4,
+ *                            first piece, pieces, log2(nodes per wave of the round)}; column n of a tile = (node n mod
+ *                            npw of the round's group, component n / npw)
+ *   pieces[n_pieces, 4]   : {float offset of the piece's first register in the four waves' dump ([wave][28 registers]
+ *                            [68 floats]: register r of lane l at r 68 + l), float offset of its A fragment in a species'
+ *                            row of atab, lanes per node (log2) of its entry, 0}
+ *   atab[S, a_stride]     : lin2 weights W[u, s, v] fan_in^-1/2 as MFMA A fragments [lane (g, c)][KS]: u = entry channel
+ *                            g KS + t (KS = max(1, lanes per node / 4)), v = 16 mt + c; zero outside the piece's channels
+ *   add[N, add_ld] (self-connection) or NULL; cmeta == NULL: out[N, out_ld >= d_out] = add + lin2(agg).
+ *   cmeta[d_act, 4] (the table of matten_gate_bn: {source column, gate column or -1, act | gate act << 8, unused}),
+ *   act_cst, bn_scale / bn_shift [d_act] (eval BatchNorm folded per activated column) or NULL:
+ *   out[N, out_ld >= d_act] = BatchNorm(Gate(add + lin2(agg))).
+ *   a_split / a_scale_inv as matten_tp_fused (required), indexed like `entries`; lds_floats_per_wave = max over entries
+ *   of 16 (16 ceil(mul NC / 16) + 4).
+ * ------------------------------------------------------------------------------------------ */
+int matten_conv_tile_nodes(void);        /* 16 */
+int matten_conv_tile_dump_regs(void);    /* registers per lane and pass of the LDS dump (plan_conv.DUMP_REGS) */
+int matten_conv_tile_dump_stride(void);  /* floats between two registers of a wave's dump (plan_conv.DUMP_RS) */
+int64_t matten_species_tiles_slots_per_block(int64_t block_nodes, int64_t n_species);
+int matten_species_tiles(const int32_t* species, int64_t n_nodes, int64_t n_species, int64_t block_nodes,
+                         int32_t* tile_nodes, int32_t* tile_species, matten_stream_t stream);
+int matten_conv_tile(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
+                     const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
+                     int64_t n_nodes, const int32_t* entries, int64_t n_entries, int64_t lds_floats_per_wave,
+                     const uint16_t* a_split, const float* a_scale_inv, float avg_num_neighbors, const float* num_neigh,
+                     const int32_t* tile_nodes, const int32_t* tile_species, int64_t n_slots, int64_t slots_per_block,
+                     const int32_t* quads, int64_t n_quads, const int32_t* wave_units, const int32_t* units,
+                     const int32_t* pieces, const float* atab, int64_t a_stride, const float* add, int64_t add_ld,
+                     int64_t d_out, const int32_t* cmeta, const float* act_cst, const float* bn_scale,
+                     const float* bn_shift, int64_t d_act, float* out, int64_t out_ld, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * FullyConnectedTensorProduct(x, one_hot(species)) == species-indexed per-irrep linear

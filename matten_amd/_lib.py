@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -47,10 +47,14 @@ SIGNATURES = {
     "matten_tp_max_cols": (c_int, []),
     "matten_tp_max_cols_l0": (c_int, []),
     "matten_tp_max_cols_l1": (c_int, []),
-    "matten_tp_lin2_group_nodes": (c_int, []),
-    "matten_tp_lin2_t_wave_floats": (c_int, []),
-    "matten_tp_lin2": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, P, P, c_int64,
-                               P, c_int64, P, c_int64, c_int64, P, c_float, P, P, P, P, c_int64, c_int64, P, P]),
+    "matten_conv_tile_nodes": (c_int, []),
+    "matten_conv_tile_dump_regs": (c_int, []),
+    "matten_conv_tile_dump_stride": (c_int, []),
+    "matten_species_tiles_slots_per_block": (c_int64, [c_int64, c_int64]),
+    "matten_species_tiles": (c_int, [P, c_int64, c_int64, c_int64, P, P, P]),
+    "matten_conv_tile": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, P, c_int64, c_int64, P, P, c_float, P,
+                                 P, P, c_int64, c_int64, P, c_int64, P, P, P, P, c_int64, P, c_int64, c_int64, P, P, P, P,
+                                 c_int64, P, c_int64, P]),
     "matten_tp_fused": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
     "matten_species_linear": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
     "matten_species_linear_rows": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),

@@ -22,23 +22,27 @@ __global__ __launch_bounds__(256) void calib_valu_kernel(int64_t iters, float se
 #pragma unroll
     for (int k = 0; k < CALIB_CHAINS; ++k) acc[k] = seed + (float)(threadIdx.x + k);
     const float m = 1.0f - 1e-7f * seed, a = 1e-9f * seed;   // run-time operands in VGPRs: VOP3 v_fma_f32 v, v, v, v
-    unsigned long long t0 = 0, r0 = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        t0 = __builtin_readcyclecounter();            // s_memtime: shader clock
-        r0 = wall_clock64();                          // s_memrealtime: constant 100 MHz
-    }
+    // the clock reads are pinned to both ends of the loop: asm volatile statements keep their order, and the empty ones make
+    // every accumulator an input / output of that point (a plain readcyclecounter floats freely around register-only code)
+    unsigned long long t0 = 0, r0 = 0, t1 = 0, r1 = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+#pragma unroll
+    for (int k = 0; k < CALIB_CHAINS; ++k) asm volatile("" : "+v"(acc[k]));
     for (int64_t it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < CALIB_UNROLL; ++u)
 #pragma unroll
             for (int k = 0; k < CALIB_CHAINS; ++k) acc[k] = __builtin_fmaf(acc[k], m, a);
     }
+#pragma unroll
+    for (int k = 0; k < CALIB_CHAINS; ++k) asm volatile("" : "+v"(acc[k]));
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < CALIB_CHAINS; ++k) s += acc[k];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        clocks[0] = __builtin_readcyclecounter() - t0;
-        clocks[1] = wall_clock64() - r0;
+        clocks[0] = t1 - t0;      // s_memtime: shader clock
+        clocks[1] = r1 - r0;      // s_memrealtime: constant 100 MHz
     }
     if (s == 12345.678f) out[0] = s;                  // keeps the chain alive
 }

@@ -1,0 +1,428 @@
+// Conv layer on 16-node single-species tiles: tensor product + neighbour sum + lin2 + self-connection in one kernel, the
+// neighbour sums agg[N, d_mid] never leave the chip.
+//   reference nn/conv.py:113-123      msg = tp(x[src], edge_attrs, edge_embedding); agg = scatter(msg, dst) / sqrt(avg)
+//                                     out = lin2(agg, species) + self_connection
+//
+// Why: agg is written by matten_tp_fused and read back by matten_agg_linear -- ~1 GB each way per layer at 64 000 nodes,
+// ~70 % of the forward's HBM traffic.  Two earlier fused attempts lost because lin2's weights are indexed by
+// the DESTINATION species: 27-41 KB of weights per node against 12 KB of agg saved.  Here a workgroup owns a TILE of 16
+// destination nodes of ONE species (matten_species_tiles below: blocks of ~32 crystals, every (block, species) run padded
+// to 16), so lin2 is a matrix product per tile with the species' weights as ready A fragments, and the x[src] gathers of
+// a tile stay inside a ~2 MB L2 footprint.
+//
+// The workgroup (4 waves) walks the layer's group entries in ROUNDS: four entries of one class on one node group of the
+// tile, i.e. the workgroup-shared walk of matten_tp_fused (tp_walk.h: same staging, same fp16-split matrix products for
+// the last radial layer, same literal-coefficient contraction, same per-node summation order).  After a round the waves
+// park their sums in LDS register by register -- dump[reg][lane], conflict-free stores, in passes of DUMP_REGS registers
+// cut at coupling boundaries so that the dump fits the LDS the walk has just released -- and lin2 is applied there:
+//     out[n, io, v, k] += sum_u A_p[u, v] * acc_e[n, u, (c, k)]            p = path (entry e, coupling c) -> io
+// as v_mfma_f32_16x16x4_f32: M = 16 output channels v, K = 4 channels u per step, N = 16 (node, component) columns.
+// Lane (g, col) reads the KS = lanes-per-node / 4 channels g*KS.. of its column from the dump with ONE ds_read (they are
+// neighbouring lanes of one register), the A fragments come from a per-species table with one coalesced load per (piece,
+// output tile).  A UNIT (output irrep, 16-channel tile, <= 4 column tiles) belongs to one wave of the round (balanced by
+// the host, plan_conv.py): it sums every piece of the round that ends in that irrep in registers and adds the result to
+// the tile's output rows in LDS.  Fixed order everywhere, no atomics: a node's result does not depend on its tile mates
+// (matrix columns are independent), so tiles may be composed in any order.
+// The rows start as the self-connection and leave as lin2's output; with the Gate tables (cmeta) the e3nn Gate and the
+// eval-mode BatchNorm that follow the conv (reference nn/conv.py:209-213) are applied while the rows are written.
+#include <atomic>
+
+#include "tp_walk.h"
+
+namespace {
+
+using namespace matten_walk;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CT_NODES = 16;      // == plan_conv.TILE_NODES
+constexpr int CT_DUMP_RS = 68;    // == plan_conv.DUMP_RS
+constexpr int CT_DUMP_REGS = 28;  // == plan_conv.DUMP_REGS
+constexpr int CT_MAX_NT = 4;      // == plan_conv.UNIT_MAX_NT
+#ifndef CT_MIN_BLOCKS
+#define CT_MIN_BLOCKS 3
+#endif
+
+struct CArgs {
+    const int* tile_nodes;     // [n_slots, 16] node ids, -1 = padding
+    const int* tile_species;   // [n_slots] species of the tile, -1 = empty slot
+    const int4* quads;         // [n_quads, 2] {e0, e1, e2, e3} {class lanes per node (log2), passes, node groups, wave_units base}
+    const int2* wave_units;    // [.., 2] {first unit, count} of (quad, pass, wave)
+    const int4* units;         // [n_units, 2] {out col of (v = 16 mt, k = 0), d3, valid v, nt0} {n_nt, first piece, n pieces, log2 nodes per wave}
+    const int4* pieces;        // [n_pieces] {dump offset, A offset, lanes per node (log2) of the entry, 0}
+    const float* atab;         // [n_species, a_stride]
+    const float* add;          // [N, add_ld] self-connection, or NULL
+    float* out;                // [N, out_gld]
+    const int4* cmeta;         // Gate: per ACTIVATED column {source column, gate column or -1, act | gate act << 8, bn index | mean index << 16}, or NULL
+    const float* act_cst;
+    const float* bn_scale;     // [d_act] or NULL
+    const float* bn_shift;
+    int n_quads, a_stride, n_slots, slots_per_block, add_ld, out_gld, d_out, d_act, out_ld, walk_floats;
+};
+
+// ---- compile-time pass layout of a group kind: couplings in order, a new pass when the next one does not fit ----------
+template <class G>
+struct DumpLayout {
+    int pass[G::NC];
+    int rel[G::NC];
+    int n_pass;
+    constexpr DumpLayout() : pass{}, rel{}, n_pass(1) {
+        int used = 0, p = 0;
+        for (int c = 0; c < G::NC; ++c) {
+            const int d3 = 2 * G::L3[c] + 1;
+            if (used + d3 > CT_DUMP_REGS) {
+                ++p;
+                used = 0;
+            }
+            pass[c] = p;
+            rel[c] = used;
+            used += d3;
+        }
+        n_pass = p + 1;
+    }
+};
+
+struct Lin2Ctx {
+    const CArgs* ca;
+    const float* atab_sp;   // the tile's species row of the A table
+    float* dump_all;        // the four waves' dump regions
+    float* otile;           // [16][out_ld]
+    int wu_base, n_pass, r;
+};
+
+__device__ __forceinline__ float ct_act(int code, float v) {
+    switch (code) {
+        case 1: return v / (1.0f + expf(-v));                          // silu
+        case 2: return tanhf(v);                                       // tanh
+        case 3: return 1.0f / (1.0f + expf(-v));                       // sigmoid
+        case 4: return (v > 20.0f ? v : log1pf(expf(v))) - 0.6931471805599453f;  // shifted softplus
+        case 5: return fabsf(v);                                       // abs
+        default: return v;
+    }
+}
+
+// lin2 of one pass of a round: this wave's units (see the header comment)
+__device__ __noinline__ void lin2_phase(const Lin2Ctx& cx, int pass) {
+    const CArgs& ca = *cx.ca;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, c = lane & 15;
+    const int2 wu = ca.wave_units[cx.wu_base + pass * WAVES_PER_BLOCK + wave];
+    const int u_beg = __builtin_amdgcn_readfirstlane(wu.x), u_cnt = __builtin_amdgcn_readfirstlane(wu.y);
+    for (int ui = u_beg; ui < u_beg + u_cnt; ++ui) {
+        const int4 r0 = ca.units[2 * ui], r1 = ca.units[2 * ui + 1];
+        const int col0 = __builtin_amdgcn_readfirstlane(r0.x), d3 = __builtin_amdgcn_readfirstlane(r0.y);
+        const int vcount = __builtin_amdgcn_readfirstlane(r0.z), nt0 = __builtin_amdgcn_readfirstlane(r0.w);
+        const int n_nt = __builtin_amdgcn_readfirstlane(r1.x), p_beg = __builtin_amdgcn_readfirstlane(r1.y);
+        const int p_cnt = __builtin_amdgcn_readfirstlane(r1.z), npw_log2 = __builtin_amdgcn_readfirstlane(r1.w);
+        const int npw = 1 << npw_log2;
+        // column of this lane in each of the unit's column tiles: (node j of the round's group, component k)
+        int jn[CT_MAX_NT], kk[CT_MAX_NT];
+#pragma unroll
+        for (int nt = 0; nt < CT_MAX_NT; ++nt) {
+            const int col = (nt0 + min(nt, n_nt - 1)) * 16 + c;
+            jn[nt] = col & (npw - 1);
+            kk[nt] = col >> npw_log2;
+        }
+        f32x4 D[CT_MAX_NT];
+#pragma unroll
+        for (int nt = 0; nt < CT_MAX_NT; ++nt) D[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pi = p_beg; pi < p_beg + p_cnt; ++pi) {
+            const int4 pc = ca.pieces[pi];
+            const int doff = __builtin_amdgcn_readfirstlane(pc.x), aoff = __builtin_amdgcn_readfirstlane(pc.y);
+            const int cu_log2 = __builtin_amdgcn_readfirstlane(pc.z);
+            const float* ap = cx.atab_sp + aoff;
+            const float* db = cx.dump_all + doff;
+            if (cu_log2 >= 4) {           // 16 lanes per node: 4 contraction steps, lane group g owns channels 4 g .. 4 g + 3
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ap + lane * 4);
+#pragma unroll
+                for (int nt = 0; nt < CT_MAX_NT; ++nt) {
+                    if (nt < n_nt) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(db + min(kk[nt], d3 - 1) * CT_DUMP_RS + jn[nt] * 16 + g * 4);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) D[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], D[nt], 0, 0, 0);
+                    }
+                }
+            } else if (cu_log2 == 3) {    // 8 lanes per node: 2 steps, channels 2 g, 2 g + 1
+                const f32x2 av = *reinterpret_cast<const f32x2*>(ap + lane * 2);
+#pragma unroll
+                for (int nt = 0; nt < CT_MAX_NT; ++nt) {
+                    if (nt < n_nt) {
+                        const f32x2 bv = *reinterpret_cast<const f32x2*>(db + min(kk[nt], d3 - 1) * CT_DUMP_RS + jn[nt] * 8 + g * 2);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) D[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], D[nt], 0, 0, 0);
+                    }
+                }
+            } else {                      // 4 or 2 lanes per node: one step, channel g (two lanes: g >= 2 meets zero weights)
+                const float av = ap[lane];
+#pragma unroll
+                for (int nt = 0; nt < CT_MAX_NT; ++nt) {
+                    if (nt < n_nt) {
+                        const float bv = db[min(kk[nt], d3 - 1) * CT_DUMP_RS + (jn[nt] << cu_log2) + g];
+                        D[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, D[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // D[nt][i] = out channel 4 g + i of column (jn, kk): add to the tile's rows (this wave owns these columns in this pass)
+#pragma unroll
+        for (int nt = 0; nt < CT_MAX_NT; ++nt) {
+            if (nt < n_nt && kk[nt] < d3) {
+                float* op = cx.otile + (cx.r * npw + jn[nt]) * ca.out_ld + col0 + kk[nt];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int v = 4 * g + i;
+                    if (v < vcount) op[v * d3] += D[nt][i];
+                }
+            }
+        }
+    }
+}
+
+// what a wave does with its neighbour sums: park them for lin2, pass by pass
+struct StoreDump {
+    float* dump;            // this wave's region [CT_DUMP_REGS][CT_DUMP_RS]
+    const Lin2Ctx* cx;
+    template <class G>
+    __device__ __forceinline__ void store(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
+                                          float a_scale_inv, int node, int j, int u, bool valid) const {
+        constexpr DumpLayout<G> L{};
+        const int lane = threadIdx.x & 63;
+        float norm = 0.0f;   // idle channel lanes and padding nodes park zeros: the matrix products read every lane
+        if (valid) norm = a_scale_inv / sqrtf(a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node]);
+#pragma unroll
+        for (int p = 0; p < L.n_pass; ++p) {
+#pragma unroll
+            for (int cc = 0; cc < G::NC; ++cc) {
+                if (L.pass[cc] == p && ((ge.mask >> cc) & 1u)) {
+                    const int d3 = 2 * G::L3[cc] + 1;
+#pragma unroll
+                    for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
+                        if (k < d3) dump[(L.rel[cc] + k) * CT_DUMP_RS + lane] = acc[G::OFF[cc] + k] * norm;
+                }
+            }
+            __syncthreads();          // every wave's sums of this pass are parked
+            lin2_phase(*cx, p);
+            __syncthreads();          // ... and consumed: the next pass / the next round's walk may overwrite them
+        }
+        for (int p = L.n_pass; p < cx->n_pass; ++p) {   // a round mate has more passes: its pieces may be this wave's units
+            __syncthreads();
+            lin2_phase(*cx, p);
+            __syncthreads();
+        }
+    }
+};
+
+#define CT_RGS(L1, GI, TD) \
+    run_group_shared<L1, GI, 1, TD, false, 0u>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreDump{dump, &cx})
+#define CT_GROUP_CASE(L1, GI) \
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): \
+        if (TwoDeepOk<L1, GI>::value && nodes_per_wave <= 8 && nodes_per_wave >= 2) CT_RGS(L1, GI, (TwoDeepOk<L1, GI>::value)); \
+        else CT_RGS(L1, GI, false); \
+        break;
+
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, CT_MIN_BLOCKS) void conv_tile_kernel(Args a, CArgs ca,
+                                                                                       const GroupEntry* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // tile slots are numbered block-major; the slots of one block of crystals run on ONE XCD (its L2 holds their x rows)
+    const int xcd = blockIdx.x % N_XCD;
+    const int q = blockIdx.x / N_XCD;
+    const int blk = (q / ca.slots_per_block) * N_XCD + xcd;
+    const int slot = blk * ca.slots_per_block + q % ca.slots_per_block;
+    if (slot >= ca.n_slots) return;
+    const int sp = __builtin_amdgcn_readfirstlane(ca.tile_species[slot]);
+    if (sp < 0) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // LDS: [walk area: 4 weight tiles + stage | overlaid by the 4 dump regions] [output rows 16 x out_ld] [node ids 16]
+    float* tile = lds + wave * a.lds_per_wave;
+    float* stage = lds + WAVES_PER_BLOCK * a.lds_per_wave;
+    float* dump = lds + wave * (CT_DUMP_REGS * CT_DUMP_RS);
+    float* otile = lds + ca.walk_floats;
+    int* nid = reinterpret_cast<int*>(otile + CT_NODES * ca.out_ld);
+    if (threadIdx.x < CT_NODES) nid[threadIdx.x] = ca.tile_nodes[slot * CT_NODES + threadIdx.x];
+    __syncthreads();
+    for (int i = threadIdx.x; i < CT_NODES * ca.d_out; i += WAVES_PER_BLOCK * 64) {
+        const int row = i / ca.d_out, col = i - row * ca.d_out;
+        const int n = nid[row];
+        otile[row * ca.out_ld + col] = (ca.add && n >= 0) ? ca.add[(int64_t)n * ca.add_ld + col] : 0.0f;
+    }
+    Lin2Ctx cx{&ca, ca.atab + (int64_t)sp * ca.a_stride, lds, otile, 0, 0, 0};
+    __syncthreads();
+
+    for (int qi = 0; qi < ca.n_quads; ++qi) {
+        const int4 q0 = ca.quads[2 * qi], q1 = ca.quads[2 * qi + 1];
+        const int e = __builtin_amdgcn_readfirstlane(wave == 0 ? q0.x : wave == 1 ? q0.y : wave == 2 ? q0.z : q0.w);
+        const int class_cu_log2 = __builtin_amdgcn_readfirstlane(q1.x);
+        const int n_groups = __builtin_amdgcn_readfirstlane(q1.z);
+        cx.n_pass = __builtin_amdgcn_readfirstlane(q1.y);
+        cx.wu_base = __builtin_amdgcn_readfirstlane(q1.w);
+        for (int r = 0; r < n_groups; ++r) {
+            cx.r = r;
+            // a loader-only wave takes the geometry of the class (its rows are the class's rows)
+            const int cu_log2 = e >= 0 ? entries[e].cu_log2 : class_cu_log2;
+            const int cu = 1 << cu_log2;
+            const int nodes_per_wave = 64 >> cu_log2;
+            const int g_in_tile = r * nodes_per_wave + (lane >> cu_log2);
+            const int u = lane & (cu - 1);
+            const int node = g_in_tile < CT_NODES ? nid[g_in_tile] : -1;
+            const bool in_range = node >= 0;
+            int beg = 0, deg = 0;
+            if (in_range) {
+                beg = a.rowptr[node];
+                deg = a.rowptr[node + 1] - beg;
+            }
+            int maxdeg = deg;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+            if (e < 0) {
+                run_loader_only_t<1>(a, cu_log2, stage, beg, deg, maxdeg);
+                for (int p = 0; p < cx.n_pass; ++p) {
+                    __syncthreads();
+                    lin2_phase(cx, p);
+                    __syncthreads();
+                }
+            } else {
+                const GroupEntry& ge = entries[e];
+                const bool valid = in_range && (u < ge.mul);
+                switch (ge.kind) {
+                    MATTEN_FOR_EACH_GROUP(CT_GROUP_CASE)
+                    default: break;
+                }
+            }
+        }
+    }
+    // the rows leave: plain lin2 output, or Gate (+ eval BatchNorm) applied on the way
+    if (ca.cmeta) {
+        for (int i = threadIdx.x; i < CT_NODES * ca.d_act; i += WAVES_PER_BLOCK * 64) {
+            const int row = i / ca.d_act, col = i - row * ca.d_act;
+            const int n = nid[row];
+            if (n < 0) continue;
+            const int4 m = ca.cmeta[col];
+            const float* orow = otile + row * ca.out_ld;
+            const int act = m.z & 255, gact = (m.z >> 8) & 255;
+            float v = orow[m.x];
+            if (m.y < 0) {
+                if (act) v = ct_act(act, v) * ca.act_cst[act];
+            } else {
+                float gv = orow[m.y];
+                if (gact) gv = ct_act(gact, gv) * ca.act_cst[gact];
+                v *= gv;
+            }
+            if (ca.bn_scale) v = fmaf(v, ca.bn_scale[col], ca.bn_shift[col]);
+            ca.out[(int64_t)n * ca.out_gld + col] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < CT_NODES * ca.d_out; i += WAVES_PER_BLOCK * 64) {
+            const int row = i / ca.d_out, col = i - row * ca.d_out;
+            const int n = nid[row];
+            if (n >= 0) ca.out[(int64_t)n * ca.out_gld + col] = otile[row * ca.out_ld + col];
+        }
+    }
+}
+
+// ---- tiles: per block of `block_nodes` consecutive nodes, the nodes grouped by species and cut into 16-node tiles -------
+// One workgroup per block.  Slot layout: block b owns slots [b * slots_per_block, (b + 1) * slots_per_block), the tiles of
+// its species in species order from the front, unused slots marked -1.  Inside a species the order follows the atomics
+// (a node's result does not depend on its place in a tile).
+constexpr int ST_THREADS = 256;
+constexpr int ST_MAX_SPECIES = 1024;
+
+__global__ __launch_bounds__(ST_THREADS) void species_tiles_kernel(const int* __restrict__ species, int n_nodes, int n_species,
+                                                                   int block_nodes, int slots_per_block,
+                                                                   int* __restrict__ tile_nodes, int* __restrict__ tile_species) {
+    __shared__ int cnt[ST_MAX_SPECIES], first[ST_MAX_SPECIES], cur[ST_MAX_SPECIES];
+    const int b = blockIdx.x;
+    const int lo = b * block_nodes, hi = min(n_nodes, lo + block_nodes);
+    for (int s = threadIdx.x; s < n_species; s += ST_THREADS) cnt[s] = 0, cur[s] = 0;
+    for (int i = threadIdx.x; i < slots_per_block; i += ST_THREADS) tile_species[b * slots_per_block + i] = -1;
+    for (int i = threadIdx.x; i < slots_per_block * CT_NODES; i += ST_THREADS)
+        tile_nodes[(int64_t)b * slots_per_block * CT_NODES + i] = -1;
+    __syncthreads();
+    for (int n = lo + threadIdx.x; n < hi; n += ST_THREADS) atomicAdd(&cnt[min(max(species[n], 0), n_species - 1)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int s = 0; s < n_species; ++s) {
+            first[s] = t;
+            const int nt = (cnt[s] + CT_NODES - 1) / CT_NODES;
+            for (int k = 0; k < nt; ++k) tile_species[b * slots_per_block + t + k] = s;
+            t += nt;
+        }
+    }
+    __syncthreads();
+    for (int n = lo + threadIdx.x; n < hi; n += ST_THREADS) {
+        const int s = min(max(species[n], 0), n_species - 1);
+        const int pos = atomicAdd(&cur[s], 1);
+        tile_nodes[((int64_t)b * slots_per_block + first[s]) * CT_NODES + pos] = n;
+    }
+}
+
+}  // namespace
+
+extern "C" int matten_conv_tile_nodes(void) { return CT_NODES; }
+extern "C" int matten_conv_tile_dump_regs(void) { return CT_DUMP_REGS; }
+extern "C" int matten_conv_tile_dump_stride(void) { return CT_DUMP_RS; }
+
+extern "C" int64_t matten_species_tiles_slots_per_block(int64_t block_nodes, int64_t n_species) {
+    return block_nodes / CT_NODES + n_species;
+}
+
+extern "C" int matten_species_tiles(const int32_t* species, int64_t n_nodes, int64_t n_species, int64_t block_nodes,
+                                    int32_t* tile_nodes, int32_t* tile_species, matten_stream_t stream_) {
+    if (n_nodes < 0 || n_species <= 0 || n_species > ST_MAX_SPECIES || block_nodes <= 0 || (block_nodes % CT_NODES))
+        return MATTEN_EINVAL;
+    if (n_nodes == 0) return MATTEN_OK;
+    if (!species || !tile_nodes || !tile_species) return MATTEN_EINVAL;
+    const int64_t n_blocks = matten_cdiv(n_nodes, block_nodes);
+    const int64_t spb = matten_species_tiles_slots_per_block(block_nodes, n_species);
+    if (n_blocks * spb * CT_NODES >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+    species_tiles_kernel<<<(unsigned)n_blocks, ST_THREADS, 0, (hipStream_t)stream_>>>(
+        species, (int)n_nodes, (int)n_species, (int)block_nodes, (int)spb, tile_nodes, tile_species);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int matten_conv_tile(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
+                                const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr,
+                                const int32_t* src_sorted, int64_t n_nodes, const int32_t* entries, int64_t n_entries,
+                                int64_t lds_floats_per_wave, const uint16_t* a_split, const float* a_scale_inv,
+                                float avg_num_neighbors, const float* num_neigh, const int32_t* tile_nodes,
+                                const int32_t* tile_species, int64_t n_slots, int64_t slots_per_block,
+                                const int32_t* quads, int64_t n_quads, const int32_t* wave_units, const int32_t* units,
+                                const int32_t* pieces, const float* atab, int64_t a_stride, const float* add,
+                                int64_t add_ld, int64_t d_out, const int32_t* cmeta, const float* act_cst,
+                                const float* bn_scale, const float* bn_shift, int64_t d_act, float* out, int64_t out_ld,
+                                matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_nodes < 0 || d_in <= 0 || w_pad <= 0 || sh_stride < 32 || (sh_stride & 3) || n_entries <= 0 ||
+        lds_floats_per_wave <= 0 || (lds_floats_per_wave & 3) || n_slots < 0 || slots_per_block <= 0 || n_quads <= 0 ||
+        a_stride <= 0 || (a_stride & 3) || d_out <= 0 || out_ld <= 0)
+        return MATTEN_EINVAL;
+    if (n_nodes == 0 || n_slots == 0) return MATTEN_OK;
+    if (!x || !h2s || !w2p || !sh_sorted || !rowptr || !src_sorted || !entries || !a_split || !a_scale_inv || !tile_nodes ||
+        !tile_species || !quads || !wave_units || !units || !pieces || !atab || !out)
+        return MATTEN_EINVAL;
+    if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
+    if (add && add_ld < d_out) return MATTEN_EINVAL;
+    if (cmeta && (!act_cst || d_act <= 0 || out_ld < d_act)) return MATTEN_EINVAL;
+    if (!cmeta && out_ld < d_out) return MATTEN_EINVAL;
+    if ((bn_scale == nullptr) != (bn_shift == nullptr)) return MATTEN_EINVAL;
+    const int lds_out_ld = (int)((d_out + 3) / 4 * 4 + 4);
+    const int64_t walk = (int64_t)WAVES_PER_BLOCK * lds_floats_per_wave + 2 * 16 * STAGE_ROW;
+    const int64_t dump = (int64_t)WAVES_PER_BLOCK * CT_DUMP_REGS * CT_DUMP_RS;
+    const int64_t walk_floats = walk > dump ? walk : dump;
+    const size_t lds = sizeof(float) * (size_t)(walk_floats + (int64_t)CT_NODES * lds_out_ld + 32);
+    if (lds > 64 * 1024) return MATTEN_EINVAL;
+    Args a{x, (const _Float16*)h2s, w2p, (const _Float16*)a_split, a_scale_inv, sh_sorted, rowptr, src_sorted, num_neigh,
+           nullptr, (int)d_in, (int)w_pad, (int)sh_stride, 0, (int)n_nodes, (int)lds_floats_per_wave, avg_num_neighbors};
+    CArgs ca{tile_nodes, tile_species, (const int4*)quads, (const int2*)wave_units, (const int4*)units, (const int4*)pieces,
+             atab, add, out, (const int4*)cmeta, act_cst, bn_scale, bn_shift, (int)n_quads, (int)a_stride, (int)n_slots,
+             (int)slots_per_block, (int)add_ld, (int)out_ld, (int)d_out, (int)d_act, lds_out_ld, (int)walk_floats};
+    const int64_t n_blocks = matten_cdiv(n_slots, slots_per_block);
+    const int64_t grid = matten_cdiv(n_blocks, N_XCD) * N_XCD * slots_per_block;
+    if (grid >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+    conv_tile_kernel<<<(unsigned)grid, WAVES_PER_BLOCK * 64, lds, stream>>>(a, ca, (const GroupEntry*)entries);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}

@@ -29,6 +29,13 @@ KEPT_ONLY = "_amd_kept_irreps_only"   # batch-dict marker: node_features hold th
 # inference: skip the output irreps of the last conv layer nothing reads (PointConv.build_inference_view); 0 = run them
 DEAD_PATH_ELIMINATION = _os.environ.get("MATTEN_DEAD_PATH_ELIMINATION", "1") != "0"
 AGG_KM_MIN_ROWS = int(_os.environ.get("MATTEN_AGG_KM_MIN_ROWS", "8192"))   # nodes per batch from which lin2 streams component-major rows
+# conv-tile kernel (matten_conv_tile: agg stays on chip): "0" off; layers with at least CONV_TILE_MIN_DMID floats of
+# neighbour sums per node, batches of at least CONV_TILE_MIN_ROWS nodes, tiles cut from blocks of CONV_TILE_BLOCK nodes
+CONV_TILE = _os.environ.get("MATTEN_CONV_TILE", "1")
+CONV_TILE_MIN_ROWS = int(_os.environ.get("MATTEN_CONV_TILE_MIN_ROWS", "8192"))
+CONV_TILE_MIN_DMID = int(_os.environ.get("MATTEN_CONV_TILE_MIN_DMID", "1000"))
+CONV_TILE_BLOCK = int(_os.environ.get("MATTEN_CONV_TILE_BLOCK", "2048"))
+TILES_KEY = "_amd_species_tiles"      # batch-dict cache: (tile_nodes, tile_species, slots per block, species tensor it was cut from)
 
 
 class PointConv(ModuleIrreps, torch.nn.Module):
@@ -67,27 +74,24 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         self.irreps_out[DataKey.NODE_FEATURES] = conv_layer_irreps
         self._lin1_sc = None  # built at first inference forward
         self._lin1_sc_packed = DerivedWeight(self._pack_lin1_sc)
-        # conv-fused inference path (matten_tp_lin2): the light input blocks' tensor product, neighbour sum and lin2 in
-        # one kernel; None when the layer has no such block or the variant is not the fused one
+        # conv-tile inference path (matten_conv_tile): tensor product + neighbour sum + lin2 (+ Gate) per 16-node
+        # single-species tile, agg never reaches memory; None when the layer does not fit (plan_conv.plan_conv_tile)
         from .. import plan as _plan
-        self.fused_plan = (_plan.plan_conv_fused(self.tp.plan, n_species, conv_layer_irreps)
-                           if self.tp.impl == "fused" else None)
-        if self.fused_plan is not None:
-            fp = self.fused_plan
-            self._fused_tables = DeviceTables(
-                light=fp.light_entries, rounds=fp.rounds, slot_index=fp.slot_index, slots=fp.slot_recs, items=fp.slot_items,
-                a_base=fp.a_base, a_stride=fp.a_stride, a_scale=fp.a_scale, light_ids=fp.light_ids,
-                heavy_ids=fp.heavy_ids, heavy=fp.heavy_entries, heavy_umap=fp.heavy_unit_map,
-                **({"rest_gather": fp.rest.gather, "rest_scale": fp.rest.scale,
-                    **{f"rest_meta{i}": m for i, m in enumerate(fp.rest.passes)}} if fp.rest is not None else {}),
-            )
-            self._fused_atab = DerivedWeight(self._build_atab)
-            self._fused_rest_w = DerivedWeight(self._pack_rest)
-            self._fused_split = DerivedWeight(self._split_by_role)
+        from .. import plan_conv as _plan_conv
+        self.tile_plan = None
+        if self.tp.impl == "fused" and CONV_TILE != "0":
+            tpl = _plan_conv.plan_conv_tile(self.tp.plan, n_species, conv_layer_irreps)
+            if tpl is not None:
+                self.tile_plan = tpl
+                self._tile_tables = DeviceTables(entries=tpl.entries, quads=tpl.quads, wave_units=tpl.wave_units,
+                                                 units=tpl.units, pieces=tpl.pieces, gather=tpl.gather, scale=tpl.scale,
+                                                 cols=tpl.fused_cols)
+                self._tile_atab = DerivedWeight(self._pack_tile_atab)
+                self._tile_radial = DerivedWeight(self._pack_tile_radial)
         # component-major neighbour sums + streaming lin2 (matten_agg_linear): the inference path of the two-kernel conv
         import os
         self.agg_plan = None
-        if self.tp.impl == "fused" and self.fused_plan is None and os.environ.get("MATTEN_AGG_LAYOUT", "km") == "km":
+        if self.tp.impl == "fused" and os.environ.get("MATTEN_AGG_LAYOUT", "km") == "km":
             ap = _plan.plan_agg_linear(self.tp.plan, n_species, conv_layer_irreps)
             if ap is not None and self._agg_fits(ap):
                 self.agg_plan = ap
@@ -115,24 +119,6 @@ class PointConv(ModuleIrreps, torch.nn.Module):
                 self._lin1_sc = DeviceTables(meta=segs)
         return self._lin1_sc
 
-    # ---- derived tensors of the conv-fused path (rebuilt when the parameters change) ----
-    def _build_atab(self, w: torch.Tensor) -> torch.Tensor:
-        """lin2.weight (flat, reference layout) -> [S, a_numel] table of matten_tp_lin2"""
-        t, dev = self._fused_tables, w.device
-        base, stride, scale = t.get("a_base", dev), t.get("a_stride", dev), t.get("a_scale", dev)
-        s = torch.arange(self.lin2.n_species, device=dev, dtype=torch.int64)[:, None]
-        idx = base.clamp(min=0)[None, :] + s * stride[None, :]
-        return torch.where(base[None, :] >= 0, w[idx] * scale[None, :], w.new_zeros(())).contiguous()
-
-    def _pack_rest(self, w: torch.Tensor) -> torch.Tensor:
-        t, dev = self._fused_tables, w.device
-        return (w[t.get("rest_gather", dev)] * t.get("rest_scale", dev)).contiguous()
-
-    def _split_by_role(self, frag: torch.Tensor, scale_inv: torch.Tensor):
-        """per-entry power-of-two scales of the A fragments, re-indexed for the light and the heavy entry lists"""
-        t, dev = self._fused_tables, frag.device
-        return scale_inv[t.get("light_ids", dev)].contiguous(), scale_inv[t.get("heavy_ids", dev)].contiguous()
-
     @staticmethod
     def _agg_fits(ap) -> bool:
         """the layer's tables fit the LDS matten_agg_linear may take (wider layers keep the mul_ir path)"""
@@ -149,32 +135,39 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         gather, scale = t.get("gather", dev), t.get("scale", dev)
         return torch.where(gather >= 0, w[gather.clamp(min=0)] * scale[None, :], w.new_zeros(())).contiguous()
 
-    def _forward_fused(self, x1, self_connection, species, data):
-        """out = lin2(agg) + self_connection without the light three quarters of agg ever reaching memory"""
-        fp, t, dev = self.fused_plan, self._fused_tables, x1.device
-        tp = self.tp
+    # ---- conv-tile path: operands derived from the parameters (rebuilt when they change) --------------------------------
+    def _pack_tile_atab(self, w: torch.Tensor) -> torch.Tensor:
+        """lin2.weight (flat, reference layout) -> [S, a_stride] MFMA A fragments of matten_conv_tile"""
+        t, dev = self._tile_tables, w.device
+        gather, scale = t.get("gather", dev), t.get("scale", dev)
+        return torch.where(gather >= 0, w[gather.clamp(min=0)] * scale[None, :], w.new_zeros(())).contiguous()
+
+    def _pack_tile_radial(self, w0: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, h_scale: torch.Tensor):
+        """last radial layer in the tile entries' [entry][u][coupling] column order -> (w2p, fp16 hi/lo fragments,
+        1 / (fragment scale x hidden-feature scale) per entry), the operands matten_tp_fused gets from UVUTensorProduct"""
+        w2p = self.tp.weight_nn.pack_last(w2, self._tile_tables.get("cols", w2.device))
+        frag, scale_inv = ops.split_a_tiles(w2p, self.tile_plan.entries)
+        return w2p, frag, (scale_inv * h_scale[1]).contiguous()
+
+    def _forward_tile(self, x1, self_connection, data, gate):
+        """lin2(agg) + self_connection (Gate / BatchNorm applied when `gate` is given) with agg never leaving the chip"""
+        tpl, t, dev = self.tile_plan, self._tile_tables, x1.device
+        mlp = self.tp.weight_nn
         nb, r0, r1 = data[DataKey.AMD_RBF].tolist()
         avg = self.avg_num_neighbors if self.avg_num_neighbors is not None else 0.0
         num_neigh = None if self.avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
-        h2p, w2p = tp.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, data)
-        frag, scale_inv = tp.a_split(r0, r1)
-        inv_light, inv_heavy = self._fused_split.get(frag, scale_inv)
-        out = ops.tp_lin2(
-            x1, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC], t.get("light", dev),
-            t.get("rounds", dev), t.get("slot_index", dev), t.get("slots", dev), t.get("items", dev),
-            self._fused_atab.get(self.lin2.weight), data[DataKey.AMD_SPECIES_I32], avg, num_neigh, (frag, inv_light),
-            self_connection, fp.d_out,
-        )
-        if fp.rest is None:
-            return out
-        agg_rest = ops.tp_fused(
-            x1, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC], t.get("heavy", dev),
-            t.get("heavy_umap", dev), len(fp.heavy_unit_map), tp.plan.fused_lds_floats_per_wave, fp.d_rest, avg,
-            num_neigh, a_split=(frag, inv_heavy),
-        )
-        metas = [t.get(f"rest_meta{i}", dev) for i in range(len(fp.rest.passes))]
-        return ops.species_linear(agg_rest, species, self._fused_rest_w.get(self.lin2.weight), fp.rest.w_stride, metas,
-                                  fp.d_out, add=out, fully_covered=True)
+        h2p, _ = mlp.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, data)
+        w2p, frag, scale_inv = self._tile_radial.get(mlp.layer0.weight, mlp.layer1.weight, mlp.layer2.weight,
+                                                     mlp.h_scale(r0, r1))
+        tiles = data.get(TILES_KEY)
+        s32 = data[DataKey.AMD_SPECIES_I32]
+        if tiles is None or tiles[3] is not s32:
+            tiles = ops.species_tiles(s32, self.lin2.n_species, CONV_TILE_BLOCK) + (s32,)
+            data[TILES_KEY] = tiles
+        return ops.conv_tile(x1, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
+                             t.get("entries", dev), tpl.lds_floats_per_wave, (frag, scale_inv), avg, num_neigh, tiles[:3],
+                             t.get("quads", dev), t.get("wave_units", dev), t.get("units", dev), t.get("pieces", dev),
+                             self._tile_atab.get(self.lin2.weight), self_connection, tpl.d_out, gate=gate)
 
     # ---- dead-output elimination (inference) ------------------------------------------------------------------------
     def build_inference_view(self, kept_irreps) -> bool:
@@ -257,9 +250,13 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         else:
             self_connection = self.sc(x, species)
             x1 = self.lin1(x, species)
-        if (self.fused_plan is not None and DataKey.AMD_SPECIES_I32 in data
+        if (self.tile_plan is not None and x1.shape[0] >= CONV_TILE_MIN_ROWS and self.tp.plan.d_mid >= CONV_TILE_MIN_DMID
+                and DataKey.AMD_SPECIES_I32 in data
                 and not _ag.needs_grad(x1, self_connection, self.lin2.weight, *self.tp.weight_nn.parameters())):
-            data[DataKey.NODE_FEATURES] = self._forward_fused(x1, self_connection, species, data)
+            gate = self.__dict__.get("_gate_tile")   # set per call by PointConvWithActivation
+            data[DataKey.NODE_FEATURES] = self._forward_tile(x1, self_connection, data, gate)
+            if gate is not None:
+                data[GATE_APPLIED] = True
             return data
         # (small batches keep the mul_ir row + row kernels: matten_agg_linear's per-workgroup set-up -- weight fragments
         # and tables into LDS, species lookup -- is ~35 us of latency per launch that only a long stream pays back:
@@ -344,6 +341,24 @@ class PointConvWithActivation(ModuleIrreps, torch.nn.Module):
             scale, shift = self._fuse_bn.get(bn.running_mean, bn.running_var, bn.weight, bn.bias)
         return (fuse.get("cmeta", dev), self.act._tables.get("act_cst", dev), self.act.plan.irreps_out.dim, scale, shift)
 
+    def _gate_tile_args(self, dev):
+        """(gate table, act_cst, d_act, bn_scale, bn_shift) for matten_conv_tile's epilogue, or None when this layer / mode
+        keeps the separate Gate kernel (training-mode BatchNorm, instance normalisation, the norm activation)"""
+        if not GATE_FUSE or self.conv.tile_plan is None or getattr(self.act, "activation_type", "gate") != "gate":
+            return None
+        if self.norm.method not in ("batch", "none", None):
+            return None
+        bn = self.norm.n
+        if bn is not None and bn.training:
+            return None
+        scale = shift = None
+        if bn is not None:
+            if self.__dict__.get("_fuse_bn") is None:
+                self.__dict__["_fuse_bn"] = DerivedWeight(self._fold_bn)
+            scale, shift = self._fuse_bn.get(bn.running_mean, bn.running_var, bn.weight, bn.bias)
+        return (self.act._tables.get("meta", dev), self.act._tables.get("act_cst", dev), self.act.plan.irreps_out.dim,
+                scale, shift)
+
     def _fold_bn(self, rm, rv, w, b):
         """eval-mode BatchNorm as per-column (scale, shift) of the activated row (same folding as matten_gate_bn)"""
         meta = torch.as_tensor(np.asarray(self.act.plan.meta).reshape(-1, 4)[:, 3].astype(np.int64), device=w.device)
@@ -360,10 +375,13 @@ class PointConvWithActivation(ModuleIrreps, torch.nn.Module):
         if not _ag.needs_grad(x, *self.conv.parameters()) and x.shape[0] >= AGG_KM_MIN_ROWS:
             fuse = self._gate_fuse_args(x.device)
         self.conv.__dict__["_gate_fuse"] = fuse
+        self.conv.__dict__["_gate_tile"] = (self._gate_tile_args(x.device)
+                                            if not _ag.needs_grad(x, *self.conv.parameters()) else None)
         try:
             data = self.conv(data)
         finally:
             self.conv.__dict__["_gate_fuse"] = None
+            self.conv.__dict__["_gate_tile"] = None
         if data.pop(GATE_APPLIED, False):
             return data   # lin2's kernel wrote the activated (and normalised) row
         # Gate and (eval-mode) BatchNorm run as one elementwise kernel

@@ -175,6 +175,18 @@ class RadialMLP(torch.nn.Module):
         w2p[:, :W] = w2s
         return w0p, w1p, w2p
 
+    def pack_last(self, w2: Tensor, cols: Tensor) -> Tensor:
+        """the last layer pre-scaled with its columns in ANOTHER consumer's order (cols[j] = reference column of output
+        column j, -1 = zeros; e.g. the conv-tile kernel's entries), padded like the packed copy of _pack"""
+        h = self.hs[1]
+        w2s = w2 * (self.act_cst / h**0.5)
+        cols = cols.to(w2.device)
+        w2s = torch.where(cols[None, :] >= 0, w2s[:, cols.clamp(min=0)], w2s.new_zeros(()))
+        W = cols.numel()
+        w2p = w2.new_zeros(h, (W + 15) // 16 * 16 + 16)
+        w2p[:, :W] = w2s
+        return w2p
+
     def forward(self, geom_sorted: Tensor, n_basis: int, r_start: float, r_end: float) -> Tensor:
         """Per-edge weights w[E, w_pad] (all three layers)."""
         if n_basis != self.hs[0]:

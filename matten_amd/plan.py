@@ -40,10 +40,7 @@ TP_KIND_STRIDE = 8
 ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
 
 
-# conv-fused kernel (matten_tp_lin2): input blocks of degree <= LIN2_FUSE_LMAX whose entries have 8 lanes per node
-LIN2_FUSE_LMAX = 1
-LIN2_T_WAVE_FLOATS = 64 * 28   # per-wave LDS region: 64 lanes x the largest accumulator count of those kinds (28)
-LIN2_GROUP_NODES = 8
+LIGHT_LMAX = 1   # scalar and vector input blocks: every chunk of a block cut at 8 channels keeps 8 lanes per node
 
 FUSED_UNIT_SHARED = 1 << 24       # the unit's workgroup stages hidden features / harmonics once for its four waves
 FUSED_UNIT_LOADER_ONLY = 1 << 25  # padding unit of a shared workgroup: feeds the stage, contracts nothing
@@ -338,8 +335,8 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                 # at least two lanes per node (a multiplicity-1 entry idles one of them): at most 32 nodes, i.e. two
                 # 16-edge MFMA tiles, per wave and chunk, which is what the fused kernel's shared LDS stage holds
                 cu_log2 = max(1, (mul_c - 1).bit_length())
-                if l1 <= LIN2_FUSE_LMAX and cap == 8 and mul >= 8:
-                    cu_log2 = 3  # every chunk of a block the conv-fused kernel may take has 8 lanes per node
+                if l1 <= LIGHT_LMAX and cap == 8 and mul >= 8:
+                    cu_log2 = 3  # (a ragged last chunk joins its block's lanes-per-node class: one workgroup shape per block)
                 nodes_per_wave = max(1, 64 // (1 << cu_log2))
                 n_tiles16 = max(1, nodes_per_wave // 16)
                 # wave tile: [16 * n_tiles16 edge rows][weight columns + 4 (+ 32: units off the shared path park the
@@ -702,291 +699,6 @@ def plan_batchnorm(irreps, odd_scalars_too: bool = False) -> Tuple[np.ndarray, n
             off += ir.dim
             mi += is0
     return np.array(chan, dtype=np.int32).reshape(-1, 4), np.array(col2chan, dtype=np.int32)
-
-
-# ------------------------------------------------------------------------------------------
-# conv-fused kernel: 'uvu' tensor product + neighbour sum + the species-indexed lin2 of the light input blocks in one
-# kernel (matten_tp_lin2), the heavy blocks through a compact agg_rest and a restricted lin2
-# ------------------------------------------------------------------------------------------
-@dataclass
-class ConvFusedPlan:
-    """Tables of matten_tp_lin2 for one conv layer (reference nn/conv.py:113-123: tp -> scatter -> lin2 + sc).
-
-    A workgroup owns LIN2_GROUP_NODES = 8 destination nodes and walks the light group entries in ROUNDS of four (one
-    entry per wave, all on the same 8 nodes).  After a round's CSR walk the waves leave their neighbour sums in LDS
-    ([wave][coupling][node, k][channel]) and the workgroup applies lin2 to them: a SLOT is 8 consecutive (out channel v,
-    component k) pairs of one output irrep; its CHAIN lists every (wave, coupling) of the round that feeds that irrep
-    with the place of the matching [mul_out, 8] weight block in the per-species table.  A slot belongs to exactly one
-    wave, so the accumulation order into the output tile is fixed."""
-    light_entries: np.ndarray      # int32 [n_light, 32] GroupEntry records (subset of UVUPlan.group_entries)
-    rounds: np.ndarray             # int32 [n_rounds, 4] index into light_entries, -1 = loader-only wave
-    slot_index: np.ndarray         # int32 [n_rounds, 4, 2] (first slot, slot count) of (round, wave)
-    slots: np.ndarray              # int32 [n_slots, 8] {chain_begin, chain_len, d3, n_pairs, out_off, pair_base, magic, 0}
-    chain: np.ndarray              # int32 [n_chain, 2] {float offset in the LDS T area, float offset in the species table}
-    a_numel: int                   # floats per species of the weight table
-    a_base: np.ndarray             # int64 [a_numel] flat lin2.weight index at species 0, -1 = structural zero
-    a_stride: np.ndarray           # int64 [a_numel] flat index increment per species (= mul_out of the instruction)
-    a_scale: np.ndarray            # f32 [a_numel] fan_in^-1/2 of the output irrep
-    heavy_entries: np.ndarray      # int32 [n_heavy, 32] GroupEntry records with out_off remapped into agg_rest
-    heavy_unit_map: np.ndarray     # int32, plan.fused_unit_map of heavy_entries (empty when there is no heavy entry)
-    d_rest: int                    # row width of agg_rest
-    rest: Optional[LinearPlan]     # lin2 restricted to the heavy paths; gather / scale index the FULL lin2 weight
-    d_out: int
-    light_ids: np.ndarray = None   # int64: index of each light / heavy entry in UVUPlan.group_entries
-    heavy_ids: np.ndarray = None
-    # the same slots / chains flattened for the kernel: one ITEM per (slot, chain element), a wave's items of a round
-    # contiguous and slot-major; 4 packed words per item (see pack_lin2_items)
-    items: np.ndarray = None       # int32 [n_items, 4]
-    item_index: np.ndarray = None  # int32 [n_rounds, 4, 2] (first item, count) of (round, wave)
-    slot_recs: np.ndarray = None   # int32 [n_slots, 8]: kernel form of `slots` (merge_lin2_items)
-    slot_items: np.ndarray = None  # int32 [n_slot_items, 4]
-
-
-def merge_lin2_items(slot_index: np.ndarray, slots: np.ndarray, chain: np.ndarray, irreps_out_mul_of_off: Dict[int, int]):
-    """Kernel form of the slots: slot record {d3, n_pairs, out_off, pair_base, magic, first item, item count, 0} and
-    items {t_off, a_off, n_chunks (<= 4), a_stride}: consecutive chain elements that are the channel chunks of one
-    path in consecutive waves (LDS offsets LIN2_T_WAVE_FLOATS apart, weight blocks mul_out * 8 apart) become one item."""
-    recs, items = [], []
-    for (cb, cl, d3, n_pairs, out_off, pair_base, magic, _) in slots.tolist():
-        astr = irreps_out_mul_of_off[out_off] * 8
-        first = len(items)
-        ci = 0
-        while ci < cl:
-            t0, a0 = chain[cb + ci].tolist()
-            n = 1
-            while (ci + n < cl and n < 4 and chain[cb + ci + n][0] == t0 + n * LIN2_T_WAVE_FLOATS
-                   and chain[cb + ci + n][1] == a0 + n * astr):
-                n += 1
-            items.append((t0, a0, n, astr))
-            ci += n
-        recs.append((d3, n_pairs, out_off, pair_base, magic, first, len(items) - first, 0))
-    return (np.array(recs, dtype=np.int32).reshape(-1, 8), np.array(items, dtype=np.int32).reshape(-1, 4))
-
-
-def pack_lin2_items(slot_index: np.ndarray, slots: np.ndarray, chain: np.ndarray):
-    """item = {t_off | d3 << 16 | last_of_slot << 20,  a_off,  magic | pair_base << 17,  n_pairs | out_off << 16}"""
-    items, index = [], np.zeros(slot_index.shape, dtype=np.int32)
-    for r in range(slot_index.shape[0]):
-        for w in range(4):
-            b, cnt = slot_index[r, w]
-            first = len(items)
-            for (cb, cl, d3, n_pairs, out_off, pair_base, magic, _) in slots[b:b + cnt].tolist():
-                assert d3 < 16 and magic < (1 << 17) and pair_base < (1 << 14) and n_pairs < 65536 and out_off < 32768
-                for ci in range(cl):
-                    t_off, a_off = chain[cb + ci].tolist()
-                    assert t_off < 65536
-                    items.append((t_off | (d3 << 16) | (int(ci == cl - 1) << 20), a_off, magic | (pair_base << 17),
-                                  n_pairs | (out_off << 16)))
-            index[r, w] = (first, len(items) - first)
-    return np.array(items, dtype=np.int64).astype(np.int32).reshape(-1, 4), index
-
-
-def _div_magic(d: int) -> int:
-    """m with (n * m) >> 16 == n // d for 0 <= n < 4096 (checked)"""
-    m = (1 << 16) // d + 1
-    assert all((n * m) >> 16 == n // d for n in range(4096)), d
-    return m
-
-
-def plan_conv_fused(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[ConvFusedPlan]:
-    """None when the layer has no light entry (the two-kernel path is used as is)."""
-    irreps_out = Irreps(irreps_out).simplify()
-    S = n_species
-    ent = np.asarray(uvu.group_entries).reshape(-1, 32)
-    mid = uvu.irreps_mid
-    # ---- full lin2 = FullyConnectedTensorProduct(irreps_mid.simplify(), Sx0e, irreps_out): where a path's channels sit ----
-    blk_of_slot, uoff_of_slot, blocks = [], [], []   # merged input block per irreps_mid slot
-    for i, (mul, ir) in enumerate(mid):
-        if blocks and blocks[-1][1] == ir:
-            blk_of_slot.append(len(blocks) - 1)
-            uoff_of_slot.append(blocks[-1][0])
-            blocks[-1] = (blocks[-1][0] + mul, ir)
-        else:
-            blk_of_slot.append(len(blocks))
-            uoff_of_slot.append(0)
-            blocks.append((mul, ir))
-    flat_of, fan, flat = {}, {}, 0
-    for ib, (mi, ir) in enumerate(blocks):
-        for io, (mo, iro) in enumerate(irreps_out):
-            if iro == ir:
-                flat_of[(ib, io)] = flat
-                flat += mi * S * mo
-                fan[io] = fan.get(io, 0) + mi * S
-    o_offs = irreps_out.offsets()
-
-    def offs_of_kind(kind):
-        l1, gi = kind // TP_KIND_STRIDE, kind % TP_KIND_STRIDE
-        lo, hi = TP_GROUPS[l1][gi]
-        combos = [(l2, l3) for l2 in range(lo, hi + 1) for l3 in range(abs(l1 - l2), min(4, l1 + l2) + 1)]
-        off, o = [], 0
-        for (_, l3) in combos:
-            off.append(o)
-            o += 2 * l3 + 1
-        return off, o
-
-    def t_offsets(e):
-        """compact LDS offsets (in accumulators) of the PRESENT couplings of entry e, and their total"""
-        off, _ = offs_of_kind(int(ent[e][0]))
-        d3 = off[1:] + [offs_of_kind(int(ent[e][0]))[1]]
-        out, o = {}, 0
-        for c in sorted(uvu.group_entry_paths[e]):
-            out[c] = o
-            o += d3[c] - off[c]
-        return out, o
-
-    light_ids = [e for e in range(len(ent))
-                 if int(ent[e][3]) == 3 and int(ent[e][0]) // TP_KIND_STRIDE <= LIN2_FUSE_LMAX
-                 and 64 * t_offsets(e)[1] <= LIN2_T_WAVE_FLOATS]
-    # Opt-in (MATTEN_CONV_FUSED=1): measured on MI355X the lin2 stage costs more than the agg round trip it removes
-    # (5.58 vs 5.38 ms per 1000-crystal forward, DESIGN.md section 8) -- lin2's weights are per species, i.e. per NODE
-    # in a crystal-ordered batch: 27 KB of weights to apply per node against 12 KB of agg saved.
-    if not light_ids or os.environ.get("MATTEN_CONV_FUSED", "0") != "1":
-        return None
-    light_set = set(light_ids)
-    # a path is handled where its entries are: all chunks of one (input block, l2 group) share lanes-per-node by construction
-    light_paths = {pi for e in light_ids for pi in uvu.group_entry_paths[e].values()}
-    heavy_ids = [e for e in range(len(ent)) if e not in light_set]
-    assert not (light_paths & {pi for e in heavy_ids for pi in uvu.group_entry_paths[e].values()})
-
-    # ---- rounds: kind-homogeneous where possible, like plan.fused_unit_map ----
-    run = sorted(light_ids, key=lambda e: int(ent[e][0]))
-    nblk = -(-len(run) // 4)
-    cuts = [round(k * len(run) / nblk) for k in range(nblk + 1)]
-    rounds = np.full((nblk, 4), -1, dtype=np.int32)
-    pos_in_light = {e: i for i, e in enumerate(light_ids)}
-    for r in range(nblk):
-        for w, e in enumerate(run[cuts[r]:cuts[r + 1]]):
-            rounds[r, w] = pos_in_light[e]
-
-    # ---- species weight table + slots ----
-    a_base: List[np.ndarray] = []
-    a_stride: List[np.ndarray] = []
-    a_scale: List[np.ndarray] = []
-    a_off_of: Dict[Tuple[int, int], int] = {}
-    a_numel = 0
-
-    def a_block(pi: int, u0: int, mul_c: int, io: int) -> int:
-        """float offset of the [mul_out][8] weight block of channels u0..u0+7 of path pi into output irrep io.  The
-        blocks of all 8-channel chunks of a path are allocated together, consecutive (stride mul_out * 8), so that the
-        kernel walks the chunks of one path with a constant stride."""
-        nonlocal a_numel
-        key = (pi, io)
-        pth = uvu.paths[pi]
-        mo = irreps_out[io].mul
-        if key not in a_off_of:
-            a_off_of[key] = a_numel
-            ib = blk_of_slot[pth.slot]
-            for c0 in range(0, pth.mul, 8):
-                ub = uoff_of_slot[pth.slot] + c0
-                v = np.arange(mo)[:, None]
-                u = np.arange(8)[None, :]
-                base = flat_of[(ib, io)] + (ub + u) * S * mo + v          # W[u_full, s=0, v]; + s * mo per species
-                base = np.where(c0 + u < pth.mul, base, -1)
-                a_base.append(base.reshape(-1).astype(np.int64))
-                a_stride.append(np.full(mo * 8, mo, dtype=np.int64))
-                a_scale.append(np.full(mo * 8, fan[io] ** -0.5, dtype=np.float32))
-                a_numel += mo * 8
-        assert u0 % 8 == 0
-        return a_off_of[key] + (u0 // 8) * mo * 8
-
-    slots: List[Tuple[int, ...]] = []
-    chain: List[Tuple[int, int]] = []
-    slot_index = np.zeros((nblk, 4, 2), dtype=np.int32)
-    for r in range(nblk):
-        feeds: Dict[int, List[Tuple[int, int]]] = {}   # io -> [(t_off, a_off)]
-        for w in range(4):
-            if rounds[r, w] < 0:
-                continue
-            e = light_ids[rounds[r, w]]
-            off, _ = t_offsets(e)
-            for c, pi in sorted(uvu.group_entry_paths[e].items()):
-                pth = uvu.paths[pi]
-                ir3 = Irrep(pth.l3, pth.p3)
-                for io, (mo, iro) in enumerate(irreps_out):
-                    if iro == ir3:
-                        feeds.setdefault(io, []).append(
-                            (w * LIN2_T_WAVE_FLOATS + 64 * off[c], a_block(pi, uvu.group_entry_u0[e], int(ent[e][2]), io)))
-        per_wave: List[List[Tuple[int, ...]]] = [[], [], [], []]
-        load = [0, 0, 0, 0]
-        jobs = []
-        for io, lst in feeds.items():
-            cb = len(chain)
-            chain.extend(lst)
-            d3 = irreps_out[io].ir.dim
-            n_pairs = irreps_out[io].mul * d3
-            for pb in range(-(-n_pairs // 8)):
-                jobs.append((len(lst), (cb, len(lst), d3, n_pairs, o_offs[io], 8 * pb, _div_magic(d3), 0)))
-        for cost, rec in sorted(jobs, key=lambda t: (-t[0], t[1])):   # longest chains first, to the least loaded wave
-            w = min(range(4), key=lambda k: (load[k], k))
-            per_wave[w].append(rec)
-            load[w] += cost + 1
-        for w in range(4):
-            slot_index[r, w] = (len(slots), len(per_wave[w]))
-            slots.extend(per_wave[w])
-
-    # ---- heavy entries: compact agg_rest and the restricted lin2 ----
-    heavy_slots = sorted({uvu.paths[pi].slot for e in heavy_ids for pi in uvu.group_entry_paths[e].values()})
-    rest_off, d_rest, rest_irreps, rest_chan = {}, 0, [], []   # rest_chan[block] = full-block channel indices
-    rest_full_blk = []
-    for sl in heavy_slots:
-        mul, ir = mid[sl]
-        rest_off[sl] = d_rest
-        d_rest += mul * ir.dim
-        ch = uoff_of_slot[sl] + np.arange(mul)
-        if rest_irreps and rest_irreps[-1][1] == ir:
-            rest_irreps[-1] = (rest_irreps[-1][0] + mul, ir)
-            rest_chan[-1] = np.concatenate([rest_chan[-1], ch])
-        else:
-            rest_irreps.append((mul, ir))
-            rest_chan.append(ch)
-            rest_full_blk.append(blk_of_slot[sl])
-    heavy_entries = ent[heavy_ids].copy() if heavy_ids else np.zeros((0, 32), dtype=np.int32)
-    for row, e in zip(heavy_entries, heavy_ids):
-        for c, pi in uvu.group_entry_paths[e].items():
-            pth = uvu.paths[pi]
-            row[8 + 12 + c] = rest_off[pth.slot] + uvu.group_entry_u0[e] * (2 * pth.l3 + 1)
-    rest = None
-    if heavy_ids:
-        irr_rest = Irreps(rest_irreps)
-        paths_rest = [(i1, io) for i1, (_, ir1) in enumerate(irr_rest) for io, (_, iro) in enumerate(irreps_out) if iro == ir1]
-        rest = _plan_linear_like(irr_rest, irreps_out, S, paths_rest)
-        g_cols, s_cols = [], []
-        for i1, io in paths_rest:
-            mo = irreps_out[io].mul
-            u = rest_chan[i1][None, :, None]
-            sp = np.arange(S)[:, None, None]
-            w = np.arange(mo)[None, None, :]
-            g_cols.append((flat_of[(rest_full_blk[i1], io)] + (u * S + sp) * mo + w).reshape(S, -1))
-            s_cols.append(np.full(rest_chan[i1].size * mo, fan[io] ** -0.5, dtype=np.float32))
-        rest.gather = np.concatenate(g_cols, axis=1).astype(np.int64)
-        rest.scale = np.concatenate(s_cols)
-        rest.weight_numel = flat
-        assert rest.gather.shape == (S, rest.w_stride) and rest.scale.shape == (rest.w_stride,)
-    light_entries = np.ascontiguousarray(ent[light_ids]).astype(np.int32)
-    for row, e in zip(light_entries, light_ids):   # reserved[c] = accumulator offset of coupling c in the wave's LDS region
-        for c, o in t_offsets(e)[0].items():
-            row[8 + c] = o
-    slots_np = np.array(slots, dtype=np.int32).reshape(-1, 8)
-    chain_np = np.array(chain, dtype=np.int32).reshape(-1, 2)
-    items, item_index = pack_lin2_items(slot_index, slots_np, chain_np)
-    slot_recs, slot_items = merge_lin2_items(slot_index, slots_np, chain_np,
-                                             {o_offs[io]: irreps_out[io].mul for io in range(len(irreps_out))})
-    # LDS of matten_tp_lin2: four wave regions + stage + the 8-node output tile + the work lists; wider layers than a
-    # workgroup can hold take the two-kernel path
-    ld = (irreps_out.dim + 23) // 32 * 32 + 8
-    lds_bytes = 4 * (4 * LIN2_T_WAVE_FLOATS + 2 * 16 * 68 + LIN2_GROUP_NODES * ld + 8 * len(slot_recs) + 4 * len(slot_items))
-    if lds_bytes > 64 * 1024:
-        return None
-    return ConvFusedPlan(
-        items=items, item_index=item_index, slot_recs=slot_recs, slot_items=slot_items,
-        light_entries=light_entries, rounds=rounds, slot_index=slot_index,
-        slots=np.array(slots, dtype=np.int32).reshape(-1, 8), chain=np.array(chain, dtype=np.int32).reshape(-1, 2),
-        a_numel=a_numel, a_base=np.concatenate(a_base), a_stride=np.concatenate(a_stride), a_scale=np.concatenate(a_scale),
-        heavy_entries=np.ascontiguousarray(heavy_entries).astype(np.int32),
-        heavy_unit_map=fused_unit_map(heavy_entries) if heavy_ids else np.zeros(0, dtype=np.int32),
-        d_rest=d_rest, rest=rest, d_out=irreps_out.dim,
-        light_ids=np.array(light_ids, dtype=np.int64), heavy_ids=np.array(heavy_ids, dtype=np.int64),
-    )
 
 
 # ------------------------------------------------------------------------------------------

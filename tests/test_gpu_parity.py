@@ -1060,15 +1060,27 @@ def test_neighbor_list_slabs_match_single_launch(monkeypatch):
         assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), k
 
 
-def test_conv_fused_kernel_matches_two_kernel_path(monkeypatch):
-    """matten_tp_lin2 (tensor product + neighbour sum + lin2 of the light input blocks in one kernel, heavy blocks through
-    the compact agg_rest) against the two-kernel conv (full agg + lin2) and the oracle, layer by layer: mixed species in
-    every 8-node group, a node count that is not a multiple of 8, per-node neighbour normalisation, and an isolated atom."""
+def _tile_switch(monkeypatch, pconv, on: bool):
+    """force the conv-tile path for every layer and batch size, or switch it off (module-level thresholds of nn/conv.py)"""
+    monkeypatch.setattr(pconv, "CONV_TILE_MIN_ROWS", 0 if on else 10**12)
+    monkeypatch.setattr(pconv, "CONV_TILE_MIN_DMID", 0)
+    monkeypatch.setattr(pconv, "AGG_KM_MIN_ROWS", 0)
+
+
+@pytest.mark.parametrize("gate_fuse", [True, False])
+def test_conv_fused_kernel_matches_two_kernel_path(monkeypatch, gate_fuse):
+    """matten_conv_tile (tensor product + neighbour sum + lin2 + self-connection [+ Gate + eval BatchNorm] per 16-node
+    single-species tile, agg never written) against the two-kernel conv (matten_tp_fused -> agg -> matten_agg_linear) and
+    the oracle, layer by layer, all four layers at full width: mixed species (ragged tiles: every (block, species) run is
+    padded to 16), a node count that is not a multiple of 16, per-node neighbour normalisation, an isolated atom, a block
+    size that cuts a crystal in two."""
     from matten_amd.data import synthetic
     from matten_amd.data.graph import collate, crystal_graph
     from matten_amd.nn import conv as pconv
 
     monkeypatch.setattr(pconv, "DEAD_PATH_ELIMINATION", False)   # all four layers at their full width
+    monkeypatch.setattr(pconv, "GATE_FUSE", gate_fuse)
+    monkeypatch.setattr(pconv, "CONV_TILE_BLOCK", 48)            # three tiles' worth of nodes per block: crystals straddle blocks
     lone = crystal_graph(np.array([[0.0, 0, 0], [1.5, 0, 0], [6.0, 6.0, 6.0]]), 12.0 * np.eye(3), [29, 79, 29], 5.0)
     lone_pair = crystal_graph(np.array([[0.0, 0, 0], [1.5, 0, 0], [2.5, 1.0, 0]]), 12.0 * np.eye(3), [29, 79, 29], 5.0)
     for avg in (18.0, None):
@@ -1077,25 +1089,49 @@ def test_conv_fused_kernel_matches_two_kernel_path(monkeypatch):
         graphs = synthetic.fcc64_graphs(2) + ([lone] if avg else [lone_pair])
         ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": avg}
         hp = dict(PAPER, average_num_neighbors="auto" if avg else None)
-        monkeypatch.setenv("MATTEN_CONV_FUSED", "1")   # opt-in variant (plan.plan_conv_fused)
-        ref, fused = build_pair(hp, ds, randomize_bn=True)
-        monkeypatch.delenv("MATTEN_CONV_FUSED")
-        _, plain = build_pair(hp, ds, randomize_bn=True)
-        convs = [m for m in fused.backbone.modules() if type(m).__name__ == "PointConv"]
-        assert all(m.fused_plan is not None for m in convs) and len(convs) == 4
-        assert all(m.fused_plan is None for m in plain.backbone.modules() if type(m).__name__ == "PointConv")
-        plain.load_state_dict(fused.state_dict())
-        cpu, a, b = collate(graphs), collate(graphs, device=DEV), collate(graphs, device=DEV)
-        with torch.no_grad():
-            for (name, rmod), (_, fmod), (_, pmod) in zip(ref.backbone.named_children(), fused.backbone.named_children(),
-                                                          plain.backbone.named_children()):
-                cpu, a, b = rmod(cpu), fmod(a), pmod(b)
-                if "node_features" in cpu:
-                    close(a["node_features"], b["node_features"], 2e-5, f"{name}: fused vs two-kernel")
-                    close(a["node_features"], cpu["node_features"], RTOL, f"{name}: fused vs oracle")
-            # run twice: the accumulation order is fixed
-            again = fused.backbone(collate(graphs, device=DEV))["my_model_output"]
-            assert torch.equal(again, a["my_model_output"])
+        ref, model = build_pair(hp, ds, randomize_bn=True)
+        convs = [m for m in model.backbone.modules() if type(m).__name__ == "PointConv"]
+        assert all(m.tile_plan is not None for m in convs) and len(convs) == 4
+        outs = {}
+        for on in (True, False):
+            _tile_switch(monkeypatch, pconv, on)
+            cpu, dev = collate(graphs), collate(graphs, device=DEV)
+            feats = {}
+            with torch.no_grad():
+                for (name, rmod), (_, pmod) in zip(ref.backbone.named_children(), model.backbone.named_children()):
+                    cpu, dev = rmod(cpu), pmod(dev)
+                    if "node_features" in cpu:
+                        feats[name] = dev["node_features"].clone()
+                        close(dev["node_features"], cpu["node_features"], RTOL, f"{name}: tile={on} vs oracle")
+                # run twice: the accumulation order is fixed
+                again = model.backbone(collate(graphs, device=DEV))["my_model_output"]
+                assert torch.equal(again, dev["my_model_output"])
+            outs[on] = feats
+        for name in outs[True]:
+            close(outs[True][name], outs[False][name], 2e-5, f"{name}: conv-tile vs two-kernel")
+
+
+def test_conv_tile_kernel_at_the_bench_batch(monkeypatch):
+    """the same comparison on the 1000-crystal fcc-64 batch of BASELINE configs[2] (64 000 nodes, 1.15 M edges; default
+    block size, Gate + BatchNorm inside the kernel, dead-output view of the last layer): conv-tile vs two-kernel model
+    output per irrep block, and a crystal's prediction does not depend on what else is in the batch (bitwise: the tiles
+    it lands in change with the batch, its arithmetic does not)."""
+    from matten_amd.data.graph import collate
+    from matten_amd.nn import conv as pconv
+
+    graphs, ds = _fcc(1000)
+    _, model = build_pair(PAPER, ds, randomize_bn=True)
+    batch = collate(graphs, device=DEV)
+    small = collate(graphs[37:187], device=DEV)
+    monkeypatch.setattr(pconv, "CONV_TILE_MIN_ROWS", 8192)
+    with torch.no_grad():
+        tiled = model(dict(batch))[0]["elastic_tensor_full"].clone()
+        tiled_small = model(dict(small))[0]["elastic_tensor_full"].clone()
+        monkeypatch.setattr(pconv, "CONV_TILE_MIN_ROWS", 10**12)
+        plain = model(dict(batch))[0]["elastic_tensor_full"].clone()
+    assert torch.isfinite(tiled).all()
+    close_blocks(tiled, plain.cpu(), rtol=5e-6, floor=2e-6, what="conv-tile vs two-kernel, 1000 crystals")
+    assert torch.equal(tiled[37:187], tiled_small), "a crystal's rows depend on the rest of the batch"
 
 
 def test_debug_mode_catches_nan_on_device():

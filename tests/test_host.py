@@ -406,130 +406,86 @@ def test_unsupported_configs_fail_up_front_with_the_full_list():
         validate_hparams(PAPER, {"average_num_neighbors": 18.0})
 
 
-def _emulate_conv_fused(uvu, cf, lin2_w, S, agg, species, add):
-    """numpy walk through the tables of plan.plan_conv_fused exactly as matten_tp_lin2 reads them (LDS T area, slots,
-    chains, species weight table) + the restricted lin2 on the compact agg_rest.  agg: the FULL [N, d_mid] layout."""
+@pytest.mark.parametrize("case", ["paper_last", "paper_l2", "paper_l1", "paper_l0", "view", "ragged"])
+def test_conv_tile_plan_reproduces_lin2(case):
+    """plan_conv.plan_conv_tile turns lin2(agg) + add of a conv layer (reference nn/conv.py:77-79,123:
+    FullyConnectedTensorProduct(irreps_mid.simplify(), Sx0e, out)) into rounds / passes / units / pieces over the LDS dump
+    of matten_conv_tile; ``plan_conv.emulate_lin2`` walks those tables exactly as the kernel does.  Checked against the
+    dense contraction of the whole lin2 on the reference's mul_ir rows, plus the structural contracts the kernel relies
+    on: every entry in exactly one round slot, every (entry, coupling) consumed exactly once, passes within the dump,
+    weight columns of the entries a permutation of the reference's."""
     from matten_amd import plan as mplan
-
-    N = agg.shape[0]
-    out = add.copy()
-    ent_full = np.asarray(uvu.group_entries).reshape(-1, 32)
-    TW = mplan.LIN2_T_WAVE_FLOATS
-    # species weight table
-    atab = np.zeros((S, cf.a_numel))
-    ok = cf.a_base >= 0
-    for s in range(S):
-        atab[s, ok] = lin2_w[cf.a_base[ok] + s * cf.a_stride[ok]] * cf.a_scale[ok]
-    # which full entry is light entry i (same record up to the reserved words)
-    full_of_light = [next(e for e in range(len(ent_full)) if (ent_full[e][:8] == row[:8]).all()
-                          and (ent_full[e][20:] == row[20:]).all()) for row in cf.light_entries]
-    for g0 in range(0, N, 8):
-        nodes = list(range(g0, min(N, g0 + 8)))
-        tile = np.zeros((8, cf.d_out))
-        for j, n in enumerate(nodes):
-            tile[j] = out[n]
-        for r in range(cf.rounds.shape[0]):
-            T = np.full(4 * TW + 64, np.nan)   # NaN: anything read that was never written shows up
-            for w in range(4):
-                li = cf.rounds[r, w]
-                if li < 0:
-                    continue
-                row = cf.light_entries[li]
-                e = full_of_light[li]
-                for c, pi in uvu.group_entry_paths[e].items():
-                    pth = uvu.paths[pi]
-                    d3 = 2 * pth.l3 + 1
-                    for j in range(8):
-                        for u in range(8):
-                            for k in range(d3):
-                                val = 0.0
-                                if j < len(nodes) and u < row[2]:
-                                    val = agg[nodes[j], row[20 + c] + u * d3 + k]
-                                T[w * TW + 64 * row[8 + c] + (j * d3 + k) * 8 + u] = val
-            for w in range(4):
-                b, cnt = cf.slot_index[r, w]
-                # the kernel's form of the slots: merged items {t_off, a_off, n_chunks, a_stride}
-                for (d3, n_pairs, out_off, pair_base, magic, ib, ni, _) in cf.slot_recs[b:b + cnt]:
-                    for j, n in enumerate(nodes):
-                        for q in range(8):
-                            idx = pair_base + q
-                            if idx >= n_pairs:
-                                continue
-                            v = (idx * magic) >> 16
-                            k = idx - v * d3
-                            acc = 0.0
-                            for (t_off, a_off, nch, astr) in cf.slot_items[ib:ib + ni]:
-                                for c in range(nch):
-                                    for u in range(8):
-                                        acc += (atab[species[n], a_off + c * astr + v * 8 + u]
-                                                * T[t_off + c * TW + (j * d3 + k) * 8 + u])
-                            tile[j, out_off + idx] += acc
-        for j, n in enumerate(nodes):
-            out[n] = tile[j]
-    if cf.rest is not None:
-        # agg_rest: what the heavy entries write (remapped out_off), gathered from the full layout
-        heavy_full = [e for e in range(len(ent_full)) if e not in set(full_of_light)]
-        rest = np.zeros((N, cf.d_rest))
-        for row, e in zip(cf.heavy_entries, heavy_full):
-            for c, pi in uvu.group_entry_paths[e].items():
-                d3 = 2 * uvu.paths[pi].l3 + 1
-                rest[:, row[20 + c]: row[20 + c] + row[2] * d3] = agg[:, ent_full[e][20 + c]: ent_full[e][20 + c] + row[2] * d3]
-        wp = lin2_w[cf.rest.gather] * cf.rest.scale
-        for p in cf.rest.passes:
-            for (xo, d, mi, wo, mo, oo, _, _) in p.tolist():
-                W = wp[species][:, wo:wo + mi * mo].reshape(N, mi, mo)
-                X = rest[:, xo:xo + mi * d].reshape(N, mi, d)
-                out[:, oo:oo + mo * d] += np.einsum("nuv,num->nvm", W, X).reshape(N, mo * d)
-    return out
-
-
-@pytest.mark.parametrize("case", ["paper_last", "paper_l1", "paper_l0", "ragged"])
-def test_conv_fused_plan_reproduces_lin2(case):
-    """plan.plan_conv_fused splits lin2(agg) + add into (light blocks: LDS slots / chains / species weight table) +
-    (heavy blocks: compact agg_rest, restricted lin2 indexing the FULL flat weight): emulated on the host against the
-    dense contraction of the whole lin2 = FullyConnectedTensorProduct(irreps_mid.simplify(), Sx0e, out)
-    (reference nn/conv.py:77-79,123)."""
-    from matten_amd import plan as mplan
+    from matten_amd import plan_conv as pc
 
     sh = "0e+1o+2e+3o+4e"
     full = "32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e"
     cases = {
         "paper_last": (full, sh, full, 3),
+        "paper_l2": ("32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e", sh, "32x0o+78x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e", 3),
         "paper_l1": ("32x0e+16x1o+4x2e+2x3o+2x4e", sh, "78x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e", 4),
         "paper_l0": ("16x0e", sh, "56x0e+16x1o+4x2e+2x3o+2x4e", 2),
-        # 20 channels: chunks 8, 8, 4 (the last one padded to 8 lanes); 11x1o: 8 + 3; an odd output multiplicity
-        "ragged": ("20x0e+11x1o+3x2e", "0e+1o+2e", "7x0e+5x1o+3x1e+2x2e", 3),
+        "view": (full, sh, "32x0e+4x2e+2x4e", 3),
+        # 20 channels: chunks 8, 8, 4; 11x1o: 8 + 3 (an idle lane); odd output multiplicities; a lone 2-channel block
+        "ragged": ("20x0e+11x1o+3x2e+2x3o", "0e+1o+2e", "7x0e+5x1o+3x1e+2x2e+17x2o+1x3o", 3),
     }
     i1, ish, tgt, S = cases[case]
     uvu = mplan.plan_uvu(i1, ish, tgt)
-    os.environ["MATTEN_CONV_FUSED"] = "1"
-    try:
-        cf = mplan.plan_conv_fused(uvu, S, tgt)
-    finally:
-        del os.environ["MATTEN_CONV_FUSED"]
-    assert cf is not None
+    tp = pc.plan_conv_tile(uvu, S, tgt)
+    assert tp is not None
     lin2 = mplan.plan_fctp(uvu.irreps_mid.simplify(), S, tgt)
     rng = np.random.default_rng(11)
-    N = 13   # two groups of 8, the second ragged
-    agg = rng.standard_normal((N, uvu.d_mid))
-    species = rng.integers(0, S, N)
-    add = rng.standard_normal((N, lin2.d_out))
+    agg = rng.standard_normal((pc.TILE_NODES, uvu.d_mid))          # one tile, the reference's mul_ir row per node
+    add = rng.standard_normal((pc.TILE_NODES, lin2.d_out))
     w = rng.standard_normal(lin2.weight_numel)
+    sp = 1
     want = add.copy()
-    wp = w[lin2.gather] * lin2.scale
+    wp = w[lin2.gather[sp]] * lin2.scale
     for p in lin2.passes:
         for (xo, d, mi, wo, mo, oo, _, _) in p.tolist():
-            W = wp[species][:, wo:wo + mi * mo].reshape(N, mi, mo)
-            X = agg[:, xo:xo + mi * d].reshape(N, mi, d)
-            want[:, oo:oo + mo * d] += np.einsum("nuv,num->nvm", W, X).reshape(N, mo * d)
-    got = _emulate_conv_fused(uvu, cf, w, S, agg, species, add)
+            W = wp[wo:wo + mi * mo].reshape(mi, mo)
+            X = agg[:, xo:xo + mi * d].reshape(-1, mi, d)
+            want[:, oo:oo + mo * d] += np.einsum("uv,num->nvm", W, X).reshape(-1, mo * d)
+    # the walk's accumulators of an entry, from the mul_ir row: acc[node, lane channel, OFF[c] + k]
+    halves = {}
+    rows = tp.entries
+    col_seen = []
+
+    def acc_of_entry(e):
+        kind = int(rows[e][0])
+        l1, gi = kind // mplan.TP_KIND_STRIDE, kind % mplan.TP_KIND_STRIDE
+        combos = pc.kind_combos(l1, gi)
+        cu, mul, w_base = 1 << int(rows[e][3]), int(rows[e][2]), int(rows[e][5])
+        nacc = sum(2 * l3 + 1 for _, l3 in combos)
+        acc = np.zeros((pc.TILE_NODES, cu, nacc))
+        off = 0
+        for c, (l2, l3) in enumerate(combos):
+            d3 = 2 * l3 + 1
+            for uu in range(mul):
+                col = int(tp.fused_cols[w_base + uu * len(combos) + c])   # reference weight column of (channel, coupling)
+                if col >= 0:
+                    pth = next(q for q in uvu.paths if q.w_off <= col < q.w_off + q.mul)
+                    assert (pth.l1, pth.l2, pth.l3) == (l1, l2, l3) and (int(rows[e][4]) >> c) & 1
+                    uch = col - pth.w_off
+                    acc[:, uu, off:off + d3] = agg[:, pth.out_off + uch * d3: pth.out_off + (uch + 1) * d3]
+            off += d3
+        return acc
+
+    got = pc.emulate_lin2(tp, uvu, w, sp, acc_of_entry, add)
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
-    # every light + heavy entry is used exactly once; LDS regions fit
-    assert len(cf.light_entries) + len(cf.heavy_entries) == len(uvu.group_entries)
-    assert sorted(x for x in cf.rounds.reshape(-1) if x >= 0) == list(range(len(cf.light_entries)))
-    assert (cf.chain[:, 0] >= 0).all() and (cf.chain[:, 0] < 4 * mplan.LIN2_T_WAVE_FLOATS).all()
-    assert (cf.chain[:, 1] >= 0).all() and (cf.chain[:, 1] < cf.a_numel).all()
+    # structure
+    used = sorted(int(e) for q in tp.quads for e in q[:4] if e >= 0)
+    assert used == list(range(len(rows)))
+    cols = np.sort(tp.fused_cols[tp.fused_cols >= 0])
+    assert (cols == np.arange(uvu.weight_numel)).all()           # every reference weight column exactly once
+    for q in tp.quads:
+        kinds = [int(rows[e][0]) for e in q[:4] if e >= 0]
+        assert int(q[5]) == max(max(pc.kind_passes(k // mplan.TP_KIND_STRIDE, k % mplan.TP_KIND_STRIDE)) for k in kinds) + 1
+        lanes = {max(2, int(rows[e][3])) for e in q[:4] if e >= 0}
+        assert lanes == {int(q[4])}                               # one chunk shape per round
+    assert (tp.pieces[:, 0] >= 0).all() and (tp.pieces[:, 0] + 9 * pc.DUMP_RS <= 4 * pc.DUMP_REGS * pc.DUMP_RS + 9 * pc.DUMP_RS).all()
+    assert (tp.pieces[:, 1] >= 0).all() and (tp.pieces[:, 1] < tp.a_stride).all()
+    assert tp.lds_bytes <= 64 * 1024 and int(rows[:, 3].max()) <= 4
 
 
 def test_debug_log_level_inserts_anomaly_detectors():
