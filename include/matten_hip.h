@@ -267,9 +267,11 @@ int matten_tp_max_cols_l1(void);   /* ... and of vector (l1 = 1) input blocks */
  *   matten_amd/plan_conv.py plan_conv_tile):
  *   quads[n_quads, 8]     : {e0, e1, e2, e3 (entry per wave, -1 = the wave only feeds the shared stage), class lanes
  *                            per node (log2), passes, node groups of the tile, base index into wave_units}
+ *   rounds[n_rounds, 2]   : {quad, node group} in walking order (rounds that stage the same edge rows adjacent)
  *   wave_units[.., 2]     : {first unit, count} of (quad, pass, wave) at base + 4 pass + wave
  *   units[n_units, 8]     : {output column of (v = 16 mt, k = 0), d3, valid v <= 16, first column tile, column tiles <= 4,
- *                            first piece, pieces, log2(nodes per wave of the round)}; column n of a tile = (node n mod
+ *                            first piece, pieces, log2(nodes per wave of the round) | class lanes per node (log2) << 8};
+ *                            column n of a tile = (node n mod
  *                            npw of the round's group, component n / npw)
  *   pieces[n_pieces, 4]   : {float offset of the piece's first register in the four waves' dump ([wave][28 registers]
  *                            [68 floats]: register r of lane l at r 68 + l), float offset of its A fragment in a species'
@@ -294,7 +296,8 @@ int matten_conv_tile(const float* x, int64_t d_in, const uint16_t* h2s, const fl
                      int64_t n_nodes, const int32_t* entries, int64_t n_entries, int64_t lds_floats_per_wave,
                      const uint16_t* a_split, const float* a_scale_inv, float avg_num_neighbors, const float* num_neigh,
                      const int32_t* tile_nodes, const int32_t* tile_species, int64_t n_slots, int64_t slots_per_block,
-                     const int32_t* quads, int64_t n_quads, const int32_t* wave_units, const int32_t* units,
+                     const int32_t* quads, int64_t n_quads, const int32_t* rounds, int64_t n_rounds,
+                     const int32_t* wave_units, const int32_t* units,
                      const int32_t* pieces, const float* atab, int64_t a_stride, const float* add, int64_t add_ld,
                      int64_t d_out, const int32_t* cmeta, const float* act_cst, const float* bn_scale,
                      const float* bn_shift, int64_t d_act, float* out, int64_t out_ld, matten_stream_t stream);

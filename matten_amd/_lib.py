@@ -53,8 +53,8 @@ SIGNATURES = {
     "matten_species_tiles_slots_per_block": (c_int64, [c_int64, c_int64]),
     "matten_species_tiles": (c_int, [P, c_int64, c_int64, c_int64, P, P, P]),
     "matten_conv_tile": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, P, c_int64, c_int64, P, P, c_float, P,
-                                 P, P, c_int64, c_int64, P, c_int64, P, P, P, P, c_int64, P, c_int64, c_int64, P, P, P, P,
-                                 c_int64, P, c_int64, P]),
+                                 P, P, c_int64, c_int64, P, c_int64, P, c_int64, P, P, P, P, c_int64, P, c_int64, c_int64, P, P, P,
+                                 P, c_int64, P, c_int64, P]),
     "matten_tp_fused": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
     "matten_species_linear": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
     "matten_species_linear_rows": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),

@@ -42,11 +42,22 @@ constexpr int CT_MAX_NT = 4;      // == plan_conv.UNIT_MAX_NT
 #ifndef CT_MIN_BLOCKS
 #define CT_MIN_BLOCKS 3
 #endif
+#if defined(MATTEN_LAB) && defined(CT_ABLATE_NO_LIN2)    // timing build: the lin2 phases compiled out (barriers stay)
+constexpr bool CT_LAB_NO_LIN2 = true;
+#else
+constexpr bool CT_LAB_NO_LIN2 = false;
+#endif
+#if defined(MATTEN_LAB) && defined(CT_ABLATE_NO_DUMP)    // timing build: the accumulators are not parked either
+constexpr bool CT_LAB_NO_DUMP = true;
+#else
+constexpr bool CT_LAB_NO_DUMP = false;
+#endif
 
 struct CArgs {
     const int* tile_nodes;     // [n_slots, 16] node ids, -1 = padding
     const int* tile_species;   // [n_slots] species of the tile, -1 = empty slot
     const int4* quads;         // [n_quads, 2] {e0, e1, e2, e3} {class lanes per node (log2), passes, node groups, wave_units base}
+    const int2* rounds;        // [n_rounds] {quad, node group}: the order the tile walks them (rounds over the same rows adjacent)
     const int2* wave_units;    // [.., 2] {first unit, count} of (quad, pass, wave)
     const int4* units;         // [n_units, 2] {out col of (v = 16 mt, k = 0), d3, valid v, nt0} {n_nt, first piece, n pieces, log2 nodes per wave}
     const int4* pieces;        // [n_pieces] {dump offset, A offset, lanes per node (log2) of the entry, 0}
@@ -57,7 +68,7 @@ struct CArgs {
     const float* act_cst;
     const float* bn_scale;     // [d_act] or NULL
     const float* bn_shift;
-    int n_quads, a_stride, n_slots, slots_per_block, add_ld, out_gld, d_out, d_act, out_ld, walk_floats;
+    int n_rounds, a_stride, n_slots, slots_per_block, add_ld, out_gld, d_out, d_act, out_ld, walk_floats;
 };
 
 // ---- compile-time pass layout of a group kind: couplings in order, a new pass when the next one does not fit ----------
@@ -83,10 +94,9 @@ struct DumpLayout {
 };
 
 struct Lin2Ctx {
-    const CArgs* ca;
     const float* atab_sp;   // the tile's species row of the A table
-    float* dump_all;        // the four waves' dump regions
-    float* otile;           // [16][out_ld]
+    float* dump_all;        // the four waves' dump regions (LDS)
+    float* otile;           // [16][out_ld] (LDS)
     int wu_base, n_pass, r;
 };
 
@@ -101,9 +111,65 @@ __device__ __forceinline__ float ct_act(int code, float v) {
     }
 }
 
+// One unit's pieces with KSV = channels per lane group and contraction step (4 / 2 / 1 for 16 / 8 / <= 4 lanes per node).
+// The A fragments of up to CT_A_BATCH pieces are requested together (one coalesced load each, L2-resident table): a
+// piece's matrix steps are far shorter than a load's latency, one load at a time would be the whole phase.
+constexpr int CT_A_BATCH = 6;
+template <int KSV>
+__device__ __forceinline__ void lin2_unit_pieces(const CArgs& ca, const Lin2Ctx& cx, int p_beg, int p_cnt, int n_nt,
+                                                 const int* __restrict__ boff, const int* __restrict__ jn, f32x4* __restrict__ D) {
+    const int lane = threadIdx.x & 63;
+    for (int p0 = p_beg; p0 < p_beg + p_cnt; p0 += CT_A_BATCH) {
+        const int nb = min(CT_A_BATCH, p_beg + p_cnt - p0);
+        float av[CT_A_BATCH][KSV];
+        int doff[CT_A_BATCH], cul[CT_A_BATCH];
+#pragma unroll
+        for (int b = 0; b < CT_A_BATCH; ++b) {
+            const int4 pc = ca.pieces[p0 + min(b, nb - 1)];
+            doff[b] = __builtin_amdgcn_readfirstlane(pc.x);
+            cul[b] = __builtin_amdgcn_readfirstlane(pc.z);
+            const float* ap = cx.atab_sp + __builtin_amdgcn_readfirstlane(pc.y) + lane * KSV;
+            if constexpr (KSV == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap);
+                av[b][0] = v[0], av[b][1] = v[1], av[b][2] = v[2], av[b][3] = v[3];
+            } else if constexpr (KSV == 2) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(ap);
+                av[b][0] = v[0], av[b][1] = v[1];
+            } else {
+                av[b][0] = ap[0];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < CT_A_BATCH; ++b) {
+            if (b < nb) {
+                const float* db = cx.dump_all + doff[b];
+#pragma unroll
+                for (int nt = 0; nt < CT_MAX_NT; ++nt) {
+                    if (nt < n_nt) {
+                        // KSV >= 2: the class has one lanes-per-node value (folded into boff); KSV == 1: 4 or 2 lanes
+                        const int o = KSV == 1 ? boff[nt] + (jn[nt] << cul[b]) : boff[nt];
+                        float bv[KSV];
+                        if constexpr (KSV == 4) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(db + o);
+                            bv[0] = v[0], bv[1] = v[1], bv[2] = v[2], bv[3] = v[3];
+                        } else if constexpr (KSV == 2) {
+                            const f32x2 v = *reinterpret_cast<const f32x2*>(db + o);
+                            bv[0] = v[0], bv[1] = v[1];
+                        } else {
+                            bv[0] = db[o];
+                        }
+#pragma unroll
+                        for (int t = 0; t < KSV; ++t) D[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b][t], bv[t], D[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // lin2 of one pass of a round: this wave's units (see the header comment)
-__device__ __noinline__ void lin2_phase(const Lin2Ctx& cx, int pass) {
-    const CArgs& ca = *cx.ca;
+__device__ __forceinline__ void lin2_phase(const CArgs& ca, const Lin2Ctx& cx, int pass) {
+    if constexpr (CT_LAB_NO_LIN2) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
@@ -114,66 +180,34 @@ __device__ __noinline__ void lin2_phase(const Lin2Ctx& cx, int pass) {
         const int col0 = __builtin_amdgcn_readfirstlane(r0.x), d3 = __builtin_amdgcn_readfirstlane(r0.y);
         const int vcount = __builtin_amdgcn_readfirstlane(r0.z), nt0 = __builtin_amdgcn_readfirstlane(r0.w);
         const int n_nt = __builtin_amdgcn_readfirstlane(r1.x), p_beg = __builtin_amdgcn_readfirstlane(r1.y);
-        const int p_cnt = __builtin_amdgcn_readfirstlane(r1.z), npw_log2 = __builtin_amdgcn_readfirstlane(r1.w);
+        const int p_cnt = __builtin_amdgcn_readfirstlane(r1.z);
+        const int npw_log2 = __builtin_amdgcn_readfirstlane(r1.w & 255), class_cu_log2 = __builtin_amdgcn_readfirstlane(r1.w >> 8);
         const int npw = 1 << npw_log2;
         // column of this lane in each of the unit's column tiles: (node j of the round's group, component k)
-        int jn[CT_MAX_NT], kk[CT_MAX_NT];
+        int jn[CT_MAX_NT], kk[CT_MAX_NT], boff[CT_MAX_NT];
+        const int ksv = class_cu_log2 >= 4 ? 4 : class_cu_log2 == 3 ? 2 : 1;
 #pragma unroll
         for (int nt = 0; nt < CT_MAX_NT; ++nt) {
             const int col = (nt0 + min(nt, n_nt - 1)) * 16 + c;
             jn[nt] = col & (npw - 1);
             kk[nt] = col >> npw_log2;
+            // float offset of this lane's B operand inside a piece's dump block (clamped: columns past d3 are discarded)
+            boff[nt] = min(kk[nt], d3 - 1) * CT_DUMP_RS + g * ksv + (ksv > 1 ? (jn[nt] << class_cu_log2) : 0);
         }
         f32x4 D[CT_MAX_NT];
 #pragma unroll
         for (int nt = 0; nt < CT_MAX_NT; ++nt) D[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int pi = p_beg; pi < p_beg + p_cnt; ++pi) {
-            const int4 pc = ca.pieces[pi];
-            const int doff = __builtin_amdgcn_readfirstlane(pc.x), aoff = __builtin_amdgcn_readfirstlane(pc.y);
-            const int cu_log2 = __builtin_amdgcn_readfirstlane(pc.z);
-            const float* ap = cx.atab_sp + aoff;
-            const float* db = cx.dump_all + doff;
-            if (cu_log2 >= 4) {           // 16 lanes per node: 4 contraction steps, lane group g owns channels 4 g .. 4 g + 3
-                const f32x4 av = *reinterpret_cast<const f32x4*>(ap + lane * 4);
-#pragma unroll
-                for (int nt = 0; nt < CT_MAX_NT; ++nt) {
-                    if (nt < n_nt) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(db + min(kk[nt], d3 - 1) * CT_DUMP_RS + jn[nt] * 16 + g * 4);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) D[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], D[nt], 0, 0, 0);
-                    }
-                }
-            } else if (cu_log2 == 3) {    // 8 lanes per node: 2 steps, channels 2 g, 2 g + 1
-                const f32x2 av = *reinterpret_cast<const f32x2*>(ap + lane * 2);
-#pragma unroll
-                for (int nt = 0; nt < CT_MAX_NT; ++nt) {
-                    if (nt < n_nt) {
-                        const f32x2 bv = *reinterpret_cast<const f32x2*>(db + min(kk[nt], d3 - 1) * CT_DUMP_RS + jn[nt] * 8 + g * 2);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) D[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], D[nt], 0, 0, 0);
-                    }
-                }
-            } else {                      // 4 or 2 lanes per node: one step, channel g (two lanes: g >= 2 meets zero weights)
-                const float av = ap[lane];
-#pragma unroll
-                for (int nt = 0; nt < CT_MAX_NT; ++nt) {
-                    if (nt < n_nt) {
-                        const float bv = db[min(kk[nt], d3 - 1) * CT_DUMP_RS + (jn[nt] << cu_log2) + g];
-                        D[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, D[nt], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        if (ksv == 4) lin2_unit_pieces<4>(ca, cx, p_beg, p_cnt, n_nt, boff, jn, D);
+        else if (ksv == 2) lin2_unit_pieces<2>(ca, cx, p_beg, p_cnt, n_nt, boff, jn, D);
+        else lin2_unit_pieces<1>(ca, cx, p_beg, p_cnt, n_nt, boff, jn, D);
         // D[nt][i] = out channel 4 g + i of column (jn, kk): add to the tile's rows (this wave owns these columns in this pass)
 #pragma unroll
         for (int nt = 0; nt < CT_MAX_NT; ++nt) {
             if (nt < n_nt && kk[nt] < d3) {
-                float* op = cx.otile + (cx.r * npw + jn[nt]) * ca.out_ld + col0 + kk[nt];
+                float* op = cx.otile + (cx.r * npw + jn[nt]) * ca.out_ld + col0 + kk[nt] + 4 * g * d3;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int v = 4 * g + i;
-                    if (v < vcount) op[v * d3] += D[nt][i];
-                }
+                for (int i = 0; i < 4; ++i)
+                    if (4 * g + i < vcount) op[i * d3] += D[nt][i];
             }
         }
     }
@@ -182,6 +216,7 @@ __device__ __noinline__ void lin2_phase(const Lin2Ctx& cx, int pass) {
 // what a wave does with its neighbour sums: park them for lin2, pass by pass
 struct StoreDump {
     float* dump;            // this wave's region [CT_DUMP_REGS][CT_DUMP_RS]
+    const CArgs* ca;
     const Lin2Ctx* cx;
     template <class G>
     __device__ __forceinline__ void store(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
@@ -190,11 +225,11 @@ struct StoreDump {
         const int lane = threadIdx.x & 63;
         float norm = 0.0f;   // idle channel lanes and padding nodes park zeros: the matrix products read every lane
         if (valid) norm = a_scale_inv / sqrtf(a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node]);
-#pragma unroll
-        for (int p = 0; p < L.n_pass; ++p) {
+        // the round's pass count (a round mate may have more passes than this kind: its pieces may be this wave's units)
+        for (int p = 0; p < cx->n_pass; ++p) {
 #pragma unroll
             for (int cc = 0; cc < G::NC; ++cc) {
-                if (L.pass[cc] == p && ((ge.mask >> cc) & 1u)) {
+                if (L.pass[cc] == p && ((ge.mask >> cc) & 1u) && (!CT_LAB_NO_DUMP || acc[0] == 12345.678f)) {      // wave-uniform
                     const int d3 = 2 * G::L3[cc] + 1;
 #pragma unroll
                     for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
@@ -202,19 +237,14 @@ struct StoreDump {
                 }
             }
             __syncthreads();          // every wave's sums of this pass are parked
-            lin2_phase(*cx, p);
+            lin2_phase(*ca, *cx, p);
             __syncthreads();          // ... and consumed: the next pass / the next round's walk may overwrite them
-        }
-        for (int p = L.n_pass; p < cx->n_pass; ++p) {   // a round mate has more passes: its pieces may be this wave's units
-            __syncthreads();
-            lin2_phase(*cx, p);
-            __syncthreads();
         }
     }
 };
 
 #define CT_RGS(L1, GI, TD) \
-    run_group_shared<L1, GI, 1, TD, false, 0u>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreDump{dump, &cx})
+    run_group_shared<L1, GI, 1, TD, false, 0u>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreDump{dump, &ca, &cx})
 #define CT_GROUP_CASE(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): \
         if (TwoDeepOk<L1, GI>::value && nodes_per_wave <= 8 && nodes_per_wave >= 2) CT_RGS(L1, GI, (TwoDeepOk<L1, GI>::value)); \
@@ -242,81 +272,79 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, CT_MIN_BLOCKS) void conv_tile
     int* nid = reinterpret_cast<int*>(otile + CT_NODES * ca.out_ld);
     if (threadIdx.x < CT_NODES) nid[threadIdx.x] = ca.tile_nodes[slot * CT_NODES + threadIdx.x];
     __syncthreads();
-    for (int i = threadIdx.x; i < CT_NODES * ca.d_out; i += WAVES_PER_BLOCK * 64) {
-        const int row = i / ca.d_out, col = i - row * ca.d_out;
+    for (int row = wave; row < CT_NODES; row += WAVES_PER_BLOCK) {      // a wave per row, lanes along the columns
         const int n = nid[row];
-        otile[row * ca.out_ld + col] = (ca.add && n >= 0) ? ca.add[(int64_t)n * ca.add_ld + col] : 0.0f;
+        const float* arow = (ca.add && n >= 0) ? ca.add + (int64_t)n * ca.add_ld : nullptr;
+        for (int col = lane; col < ca.d_out; col += 64) otile[row * ca.out_ld + col] = arow ? arow[col] : 0.0f;
     }
-    Lin2Ctx cx{&ca, ca.atab + (int64_t)sp * ca.a_stride, lds, otile, 0, 0, 0};
+    Lin2Ctx cx{ca.atab + (int64_t)sp * ca.a_stride, lds, otile, 0, 0, 0};
     __syncthreads();
 
-    for (int qi = 0; qi < ca.n_quads; ++qi) {
+    for (int ri = 0; ri < ca.n_rounds; ++ri) {
+        const int2 rd = ca.rounds[ri];
+        const int qi = __builtin_amdgcn_readfirstlane(rd.x), r = __builtin_amdgcn_readfirstlane(rd.y);
         const int4 q0 = ca.quads[2 * qi], q1 = ca.quads[2 * qi + 1];
         const int e = __builtin_amdgcn_readfirstlane(wave == 0 ? q0.x : wave == 1 ? q0.y : wave == 2 ? q0.z : q0.w);
         const int class_cu_log2 = __builtin_amdgcn_readfirstlane(q1.x);
-        const int n_groups = __builtin_amdgcn_readfirstlane(q1.z);
         cx.n_pass = __builtin_amdgcn_readfirstlane(q1.y);
         cx.wu_base = __builtin_amdgcn_readfirstlane(q1.w);
-        for (int r = 0; r < n_groups; ++r) {
-            cx.r = r;
-            // a loader-only wave takes the geometry of the class (its rows are the class's rows)
-            const int cu_log2 = e >= 0 ? entries[e].cu_log2 : class_cu_log2;
-            const int cu = 1 << cu_log2;
-            const int nodes_per_wave = 64 >> cu_log2;
-            const int g_in_tile = r * nodes_per_wave + (lane >> cu_log2);
-            const int u = lane & (cu - 1);
-            const int node = g_in_tile < CT_NODES ? nid[g_in_tile] : -1;
-            const bool in_range = node >= 0;
-            int beg = 0, deg = 0;
-            if (in_range) {
-                beg = a.rowptr[node];
-                deg = a.rowptr[node + 1] - beg;
-            }
-            int maxdeg = deg;
+        cx.r = r;
+        // a loader-only wave takes the geometry of the class (its rows are the class's rows)
+        const int cu_log2 = e >= 0 ? entries[e].cu_log2 : class_cu_log2;
+        const int cu = 1 << cu_log2;
+        const int nodes_per_wave = 64 >> cu_log2;
+        const int g_in_tile = r * nodes_per_wave + (lane >> cu_log2);
+        const int u = lane & (cu - 1);
+        const int node = g_in_tile < CT_NODES ? nid[g_in_tile] : -1;
+        const bool in_range = node >= 0;
+        int beg = 0, deg = 0;
+        if (in_range) {
+            beg = a.rowptr[node];
+            deg = a.rowptr[node + 1] - beg;
+        }
+        int maxdeg = deg;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
-            if (e < 0) {
-                run_loader_only_t<1>(a, cu_log2, stage, beg, deg, maxdeg);
-                for (int p = 0; p < cx.n_pass; ++p) {
-                    __syncthreads();
-                    lin2_phase(cx, p);
-                    __syncthreads();
-                }
-            } else {
-                const GroupEntry& ge = entries[e];
-                const bool valid = in_range && (u < ge.mul);
-                switch (ge.kind) {
-                    MATTEN_FOR_EACH_GROUP(CT_GROUP_CASE)
-                    default: break;
-                }
+        for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+        if (e < 0) {
+            run_loader_only_t<1>(a, cu_log2, stage, beg, deg, maxdeg);
+            for (int p = 0; p < cx.n_pass; ++p) {
+                __syncthreads();
+                lin2_phase(ca, cx, p);
+                __syncthreads();
+            }
+        } else {
+            const GroupEntry& ge = entries[e];
+            const bool valid = in_range && (u < ge.mul);
+            switch (ge.kind) {
+                MATTEN_FOR_EACH_GROUP(CT_GROUP_CASE)
+                default: break;
             }
         }
     }
-    // the rows leave: plain lin2 output, or Gate (+ eval BatchNorm) applied on the way
-    if (ca.cmeta) {
-        for (int i = threadIdx.x; i < CT_NODES * ca.d_act; i += WAVES_PER_BLOCK * 64) {
-            const int row = i / ca.d_act, col = i - row * ca.d_act;
-            const int n = nid[row];
-            if (n < 0) continue;
-            const int4 m = ca.cmeta[col];
-            const float* orow = otile + row * ca.out_ld;
-            const int act = m.z & 255, gact = (m.z >> 8) & 255;
-            float v = orow[m.x];
-            if (m.y < 0) {
-                if (act) v = ct_act(act, v) * ca.act_cst[act];
-            } else {
-                float gv = orow[m.y];
-                if (gact) gv = ct_act(gact, gv) * ca.act_cst[gact];
-                v *= gv;
+    // the rows leave: plain lin2 output, or Gate (+ eval BatchNorm) applied on the way.  A wave per row, lanes along the
+    // columns: whole 256-byte runs per store instruction
+    for (int row = wave; row < CT_NODES; row += WAVES_PER_BLOCK) {
+        const int n = nid[row];
+        if (n < 0) continue;
+        const float* orow = otile + row * ca.out_ld;
+        float* grow = ca.out + (int64_t)n * ca.out_gld;
+        if (ca.cmeta) {
+            for (int col = lane; col < ca.d_act; col += 64) {
+                const int4 m = ca.cmeta[col];
+                const int act = m.z & 255, gact = (m.z >> 8) & 255;
+                float v = orow[m.x];
+                if (m.y < 0) {
+                    if (act) v = ct_act(act, v) * ca.act_cst[act];
+                } else {
+                    float gv = orow[m.y];
+                    if (gact) gv = ct_act(gact, gv) * ca.act_cst[gact];
+                    v *= gv;
+                }
+                if (ca.bn_scale) v = fmaf(v, ca.bn_scale[col], ca.bn_shift[col]);
+                grow[col] = v;
             }
-            if (ca.bn_scale) v = fmaf(v, ca.bn_scale[col], ca.bn_shift[col]);
-            ca.out[(int64_t)n * ca.out_gld + col] = v;
-        }
-    } else {
-        for (int i = threadIdx.x; i < CT_NODES * ca.d_out; i += WAVES_PER_BLOCK * 64) {
-            const int row = i / ca.d_out, col = i - row * ca.d_out;
-            const int n = nid[row];
-            if (n >= 0) ca.out[(int64_t)n * ca.out_gld + col] = otile[row * ca.out_ld + col];
+        } else {
+            for (int col = lane; col < ca.d_out; col += 64) grow[col] = orow[col];
         }
     }
 }
@@ -389,7 +417,8 @@ extern "C" int matten_conv_tile(const float* x, int64_t d_in, const uint16_t* h2
                                 int64_t lds_floats_per_wave, const uint16_t* a_split, const float* a_scale_inv,
                                 float avg_num_neighbors, const float* num_neigh, const int32_t* tile_nodes,
                                 const int32_t* tile_species, int64_t n_slots, int64_t slots_per_block,
-                                const int32_t* quads, int64_t n_quads, const int32_t* wave_units, const int32_t* units,
+                                const int32_t* quads, int64_t n_quads, const int32_t* rounds, int64_t n_rounds,
+                                const int32_t* wave_units, const int32_t* units,
                                 const int32_t* pieces, const float* atab, int64_t a_stride, const float* add,
                                 int64_t add_ld, int64_t d_out, const int32_t* cmeta, const float* act_cst,
                                 const float* bn_scale, const float* bn_shift, int64_t d_act, float* out, int64_t out_ld,
@@ -397,11 +426,12 @@ extern "C" int matten_conv_tile(const float* x, int64_t d_in, const uint16_t* h2
     hipStream_t stream = (hipStream_t)stream_;
     if (n_nodes < 0 || d_in <= 0 || w_pad <= 0 || sh_stride < 32 || (sh_stride & 3) || n_entries <= 0 ||
         lds_floats_per_wave <= 0 || (lds_floats_per_wave & 3) || n_slots < 0 || slots_per_block <= 0 || n_quads <= 0 ||
+        n_rounds <= 0 ||
         a_stride <= 0 || (a_stride & 3) || d_out <= 0 || out_ld <= 0)
         return MATTEN_EINVAL;
     if (n_nodes == 0 || n_slots == 0) return MATTEN_OK;
     if (!x || !h2s || !w2p || !sh_sorted || !rowptr || !src_sorted || !entries || !a_split || !a_scale_inv || !tile_nodes ||
-        !tile_species || !quads || !wave_units || !units || !pieces || !atab || !out)
+        !tile_species || !quads || !rounds || !wave_units || !units || !pieces || !atab || !out)
         return MATTEN_EINVAL;
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
     if (add && add_ld < d_out) return MATTEN_EINVAL;
@@ -416,8 +446,9 @@ extern "C" int matten_conv_tile(const float* x, int64_t d_in, const uint16_t* h2
     if (lds > 64 * 1024) return MATTEN_EINVAL;
     Args a{x, (const _Float16*)h2s, w2p, (const _Float16*)a_split, a_scale_inv, sh_sorted, rowptr, src_sorted, num_neigh,
            nullptr, (int)d_in, (int)w_pad, (int)sh_stride, 0, (int)n_nodes, (int)lds_floats_per_wave, avg_num_neighbors};
-    CArgs ca{tile_nodes, tile_species, (const int4*)quads, (const int2*)wave_units, (const int4*)units, (const int4*)pieces,
-             atab, add, out, (const int4*)cmeta, act_cst, bn_scale, bn_shift, (int)n_quads, (int)a_stride, (int)n_slots,
+    CArgs ca{tile_nodes, tile_species, (const int4*)quads, (const int2*)rounds, (const int2*)wave_units, (const int4*)units,
+             (const int4*)pieces, atab, add, out, (const int4*)cmeta, act_cst, bn_scale, bn_shift, (int)n_rounds, (int)a_stride,
+             (int)n_slots,
              (int)slots_per_block, (int)add_ld, (int)out_ld, (int)d_out, (int)d_act, lds_out_ld, (int)walk_floats};
     const int64_t n_blocks = matten_cdiv(n_slots, slots_per_block);
     const int64_t grid = matten_cdiv(n_blocks, N_XCD) * N_XCD * slots_per_block;

@@ -83,7 +83,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
             tpl = _plan_conv.plan_conv_tile(self.tp.plan, n_species, conv_layer_irreps)
             if tpl is not None:
                 self.tile_plan = tpl
-                self._tile_tables = DeviceTables(entries=tpl.entries, quads=tpl.quads, wave_units=tpl.wave_units,
+                self._tile_tables = DeviceTables(entries=tpl.entries, quads=tpl.quads, rounds=tpl.rounds, wave_units=tpl.wave_units,
                                                  units=tpl.units, pieces=tpl.pieces, gather=tpl.gather, scale=tpl.scale,
                                                  cols=tpl.fused_cols)
                 self._tile_atab = DerivedWeight(self._pack_tile_atab)
@@ -166,7 +166,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
             data[TILES_KEY] = tiles
         return ops.conv_tile(x1, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
                              t.get("entries", dev), tpl.lds_floats_per_wave, (frag, scale_inv), avg, num_neigh, tiles[:3],
-                             t.get("quads", dev), t.get("wave_units", dev), t.get("units", dev), t.get("pieces", dev),
+                             t.get("quads", dev), t.get("rounds", dev), t.get("wave_units", dev), t.get("units", dev), t.get("pieces", dev),
                              self._tile_atab.get(self.lin2.weight), self_connection, tpl.d_out, gate=gate)
 
     # ---- dead-output elimination (inference) ------------------------------------------------------------------------

@@ -73,6 +73,8 @@ class ConvTilePlan:
     a_tiles: int               # 16-column tiles of all entries (pre-split A operand of the radial layer)
     lds_floats_per_wave: int   # the walk's weight tile
     quads: np.ndarray          # int32 [n_quads, 8] {e0, e1, e2, e3 (-1: loader only), cu_log2, n_pass, n_groups, wave_unit base}
+    rounds: np.ndarray         # int32 [n_rounds, 2] {quad, node group} in walking order: class by class, node group by node
+                               # group, so that the rounds that stage the SAME edge rows follow each other (L2 reuse)
     wave_units: np.ndarray     # int32 [sum n_pass * 4, 2] {first unit, n units} of (quad, pass, wave)
     units: np.ndarray          # int32 [n_units, 8] {out col of (v = 16 mt, k = 0), d3, valid v, nt0, n_nt, first piece, n pieces, 0}
     pieces: np.ndarray         # int32 [n_pieces, 4] {dump offset (floats), A offset (floats per species row), lanes per node (log2) of its entry, 0}
@@ -309,7 +311,13 @@ def plan_conv_tile(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[ConvTil
                         pieces.append((pw * DUMP_REGS * DUMP_RS + rel * DUMP_RS, a_of[keyA], e_cu_log2, 0))
                         mfma += ksv * nn * n_groups
                     units.append((o_offs[io] + 16 * mt * d3, d3, min(16, mo - 16 * mt), nt0, nn, first_piece,
-                                  len(pieces) - first_piece, npw_log2))
+                                  len(pieces) - first_piece, npw_log2 | (cu_log2 << 8)))
+    rounds = []
+    for cls in sorted({int(q[4]) for q in quad_rows}, reverse=True):
+        qs = [qi for qi, q in enumerate(quad_rows) if int(q[4]) == cls]
+        for r in range(int(quad_rows[qs[0]][6])):
+            rounds += [(qi, r) for qi in qs]
+    assert len(rounds) == n_rounds
     gather = np.concatenate(gather_parts, axis=1).astype(np.int64) if gather_parts else np.zeros((S, 0), np.int64)
     assert gather.size == 0 or gather.max() < flat
     d_out = irreps_out.dim
@@ -322,7 +330,8 @@ def plan_conv_tile(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[ConvTil
         return None
     return ConvTilePlan(
         entries=rows.astype(np.int32), fused_cols=fused_cols, a_tiles=a_tiles, lds_floats_per_wave=lds_wave,
-        quads=np.array(quad_rows, dtype=np.int32).reshape(-1, 8), wave_units=np.array(wave_units, dtype=np.int32).reshape(-1, 2),
+        quads=np.array(quad_rows, dtype=np.int32).reshape(-1, 8), rounds=np.array(rounds, dtype=np.int32).reshape(-1, 2),
+        wave_units=np.array(wave_units, dtype=np.int32).reshape(-1, 2),
         units=np.array(units, dtype=np.int32).reshape(-1, 8), pieces=np.array(pieces, dtype=np.int32).reshape(-1, 4),
         a_stride=a_off, gather=gather, scale=np.concatenate(scale_parts) if scale_parts else np.zeros(0, np.float32),
         d_out=d_out, out_ld=out_ld, n_rounds=n_rounds, lds_bytes=lds_bytes, idle_waves=idle_waves, mfma_per_tile=mfma)
@@ -366,7 +375,8 @@ def emulate_lin2(plan: ConvTilePlan, uvu: UVUPlan, lin2_weight: np.ndarray, spec
                 for w in range(4):
                     u0, nu = plan.wave_units[base + ps * 4 + w]
                     for un in plan.units[u0:u0 + nu]:
-                        col0, d3, vcount, nt0, n_nt, p0, npc, npw_log2 = (int(t) for t in un)
+                        col0, d3, vcount, nt0, n_nt, p0, npc, packed = (int(t) for t in un)
+                        npw_log2 = packed & 255
                         D = np.zeros((n_nt, 16, 16))               # [nt][v][col]
                         for pc in plan.pieces[p0:p0 + npc]:
                             doff, aoff, cu = int(pc[0]), int(pc[1]), 1 << int(pc[2])
