@@ -268,14 +268,16 @@ int matten_tp_max_cols_l1(void);   /* ... and of vector (l1 = 1) input blocks */
  *   quads[n_quads, 8]     : {e0, e1, e2, e3 (entry per wave, -1 = the wave only feeds the shared stage), class lanes
  *                            per node (log2), passes, node groups of the tile, base index into wave_units}
  *   rounds[n_rounds, 2]   : {quad, node group} in walking order (rounds that stage the same edge rows adjacent)
- *   wave_units[.., 2]     : {first unit, count} of (quad, pass, wave) at base + 4 pass + wave
- *   units[n_units, 8]     : {output column of (v = 16 mt, k = 0), d3, valid v <= 16, first column tile, column tiles <= 4,
- *                            first piece, pieces, log2(nodes per wave of the round) | class lanes per node (log2) << 8};
- *                            column n of a tile = (node n mod
- *                            npw of the round's group, component n / npw)
- *   pieces[n_pieces, 4]   : {float offset of the piece's first register in the four waves' dump ([wave][28 registers]
- *                            [68 floats]: register r of lane l at r 68 + l), float offset of its A fragment in a species'
- *                            row of atab, lanes per node (log2) of its entry, 0}
+ *   the lin2 work lists, packed (the kernel keeps a copy in LDS), in the order a wave meets them:
+ *   phase_recs[.., 2]     : {first fragment | count << 16, first unit} of (quad, pass, wave) at base + 4 pass + wave
+ *   unit_recs[n_unit, 2]  : {output column of (v = 16 mt, k = 0) | d3 << 12 | valid v (<= 16) << 16 | first column tile << 21 |
+ *                            column tiles (<= 4) << 25,  log2(nodes per wave of the round) | class lanes per node (log2) << 4};
+ *                            a unit = (output irrep, 16-channel tile, column tiles); column n of a tile = (node n mod npw of
+ *                            the round's node group, component n / npw)
+ *   frag_recs[n_frag]     : one (piece, unit) product each: A fragment offset / 64 in a species' row of atab | first register
+ *                            of the piece in its wave's dump << 14 | that wave << 19 | lanes per node (log2) of its entry << 21 |
+ *                            last fragment of its unit << 24.  Dump: [wave][28 registers][68 floats], register r of lane l at
+ *                            r 68 + l
  *   atab[S, a_stride]     : lin2 weights W[u, s, v] fan_in^-1/2 as MFMA A fragments [lane (g, c)][KS]: u = entry channel
  *                            g KS + t (KS = max(1, lanes per node / 4)), v = 16 mt + c; zero outside the piece's channels
  *   add[N, add_ld] (self-connection) or NULL; cmeta == NULL: out[N, out_ld >= d_out] = add + lin2(agg).
@@ -297,8 +299,8 @@ int matten_conv_tile(const float* x, int64_t d_in, const uint16_t* h2s, const fl
                      const uint16_t* a_split, const float* a_scale_inv, float avg_num_neighbors, const float* num_neigh,
                      const int32_t* tile_nodes, const int32_t* tile_species, int64_t n_slots, int64_t slots_per_block,
                      const int32_t* quads, int64_t n_quads, const int32_t* rounds, int64_t n_rounds,
-                     const int32_t* wave_units, const int32_t* units,
-                     const int32_t* pieces, const float* atab, int64_t a_stride, const float* add, int64_t add_ld,
+                     const int32_t* frag_recs, int64_t n_frag, const int32_t* unit_recs, int64_t n_unit,
+                     const int32_t* phase_recs, int64_t n_phase, const float* atab, int64_t a_stride, const float* add, int64_t add_ld,
                      int64_t d_out, const int32_t* cmeta, const float* act_cst, const float* bn_scale,
                      const float* bn_shift, int64_t d_act, float* out, int64_t out_ld, matten_stream_t stream);
 

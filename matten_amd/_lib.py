@@ -52,9 +52,12 @@ SIGNATURES = {
     "matten_conv_tile_dump_stride": (c_int, []),
     "matten_species_tiles_slots_per_block": (c_int64, [c_int64, c_int64]),
     "matten_species_tiles": (c_int, [P, c_int64, c_int64, c_int64, P, P, P]),
-    "matten_conv_tile": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, P, c_int64, c_int64, P, P, c_float, P,
-                                 P, P, c_int64, c_int64, P, c_int64, P, c_int64, P, P, P, P, c_int64, P, c_int64, c_int64, P, P, P,
-                                 P, c_int64, P, c_int64, P]),
+    "matten_conv_tile": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64,              # x .. n_nodes
+                                 P, c_int64, c_int64, P, P, c_float, P,                             # entries .. num_neigh
+                                 P, P, c_int64, c_int64,                                            # tiles
+                                 P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64,        # quads, rounds, frags, units, phases
+                                 P, c_int64, P, c_int64, c_int64,                                   # atab, a_stride, add, add_ld, d_out
+                                 P, P, P, P, c_int64, P, c_int64, P]),                              # gate tables, d_act, out, out_ld, stream
     "matten_tp_fused": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
     "matten_species_linear": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
     "matten_species_linear_rows": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),

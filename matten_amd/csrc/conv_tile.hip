@@ -47,6 +47,11 @@ constexpr bool CT_LAB_NO_LIN2 = true;
 #else
 constexpr bool CT_LAB_NO_LIN2 = false;
 #endif
+#if defined(MATTEN_LAB) && defined(CT_ABLATE_NO_ALOAD)   // timing build: the A fragments are constants (no global load in the lin2 phase)
+constexpr bool CT_LAB_NO_ALOAD = true;
+#else
+constexpr bool CT_LAB_NO_ALOAD = false;
+#endif
 #if defined(MATTEN_LAB) && defined(CT_ABLATE_NO_DUMP)    // timing build: the accumulators are not parked either
 constexpr bool CT_LAB_NO_DUMP = true;
 #else
@@ -58,9 +63,9 @@ struct CArgs {
     const int* tile_species;   // [n_slots] species of the tile, -1 = empty slot
     const int4* quads;         // [n_quads, 2] {e0, e1, e2, e3} {class lanes per node (log2), passes, node groups, wave_units base}
     const int2* rounds;        // [n_rounds] {quad, node group}: the order the tile walks them (rounds over the same rows adjacent)
-    const int2* wave_units;    // [.., 2] {first unit, count} of (quad, pass, wave)
-    const int4* units;         // [n_units, 2] {out col of (v = 16 mt, k = 0), d3, valid v, nt0} {n_nt, first piece, n pieces, log2 nodes per wave}
-    const int4* pieces;        // [n_pieces] {dump offset, A offset, lanes per node (log2) of the entry, 0}
+    const int* frag_recs;      // [n_frag]   A offset / 64 | first register << 14 | dump wave << 19 | lanes per node (log2) << 21 | last of unit << 24
+    const int2* unit_recs;     // [n_unit]   {out col | d3 << 12 | valid v << 16 | nt0 << 21 | n_nt << 25, log2 nodes per wave | class lanes (log2) << 4}
+    const int2* phase_recs;    // [n_phase]  {first fragment | count << 16, first unit} of (quad, pass, wave) at base + 4 pass + wave
     const float* atab;         // [n_species, a_stride]
     const float* add;          // [N, add_ld] self-connection, or NULL
     float* out;                // [N, out_gld]
@@ -68,7 +73,7 @@ struct CArgs {
     const float* act_cst;
     const float* bn_scale;     // [d_act] or NULL
     const float* bn_shift;
-    int n_rounds, a_stride, n_slots, slots_per_block, add_ld, out_gld, d_out, d_act, out_ld, walk_floats;
+    int n_rounds, a_stride, n_slots, slots_per_block, add_ld, out_gld, d_out, d_act, out_ld, walk_floats, n_frag, n_unit, n_phase;
 };
 
 // ---- compile-time pass layout of a group kind: couplings in order, a new pass when the next one does not fit ----------
@@ -93,11 +98,22 @@ struct DumpLayout {
     }
 };
 
+// The lin2 phase is a real function (one copy of its code, its own register allocation: inlined into every group kind it
+// doubled the kernel and moved the walk's registers); its pointers carry their address spaces explicitly, because a
+// generic pointer argument would turn every LDS access into a flat instruction that queues behind the gathers.
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) const float lds_cf32;
+typedef __attribute__((address_space(3))) const int lds_ci32;
+typedef __attribute__((address_space(1))) const float glb_cf32;
+typedef float lds_f32x4 __attribute__((ext_vector_type(4)));
 struct Lin2Ctx {
-    const float* atab_sp;   // the tile's species row of the A table
-    float* dump_all;        // the four waves' dump regions (LDS)
-    float* otile;           // [16][out_ld] (LDS)
-    int wu_base, n_pass, r;
+    glb_cf32* atab_sp;      // the tile's species row of the A table (global)
+    lds_cf32* dump_all;     // the four waves' dump regions
+    lds_f32* otile;         // [16][out_ld]
+    lds_ci32* frag_l;       // LDS copies of the packed work lists: fragments, units (2 ints each), phases (2 ints each)
+    lds_ci32* unit_l;
+    lds_ci32* phase_l;
+    int out_ld, wu_base, n_pass, r, class_cu_log2;
 };
 
 __device__ __forceinline__ float ct_act(int code, float v) {
@@ -111,49 +127,84 @@ __device__ __forceinline__ float ct_act(int code, float v) {
     }
 }
 
-// One unit's pieces with KSV = channels per lane group and contraction step (4 / 2 / 1 for 16 / 8 / <= 4 lanes per node).
-// The A fragments of up to CT_A_BATCH pieces are requested together (one coalesced load each, L2-resident table): a
-// piece's matrix steps are far shorter than a load's latency, one load at a time would be the whole phase.
-constexpr int CT_A_BATCH = 6;
+// lin2 of one pass of a round: this wave's fragments, unit by unit (see the header comment).  KSV = channels per lane group
+// and contraction step of the round's class (4 / 2 / 1 for 16 / 8 / <= 4 lanes per node).
+// Latency is the whole cost of this phase (the matrix work is ~1 % of the tile's time): under the load of three
+// workgroups' gathers a dependent global load takes microseconds.  So the work lists are read from LDS (packed records,
+// copied once per workgroup), and the A fragments of up to CT_MAXF pieces are requested TOGETHER -- one coalesced load
+// each from the L2-resident table -- before any of them is used: one memory round trip per batch instead of one per piece.
+#ifndef CT_MAXF_N
+#define CT_MAXF_N 8
+#endif
+constexpr int CT_MAXF = CT_MAXF_N;
 template <int KSV>
-__device__ __forceinline__ void lin2_unit_pieces(const CArgs& ca, const Lin2Ctx& cx, int p_beg, int p_cnt, int n_nt,
-                                                 const int* __restrict__ boff, const int* __restrict__ jn, f32x4* __restrict__ D) {
+__device__ __forceinline__ void lin2_phase_t(const Lin2Ctx& cx, int pass) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    for (int p0 = p_beg; p0 < p_beg + p_cnt; p0 += CT_A_BATCH) {
-        const int nb = min(CT_A_BATCH, p_beg + p_cnt - p0);
-        float av[CT_A_BATCH][KSV];
-        int doff[CT_A_BATCH], cul[CT_A_BATCH];
+    const int g = lane >> 4, c = lane & 15;
+    const int ph_x = __builtin_amdgcn_readfirstlane(cx.phase_l[2 * (cx.wu_base + pass * WAVES_PER_BLOCK + wave)]);
+    const int f_beg = ph_x & 0xffff, f_cnt = (ph_x >> 16) & 0xffff;
+    int ui = __builtin_amdgcn_readfirstlane(cx.phase_l[2 * (cx.wu_base + pass * WAVES_PER_BLOCK + wave) + 1]);
+    // state of the unit being accumulated (persists across batches)
+    int jn[CT_MAX_NT], kk[CT_MAX_NT], boff[CT_MAX_NT];
+    f32x4 D[CT_MAX_NT];
+    int col0 = 0, d3 = 1, vcount = 0, n_nt = 0, npw_log2 = 0;
+    bool fresh = true;
+    for (int fb = 0; fb < f_cnt; fb += CT_MAXF) {
+        const int nb = min(CT_MAXF, f_cnt - fb);
+        int rec[CT_MAXF];
+        float av[CT_MAXF][KSV];
 #pragma unroll
-        for (int b = 0; b < CT_A_BATCH; ++b) {
-            const int4 pc = ca.pieces[p0 + min(b, nb - 1)];
-            doff[b] = __builtin_amdgcn_readfirstlane(pc.x);
-            cul[b] = __builtin_amdgcn_readfirstlane(pc.z);
-            const float* ap = cx.atab_sp + __builtin_amdgcn_readfirstlane(pc.y) + lane * KSV;
-            if constexpr (KSV == 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ap);
+        for (int b = 0; b < CT_MAXF; ++b) {
+            rec[b] = __builtin_amdgcn_readfirstlane(cx.frag_l[f_beg + fb + min(b, nb - 1)]);
+            glb_cf32* ap = cx.atab_sp + (rec[b] & 0x3fff) * 64 + lane * KSV;
+            if constexpr (CT_LAB_NO_ALOAD) {
+#pragma unroll
+                for (int t = 0; t < KSV; ++t) av[b][t] = 1e-3f * (float)(rec[b] & 0xff);
+            } else if constexpr (KSV == 4) {
+                const f32x4 v = *reinterpret_cast<__attribute__((address_space(1))) const f32x4*>(ap);
                 av[b][0] = v[0], av[b][1] = v[1], av[b][2] = v[2], av[b][3] = v[3];
             } else if constexpr (KSV == 2) {
-                const f32x2 v = *reinterpret_cast<const f32x2*>(ap);
+                const f32x2 v = *reinterpret_cast<__attribute__((address_space(1))) const f32x2*>(ap);
                 av[b][0] = v[0], av[b][1] = v[1];
             } else {
                 av[b][0] = ap[0];
             }
         }
 #pragma unroll
-        for (int b = 0; b < CT_A_BATCH; ++b) {
+        for (int b = 0; b < CT_MAXF; ++b) {
             if (b < nb) {
-                const float* db = cx.dump_all + doff[b];
+                if (fresh) {   // first fragment of a unit: its columns
+                    const int ux = __builtin_amdgcn_readfirstlane(cx.unit_l[2 * ui]);
+                    const int uy = __builtin_amdgcn_readfirstlane(cx.unit_l[2 * ui + 1]);
+                    col0 = ux & 0xfff, d3 = (ux >> 12) & 15, vcount = (ux >> 16) & 31, n_nt = (ux >> 25) & 7;
+                    const int nt0 = (ux >> 21) & 15, class_cu_log2 = uy >> 4;
+                    npw_log2 = uy & 15;
+#pragma unroll
+                    for (int nt = 0; nt < CT_MAX_NT; ++nt) {
+                        const int col = (nt0 + min(nt, n_nt - 1)) * 16 + c;
+                        jn[nt] = col & ((1 << npw_log2) - 1);
+                        kk[nt] = col >> npw_log2;
+                        // float offset of this lane's B operand inside a piece's dump block (columns past d3: clamped, discarded)
+                        boff[nt] = min(kk[nt], d3 - 1) * CT_DUMP_RS + g * KSV + (KSV > 1 ? (jn[nt] << class_cu_log2) : 0);
+                        D[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    fresh = false;
+                }
+                const int r = rec[b];
+                lds_cf32* db = cx.dump_all + ((r >> 19) & 3) * (CT_DUMP_REGS * CT_DUMP_RS) + ((r >> 14) & 31) * CT_DUMP_RS;
+                const int cul = (r >> 21) & 7;
 #pragma unroll
                 for (int nt = 0; nt < CT_MAX_NT; ++nt) {
                     if (nt < n_nt) {
                         // KSV >= 2: the class has one lanes-per-node value (folded into boff); KSV == 1: 4 or 2 lanes
-                        const int o = KSV == 1 ? boff[nt] + (jn[nt] << cul[b]) : boff[nt];
+                        const int o = KSV == 1 ? boff[nt] + (jn[nt] << cul) : boff[nt];
                         float bv[KSV];
                         if constexpr (KSV == 4) {
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(db + o);
+                            const f32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const f32x4*>(db + o);
                             bv[0] = v[0], bv[1] = v[1], bv[2] = v[2], bv[3] = v[3];
                         } else if constexpr (KSV == 2) {
-                            const f32x2 v = *reinterpret_cast<const f32x2*>(db + o);
+                            const f32x2 v = *reinterpret_cast<__attribute__((address_space(3))) const f32x2*>(db + o);
                             bv[0] = v[0], bv[1] = v[1];
                         } else {
                             bv[0] = db[o];
@@ -162,61 +213,34 @@ __device__ __forceinline__ void lin2_unit_pieces(const CArgs& ca, const Lin2Ctx&
                         for (int t = 0; t < KSV; ++t) D[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b][t], bv[t], D[nt], 0, 0, 0);
                     }
                 }
+                if ((r >> 24) & 1) {   // last fragment of the unit: D[nt][i] = out channel 4 g + i of column (jn, kk) -> the tile's rows
+#pragma unroll
+                    for (int nt = 0; nt < CT_MAX_NT; ++nt) {
+                        if (nt < n_nt && kk[nt] < d3) {
+                            lds_f32* op = cx.otile + ((cx.r << npw_log2) + jn[nt]) * cx.out_ld + col0 + kk[nt] + 4 * g * d3;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (4 * g + i < vcount) op[i * d3] += D[nt][i];
+                        }
+                    }
+                    ++ui;
+                    fresh = true;
+                }
             }
         }
     }
 }
 
-// lin2 of one pass of a round: this wave's units (see the header comment)
-__device__ __forceinline__ void lin2_phase(const CArgs& ca, const Lin2Ctx& cx, int pass) {
+__device__ __noinline__ void lin2_phase(Lin2Ctx cx, int pass) {
     if constexpr (CT_LAB_NO_LIN2) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, c = lane & 15;
-    const int2 wu = ca.wave_units[cx.wu_base + pass * WAVES_PER_BLOCK + wave];
-    const int u_beg = __builtin_amdgcn_readfirstlane(wu.x), u_cnt = __builtin_amdgcn_readfirstlane(wu.y);
-    for (int ui = u_beg; ui < u_beg + u_cnt; ++ui) {
-        const int4 r0 = ca.units[2 * ui], r1 = ca.units[2 * ui + 1];
-        const int col0 = __builtin_amdgcn_readfirstlane(r0.x), d3 = __builtin_amdgcn_readfirstlane(r0.y);
-        const int vcount = __builtin_amdgcn_readfirstlane(r0.z), nt0 = __builtin_amdgcn_readfirstlane(r0.w);
-        const int n_nt = __builtin_amdgcn_readfirstlane(r1.x), p_beg = __builtin_amdgcn_readfirstlane(r1.y);
-        const int p_cnt = __builtin_amdgcn_readfirstlane(r1.z);
-        const int npw_log2 = __builtin_amdgcn_readfirstlane(r1.w & 255), class_cu_log2 = __builtin_amdgcn_readfirstlane(r1.w >> 8);
-        const int npw = 1 << npw_log2;
-        // column of this lane in each of the unit's column tiles: (node j of the round's group, component k)
-        int jn[CT_MAX_NT], kk[CT_MAX_NT], boff[CT_MAX_NT];
-        const int ksv = class_cu_log2 >= 4 ? 4 : class_cu_log2 == 3 ? 2 : 1;
-#pragma unroll
-        for (int nt = 0; nt < CT_MAX_NT; ++nt) {
-            const int col = (nt0 + min(nt, n_nt - 1)) * 16 + c;
-            jn[nt] = col & (npw - 1);
-            kk[nt] = col >> npw_log2;
-            // float offset of this lane's B operand inside a piece's dump block (clamped: columns past d3 are discarded)
-            boff[nt] = min(kk[nt], d3 - 1) * CT_DUMP_RS + g * ksv + (ksv > 1 ? (jn[nt] << class_cu_log2) : 0);
-        }
-        f32x4 D[CT_MAX_NT];
-#pragma unroll
-        for (int nt = 0; nt < CT_MAX_NT; ++nt) D[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ksv == 4) lin2_unit_pieces<4>(ca, cx, p_beg, p_cnt, n_nt, boff, jn, D);
-        else if (ksv == 2) lin2_unit_pieces<2>(ca, cx, p_beg, p_cnt, n_nt, boff, jn, D);
-        else lin2_unit_pieces<1>(ca, cx, p_beg, p_cnt, n_nt, boff, jn, D);
-        // D[nt][i] = out channel 4 g + i of column (jn, kk): add to the tile's rows (this wave owns these columns in this pass)
-#pragma unroll
-        for (int nt = 0; nt < CT_MAX_NT; ++nt) {
-            if (nt < n_nt && kk[nt] < d3) {
-                float* op = cx.otile + (cx.r * npw + jn[nt]) * ca.out_ld + col0 + kk[nt] + 4 * g * d3;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (4 * g + i < vcount) op[i * d3] += D[nt][i];
-            }
-        }
-    }
+    if (cx.class_cu_log2 >= 4) lin2_phase_t<4>(cx, pass);
+    else if (cx.class_cu_log2 == 3) lin2_phase_t<2>(cx, pass);
+    else lin2_phase_t<1>(cx, pass);
 }
 
 // what a wave does with its neighbour sums: park them for lin2, pass by pass
 struct StoreDump {
     float* dump;            // this wave's region [CT_DUMP_REGS][CT_DUMP_RS]
-    const CArgs* ca;
     const Lin2Ctx* cx;
     template <class G>
     __device__ __forceinline__ void store(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
@@ -237,14 +261,14 @@ struct StoreDump {
                 }
             }
             __syncthreads();          // every wave's sums of this pass are parked
-            lin2_phase(*ca, *cx, p);
+            lin2_phase(*cx, p);
             __syncthreads();          // ... and consumed: the next pass / the next round's walk may overwrite them
         }
     }
 };
 
 #define CT_RGS(L1, GI, TD) \
-    run_group_shared<L1, GI, 1, TD, false, 0u>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreDump{dump, &ca, &cx})
+    run_group_shared<L1, GI, 1, TD, false, 0u>(a, ge, tile, stage, e, node, lane, valid, beg, deg, maxdeg, StoreDump{dump, &cx})
 #define CT_GROUP_CASE(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): \
         if (TwoDeepOk<L1, GI>::value && nodes_per_wave <= 8 && nodes_per_wave >= 2) CT_RGS(L1, GI, (TwoDeepOk<L1, GI>::value)); \
@@ -270,14 +294,21 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, CT_MIN_BLOCKS) void conv_tile
     float* dump = lds + wave * (CT_DUMP_REGS * CT_DUMP_RS);
     float* otile = lds + ca.walk_floats;
     int* nid = reinterpret_cast<int*>(otile + CT_NODES * ca.out_ld);
+    int* frag_l = nid + 32;                      // packed work lists of the lin2 phases (read many times per tile)
+    int* unit_l = frag_l + ca.n_frag;
+    int* phase_l = unit_l + 2 * ca.n_unit;
     if (threadIdx.x < CT_NODES) nid[threadIdx.x] = ca.tile_nodes[slot * CT_NODES + threadIdx.x];
+    for (int i = threadIdx.x; i < ca.n_frag; i += WAVES_PER_BLOCK * 64) frag_l[i] = ca.frag_recs[i];
+    for (int i = threadIdx.x; i < 2 * ca.n_unit; i += WAVES_PER_BLOCK * 64) unit_l[i] = reinterpret_cast<const int*>(ca.unit_recs)[i];
+    for (int i = threadIdx.x; i < 2 * ca.n_phase; i += WAVES_PER_BLOCK * 64) phase_l[i] = reinterpret_cast<const int*>(ca.phase_recs)[i];
     __syncthreads();
     for (int row = wave; row < CT_NODES; row += WAVES_PER_BLOCK) {      // a wave per row, lanes along the columns
         const int n = nid[row];
         const float* arow = (ca.add && n >= 0) ? ca.add + (int64_t)n * ca.add_ld : nullptr;
         for (int col = lane; col < ca.d_out; col += 64) otile[row * ca.out_ld + col] = arow ? arow[col] : 0.0f;
     }
-    Lin2Ctx cx{ca.atab + (int64_t)sp * ca.a_stride, lds, otile, 0, 0, 0};
+    Lin2Ctx cx{(glb_cf32*)(ca.atab + (int64_t)sp * ca.a_stride), (lds_cf32*)lds, (lds_f32*)otile, (lds_ci32*)frag_l,
+               (lds_ci32*)unit_l, (lds_ci32*)phase_l, ca.out_ld, 0, 0, 0, 0};
     __syncthreads();
 
     for (int ri = 0; ri < ca.n_rounds; ++ri) {
@@ -289,6 +320,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, CT_MIN_BLOCKS) void conv_tile
         cx.n_pass = __builtin_amdgcn_readfirstlane(q1.y);
         cx.wu_base = __builtin_amdgcn_readfirstlane(q1.w);
         cx.r = r;
+        cx.class_cu_log2 = class_cu_log2;
         // a loader-only wave takes the geometry of the class (its rows are the class's rows)
         const int cu_log2 = e >= 0 ? entries[e].cu_log2 : class_cu_log2;
         const int cu = 1 << cu_log2;
@@ -309,7 +341,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, CT_MIN_BLOCKS) void conv_tile
             run_loader_only_t<1>(a, cu_log2, stage, beg, deg, maxdeg);
             for (int p = 0; p < cx.n_pass; ++p) {
                 __syncthreads();
-                lin2_phase(ca, cx, p);
+                lin2_phase(cx, p);
                 __syncthreads();
             }
         } else {
@@ -418,20 +450,20 @@ extern "C" int matten_conv_tile(const float* x, int64_t d_in, const uint16_t* h2
                                 float avg_num_neighbors, const float* num_neigh, const int32_t* tile_nodes,
                                 const int32_t* tile_species, int64_t n_slots, int64_t slots_per_block,
                                 const int32_t* quads, int64_t n_quads, const int32_t* rounds, int64_t n_rounds,
-                                const int32_t* wave_units, const int32_t* units,
-                                const int32_t* pieces, const float* atab, int64_t a_stride, const float* add,
+                                const int32_t* frag_recs, int64_t n_frag, const int32_t* unit_recs, int64_t n_unit,
+                                const int32_t* phase_recs, int64_t n_phase, const float* atab, int64_t a_stride, const float* add,
                                 int64_t add_ld, int64_t d_out, const int32_t* cmeta, const float* act_cst,
                                 const float* bn_scale, const float* bn_shift, int64_t d_act, float* out, int64_t out_ld,
                                 matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_nodes < 0 || d_in <= 0 || w_pad <= 0 || sh_stride < 32 || (sh_stride & 3) || n_entries <= 0 ||
         lds_floats_per_wave <= 0 || (lds_floats_per_wave & 3) || n_slots < 0 || slots_per_block <= 0 || n_quads <= 0 ||
-        n_rounds <= 0 ||
+        n_rounds <= 0 || n_frag <= 0 || n_unit <= 0 || n_phase <= 0 ||
         a_stride <= 0 || (a_stride & 3) || d_out <= 0 || out_ld <= 0)
         return MATTEN_EINVAL;
     if (n_nodes == 0 || n_slots == 0) return MATTEN_OK;
     if (!x || !h2s || !w2p || !sh_sorted || !rowptr || !src_sorted || !entries || !a_split || !a_scale_inv || !tile_nodes ||
-        !tile_species || !quads || !rounds || !wave_units || !units || !pieces || !atab || !out)
+        !tile_species || !quads || !rounds || !frag_recs || !unit_recs || !phase_recs || !atab || !out)
         return MATTEN_EINVAL;
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
     if (add && add_ld < d_out) return MATTEN_EINVAL;
@@ -442,14 +474,15 @@ extern "C" int matten_conv_tile(const float* x, int64_t d_in, const uint16_t* h2
     const int64_t walk = (int64_t)WAVES_PER_BLOCK * lds_floats_per_wave + 2 * 16 * STAGE_ROW;
     const int64_t dump = (int64_t)WAVES_PER_BLOCK * CT_DUMP_REGS * CT_DUMP_RS;
     const int64_t walk_floats = walk > dump ? walk : dump;
-    const size_t lds = sizeof(float) * (size_t)(walk_floats + (int64_t)CT_NODES * lds_out_ld + 32);
+    const size_t lds = sizeof(float) * (size_t)(walk_floats + (int64_t)CT_NODES * lds_out_ld + 32 + n_frag + 2 * n_unit + 2 * n_phase);
     if (lds > 64 * 1024) return MATTEN_EINVAL;
     Args a{x, (const _Float16*)h2s, w2p, (const _Float16*)a_split, a_scale_inv, sh_sorted, rowptr, src_sorted, num_neigh,
            nullptr, (int)d_in, (int)w_pad, (int)sh_stride, 0, (int)n_nodes, (int)lds_floats_per_wave, avg_num_neighbors};
-    CArgs ca{tile_nodes, tile_species, (const int4*)quads, (const int2*)rounds, (const int2*)wave_units, (const int4*)units,
-             (const int4*)pieces, atab, add, out, (const int4*)cmeta, act_cst, bn_scale, bn_shift, (int)n_rounds, (int)a_stride,
+    CArgs ca{tile_nodes, tile_species, (const int4*)quads, (const int2*)rounds, frag_recs, (const int2*)unit_recs,
+             (const int2*)phase_recs, atab, add, out, (const int4*)cmeta, act_cst, bn_scale, bn_shift, (int)n_rounds, (int)a_stride,
              (int)n_slots,
-             (int)slots_per_block, (int)add_ld, (int)out_ld, (int)d_out, (int)d_act, lds_out_ld, (int)walk_floats};
+             (int)slots_per_block, (int)add_ld, (int)out_ld, (int)d_out, (int)d_act, lds_out_ld, (int)walk_floats,
+             (int)n_frag, (int)n_unit, (int)n_phase};
     const int64_t n_blocks = matten_cdiv(n_slots, slots_per_block);
     const int64_t grid = matten_cdiv(n_blocks, N_XCD) * N_XCD * slots_per_block;
     if (grid >= ((int64_t)1 << 31)) return MATTEN_EINVAL;

@@ -29,9 +29,12 @@ KEPT_ONLY = "_amd_kept_irreps_only"   # batch-dict marker: node_features hold th
 # inference: skip the output irreps of the last conv layer nothing reads (PointConv.build_inference_view); 0 = run them
 DEAD_PATH_ELIMINATION = _os.environ.get("MATTEN_DEAD_PATH_ELIMINATION", "1") != "0"
 AGG_KM_MIN_ROWS = int(_os.environ.get("MATTEN_AGG_KM_MIN_ROWS", "8192"))   # nodes per batch from which lin2 streams component-major rows
-# conv-tile kernel (matten_conv_tile: agg stays on chip): "0" off; layers with at least CONV_TILE_MIN_DMID floats of
-# neighbour sums per node, batches of at least CONV_TILE_MIN_ROWS nodes, tiles cut from blocks of CONV_TILE_BLOCK nodes
-CONV_TILE = _os.environ.get("MATTEN_CONV_TILE", "1")
+# conv-tile kernel (matten_conv_tile: agg stays on chip).  OPT-IN (MATTEN_CONV_TILE=1): parity-green, but measured 8-20 %
+# slower per layer than tp_fused + agg_linear on MI355X (docs/LAB_NOTES.md round 4: the tile walk
+# without its lin2 phases only equals tp_fused WITH its agg stores, and lin2 on chip costs what agg_linear costs).  When on:
+# layers with at least CONV_TILE_MIN_DMID floats of neighbour sums per node, batches of at least CONV_TILE_MIN_ROWS nodes,
+# tiles cut from blocks of CONV_TILE_BLOCK nodes.  The plan is always built (host tests, A/B tools).
+CONV_TILE = _os.environ.get("MATTEN_CONV_TILE", "0")
 CONV_TILE_MIN_ROWS = int(_os.environ.get("MATTEN_CONV_TILE_MIN_ROWS", "8192"))
 CONV_TILE_MIN_DMID = int(_os.environ.get("MATTEN_CONV_TILE_MIN_DMID", "1000"))
 CONV_TILE_BLOCK = int(_os.environ.get("MATTEN_CONV_TILE_BLOCK", "2048"))
@@ -79,13 +82,13 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         from .. import plan as _plan
         from .. import plan_conv as _plan_conv
         self.tile_plan = None
-        if self.tp.impl == "fused" and CONV_TILE != "0":
+        if self.tp.impl == "fused":
             tpl = _plan_conv.plan_conv_tile(self.tp.plan, n_species, conv_layer_irreps)
             if tpl is not None:
                 self.tile_plan = tpl
-                self._tile_tables = DeviceTables(entries=tpl.entries, quads=tpl.quads, rounds=tpl.rounds, wave_units=tpl.wave_units,
-                                                 units=tpl.units, pieces=tpl.pieces, gather=tpl.gather, scale=tpl.scale,
-                                                 cols=tpl.fused_cols)
+                self._tile_tables = DeviceTables(entries=tpl.entries, quads=tpl.quads, rounds=tpl.rounds, frags=tpl.frag_recs,
+                                                 units=tpl.unit_recs, phases=tpl.phase_recs, gather=tpl.gather,
+                                                 scale=tpl.scale, cols=tpl.fused_cols)
                 self._tile_atab = DerivedWeight(self._pack_tile_atab)
                 self._tile_radial = DerivedWeight(self._pack_tile_radial)
         # component-major neighbour sums + streaming lin2 (matten_agg_linear): the inference path of the two-kernel conv
@@ -166,7 +169,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
             data[TILES_KEY] = tiles
         return ops.conv_tile(x1, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
                              t.get("entries", dev), tpl.lds_floats_per_wave, (frag, scale_inv), avg, num_neigh, tiles[:3],
-                             t.get("quads", dev), t.get("rounds", dev), t.get("wave_units", dev), t.get("units", dev), t.get("pieces", dev),
+                             t.get("quads", dev), t.get("rounds", dev), t.get("frags", dev), t.get("units", dev), t.get("phases", dev),
                              self._tile_atab.get(self.lin2.weight), self_connection, tpl.d_out, gate=gate)
 
     # ---- dead-output elimination (inference) ------------------------------------------------------------------------
@@ -250,7 +253,8 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         else:
             self_connection = self.sc(x, species)
             x1 = self.lin1(x, species)
-        if (self.tile_plan is not None and x1.shape[0] >= CONV_TILE_MIN_ROWS and self.tp.plan.d_mid >= CONV_TILE_MIN_DMID
+        if (self.tile_plan is not None and CONV_TILE != "0" and x1.shape[0] >= CONV_TILE_MIN_ROWS
+                and self.tp.plan.d_mid >= CONV_TILE_MIN_DMID
                 and DataKey.AMD_SPECIES_I32 in data
                 and not _ag.needs_grad(x1, self_connection, self.lin2.weight, *self.tp.weight_nn.parameters())):
             gate = self.__dict__.get("_gate_tile")   # set per call by PointConvWithActivation

@@ -517,7 +517,7 @@ def species_tiles(species_i32: torch.Tensor, n_species: int, block_nodes: int):
 
 
 def conv_tile(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, lds_floats_per_wave: int, a_split, avg_num_neighbors: float,
-              num_neigh, tiles, quads, rounds, wave_units, units, pieces, atab, add, d_out: int, gate=None) -> torch.Tensor:
+              num_neigh, tiles, quads, rounds, frag_recs, unit_recs, phase_recs, atab, add, d_out: int, gate=None) -> torch.Tensor:
     """out = add + lin2(neighbour sums) (or, with gate = (cmeta, act_cst, d_act, bn_scale, bn_shift), the activated and
     normalised row) without agg ever reaching memory: include/matten_hip.h matten_conv_tile, tables from
     plan_conv.plan_conv_tile, tiles = ops.species_tiles(...), a_split = (fragments, scale_inv per entry)."""
@@ -554,7 +554,8 @@ def conv_tile(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, lds_floats_pe
                                   _ptr(rowptr), _ptr(src_sorted), N, _ptr(entries), entries.shape[0], lds_floats_per_wave,
                                   _ptr(frag), _ptr(scale_inv), float(avg_num_neighbors or 0.0), _ptr(num_neigh),
                                   _ptr(tile_nodes), _ptr(tile_species), tile_species.shape[0], spb, _ptr(quads),
-                                  quads.shape[0], _ptr(rounds), rounds.shape[0], _ptr(wave_units), _ptr(units), _ptr(pieces),
+                                  quads.shape[0], _ptr(rounds), rounds.shape[0], _ptr(frag_recs), frag_recs.shape[0],
+                                  _ptr(unit_recs), unit_recs.shape[0], _ptr(phase_recs), phase_recs.shape[0],
                                   _ptr(atab), atab.shape[1],
                                   _ptr(add), add.stride(0) if add is not None else d_out, d_out, _ptr(cmeta), _ptr(act_cst),
                                   _ptr(bn_scale), _ptr(bn_shift), d_act, _ptr(out), width, _stream())

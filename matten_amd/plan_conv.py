@@ -78,6 +78,10 @@ class ConvTilePlan:
     wave_units: np.ndarray     # int32 [sum n_pass * 4, 2] {first unit, n units} of (quad, pass, wave)
     units: np.ndarray          # int32 [n_units, 8] {out col of (v = 16 mt, k = 0), d3, valid v, nt0, n_nt, first piece, n pieces, 0}
     pieces: np.ndarray         # int32 [n_pieces, 4] {dump offset (floats), A offset (floats per species row), lanes per node (log2) of its entry, 0}
+    # the same work lists packed for the kernel's LDS copy (one 32-bit record per fragment, in the order a wave meets them)
+    frag_recs: np.ndarray      # int32 [n_frags]  A offset / 64 | first register << 14 | dump wave << 19 | lanes per node (log2) << 21 | last of its unit << 24
+    unit_recs: np.ndarray      # int32 [n_units, 2] {out col | d3 << 12 | valid v << 16 | nt0 << 21 | n_nt << 25, log2 nodes per wave | class lanes << 4}
+    phase_recs: np.ndarray     # int32 [sum n_pass * 4, 2] {first fragment | count << 16, first unit} of (quad, pass, wave)
     a_stride: int              # floats per species of the A table
     gather: np.ndarray         # int64 [S, a_stride] index into the flat lin2 weight, -1 = structural zero
     scale: np.ndarray          # f32 [a_stride]
@@ -328,7 +332,27 @@ def plan_conv_tile(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[ConvTil
     lds_bytes = 4 * (max(walk, dump) + TILE_NODES * out_ld + 32)
     if lds_bytes > 64 * 1024:
         return None
+    # packed records: a wave's fragments of a (quad, pass), unit by unit
+    frag_recs, unit_recs, phase_recs = [], [], []
+    for (u0, nu) in wave_units:
+        phase_recs.append((len(frag_recs), len(unit_recs)))
+        n0 = len(frag_recs)
+        for (col0, d3, vcount, nt0, nn, p0, npc, packed) in units[u0:u0 + nu]:
+            assert col0 < 4096 and d3 < 16 and vcount <= 16 and nt0 < 16 and nn <= UNIT_MAX_NT and npc >= 1
+            unit_recs.append((col0 | (d3 << 12) | (vcount << 16) | (nt0 << 21) | (nn << 25), (packed & 255) | ((packed >> 8) << 4)))
+            for k, (doff, aoff, cul, _) in enumerate(pieces[p0:p0 + npc]):
+                wv, rel = doff // (DUMP_REGS * DUMP_RS), (doff % (DUMP_REGS * DUMP_RS)) // DUMP_RS
+                assert aoff % 64 == 0 and aoff // 64 < (1 << 14) and rel < 32 and wv < 4 and cul < 8
+                frag_recs.append((aoff // 64) | (rel << 14) | (wv << 19) | (cul << 21) | (int(k == npc - 1) << 24))
+        nf = len(frag_recs) - n0
+        assert n0 < 65536 and nf < 65536
+        phase_recs[-1] = (n0 | (nf << 16), phase_recs[-1][1])
+    lds_bytes += 4 * (len(frag_recs) + 2 * len(unit_recs) + 2 * len(phase_recs))
+    if lds_bytes > 64 * 1024:
+        return None
     return ConvTilePlan(
+        frag_recs=np.array(frag_recs, dtype=np.int64).astype(np.int32), unit_recs=np.array(unit_recs, dtype=np.int64).astype(np.int32).reshape(-1, 2),
+        phase_recs=np.array(phase_recs, dtype=np.int64).astype(np.int32).reshape(-1, 2),
         entries=rows.astype(np.int32), fused_cols=fused_cols, a_tiles=a_tiles, lds_floats_per_wave=lds_wave,
         quads=np.array(quad_rows, dtype=np.int32).reshape(-1, 8), rounds=np.array(rounds, dtype=np.int32).reshape(-1, 2),
         wave_units=np.array(wave_units, dtype=np.int32).reshape(-1, 2),

@@ -1062,6 +1062,7 @@ def test_neighbor_list_slabs_match_single_launch(monkeypatch):
 
 def _tile_switch(monkeypatch, pconv, on: bool):
     """force the conv-tile path for every layer and batch size, or switch it off (module-level thresholds of nn/conv.py)"""
+    monkeypatch.setattr(pconv, "CONV_TILE", "1" if on else "0")
     monkeypatch.setattr(pconv, "CONV_TILE_MIN_ROWS", 0 if on else 10**12)
     monkeypatch.setattr(pconv, "CONV_TILE_MIN_DMID", 0)
     monkeypatch.setattr(pconv, "AGG_KM_MIN_ROWS", 0)
@@ -1123,6 +1124,7 @@ def test_conv_tile_kernel_at_the_bench_batch(monkeypatch):
     _, model = build_pair(PAPER, ds, randomize_bn=True)
     batch = collate(graphs, device=DEV)
     small = collate(graphs[37:187], device=DEV)
+    monkeypatch.setattr(pconv, "CONV_TILE", "1")
     monkeypatch.setattr(pconv, "CONV_TILE_MIN_ROWS", 8192)
     with torch.no_grad():
         tiled = model(dict(batch))[0]["elastic_tensor_full"].clone()

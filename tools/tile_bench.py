@@ -38,6 +38,7 @@ def run(tag, b, steps=6):
     print(f"{tag:44s} fwd {dt*1e3:6.3f} ms | " + "  ".join(f"{k.split('/')[0][:9]}:{k.split('/')[1][:10]} {v:.3f}" for k, v in ev.items()), flush=True)
 
 
+pconv.CONV_TILE = "1"
 pconv.CONV_TILE_MIN_ROWS = 10**12
 run("two-kernel, 10 species", batch)
 run("two-kernel, 1 species", one)
