@@ -58,6 +58,20 @@ int matten_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes
                      int32_t* rowptr, int32_t* src_sorted, void* workspace, size_t workspace_bytes,
                      int32_t* err_flag, matten_stream_t stream);
 
+/* Long CSR segments cut into VIRTUAL nodes of at most max_len edges (small batches, where one hub -- a one-atom cell has
+ * hundreds of neighbours inside the cutoff -- would otherwise set the duration of every tensor-product launch: the kernels
+ * walk a segment serially).  The pieces tile the sorted edge list in order:
+ *   vrowptr[bound + 1] : CSR row pointer over virtual nodes (pieces past the real count are empty, = n_edges)
+ *   vseg[n_nodes + 1]  : int64, virtual range of every real node (the `ptr` of matten_segment_reduce: the real node's
+ *                        neighbour sum = ordered sum of its pieces' rows)
+ *   vnn[bound]         : num_neigh of the piece's real node (optional, for per-node normalisation; both NULL or neither)
+ * bound = matten_csr_split_bound(n_nodes, n_edges, max_len) = n_nodes + n_edges / max_len; no host sync.
+ * Reference: the order torch_scatter.scatter adds messages in is unspecified (nn/conv.py:114); here it is fixed and
+ * depends on the node's own segment only. */
+int64_t matten_csr_split_bound(int64_t n_nodes, int64_t n_edges, int64_t max_len);
+int matten_csr_split(const int32_t* rowptr, int64_t n_nodes, int64_t n_edges, int64_t max_len, int32_t* vrowptr,
+                     int64_t* vseg, const float* num_neigh, float* vnn, matten_stream_t stream);
+
 /* Grouping of n items by an integer key in [0, n_keys): order[n] = item positions stably sorted by key,
  * seg[n_keys+1] = first sorted position of each key.  This is the species grouping the species-indexed linears
  * (FullyConnectedTensorProduct with a one-hot operand, nn/conv.py:59-86) walk instead of evaluating densely over

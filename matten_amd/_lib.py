@@ -24,6 +24,8 @@ SIGNATURES = {
     "matten_group_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "matten_csr_counting_max_avg_degree": (c_int, []),
     "matten_csr_build": (c_int, [P, c_int64, c_int64, P, P, P, P, c_size_t, P, P]),
+    "matten_csr_split_bound": (c_int64, [c_int64, c_int64, c_int64]),
+    "matten_csr_split": (c_int, [P, c_int64, c_int64, c_int64, P, P, P, P, P]),
     "matten_group_by_key": (c_int, [P, c_int64, c_int64, P, P, P, c_size_t, P, P]),
     "matten_species_embed": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_int64, P, P, P, P, P, P]),
     "matten_edge_geom": (c_int, [P, P, P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_float, c_float, P, P, c_int, P, P, P, P, P]),

@@ -226,6 +226,63 @@ inline int key_bits(int64_t N) {
 
 }  // namespace
 
+// ---- long CSR segments cut into VIRTUAL nodes (small batches) ------------------------------------------------------------
+// The tensor-product kernels give a lane one (destination node, channel) and walk the node's segment edge by edge: the
+// launch lasts as long as the longest segment.  In a large regular batch that is the degree (18-30 everywhere); in a small
+// batch of real crystals it is the one hub (a one- or two-atom cell has 100-300 neighbours inside the cutoff while the
+// average is 30: the reference's n100 sample spends 65 % of its forward walking a handful of such segments on a few CUs).
+// Here every segment is cut into pieces of at most `max_len` edges; the pieces tile the sorted edge list in order, so
+// vrowptr[] is itself a CSR row pointer over virtual nodes, the kernels run on it unchanged, and the real node's sum is
+// the ordered sum of its pieces (matten_segment_reduce over vseg): fixed order, independent of the rest of the batch.
+// One workgroup (the batches this is for have a few thousand nodes): block scans of 1024 nodes with a running carry.
+__global__ __launch_bounds__(1024) void csr_split_kernel(const int* __restrict__ rowptr, int N, int max_len, int nv_bound,
+                                                         int* __restrict__ vrowptr, int64_t* __restrict__ vseg,
+                                                         const float* __restrict__ num_neigh, float* __restrict__ vnn) {
+    __shared__ int sh[1024];
+    __shared__ int carry_s;
+    const int t = threadIdx.x;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    const int E = rowptr[N];
+    for (int base = 0; base < N; base += 1024) {
+        const int n = base + t;
+        int beg = 0, k = 0;
+        if (n < N) {
+            beg = rowptr[n];
+            k = max(1, (rowptr[n + 1] - beg + max_len - 1) / max_len);
+        }
+        sh[t] = k;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan (Hillis-Steele)
+            const int v = t >= off ? sh[t - off] : 0;
+            __syncthreads();
+            sh[t] += v;
+            __syncthreads();
+        }
+        const int carry = carry_s;
+        const int first = carry + sh[t] - k;
+        if (n < N) {
+            vseg[n] = first;
+            for (int i = 0; i < k; ++i) {
+                const int v = first + i;
+                if (v < nv_bound) {
+                    vrowptr[v] = beg + i * max_len;
+                    if (vnn) vnn[v] = num_neigh[n];
+                }
+            }
+        }
+        __syncthreads();
+        if (t == 1023) carry_s = carry + sh[1023];
+        __syncthreads();
+    }
+    const int nv = min(carry_s, nv_bound);
+    if (t == 0) vseg[N] = nv;
+    for (int v = nv + t; v <= nv_bound; v += 1024) {   // unused virtual nodes: empty segments behind the last edge
+        vrowptr[v] = E;
+        if (vnn && v < nv_bound) vnn[v] = 1.0f;
+    }
+}
+
 extern "C" size_t matten_csr_workspace_bytes(int64_t E, int64_t N) {
     if (E < 0 || N < 0) return 0;
     size_t tmp = 0;
@@ -372,6 +429,23 @@ extern "C" int matten_group_by_key(const int64_t* key, int64_t n, int64_t n_keys
                                   stream, false) != hipSuccess)
         return MATTEN_ELAUNCH;
     csr_rowptr_kernel<<<(unsigned)matten_cdiv(n_keys + 1, T), T, 0, stream>>>(keys_out, n, n_keys, seg);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
+
+extern "C" int64_t matten_csr_split_bound(int64_t n_nodes, int64_t n_edges, int64_t max_len) {
+    return max_len > 0 ? n_nodes + n_edges / max_len : n_nodes;   // every node one piece + one more per max_len edges
+}
+
+extern "C" int matten_csr_split(const int32_t* rowptr, int64_t n_nodes, int64_t n_edges, int64_t max_len, int32_t* vrowptr,
+                                int64_t* vseg, const float* num_neigh, float* vnn, matten_stream_t stream_) {
+    if (n_nodes < 0 || n_edges < 0 || max_len <= 0 || n_nodes >= ((int64_t)1 << 30) || n_edges >= ((int64_t)1 << 31))
+        return MATTEN_EINVAL;
+    if (!rowptr || !vrowptr || !vseg || ((num_neigh == nullptr) != (vnn == nullptr))) return MATTEN_EINVAL;
+    const int64_t bound = matten_csr_split_bound(n_nodes, n_edges, max_len);
+    if (bound >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+    csr_split_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(rowptr, (int)n_nodes, (int)max_len, (int)bound, vrowptr, vseg,
+                                                          num_neigh, vnn);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

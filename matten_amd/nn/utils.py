@@ -243,6 +243,12 @@ class RadialMLP(torch.nn.Module):
         return ops.radial_hidden(geom_sorted, n_basis, r_start, r_end, w0p, w1p, self.h_scale(r_start, r_end)), w2p
 
 
+# small batches: CSR segments longer than HUB_SPLIT_LEN edges are walked in pieces (ops.csr_split); 0 = off.  Large batches
+# (>= HUB_SPLIT_MAX_ROWS nodes) keep whole segments: regular degrees, and the pieces' rows would cost memory traffic.
+HUB_SPLIT_LEN = int(os.environ.get("MATTEN_HUB_SPLIT_LEN", "16"))   # n100 hipGraph forward: 827 us whole segments, 574 / 468 / 454 us at 32 / 16 / 8
+HUB_SPLIT_MAX_ROWS = int(os.environ.get("MATTEN_HUB_SPLIT_MAX_ROWS", "8192"))
+
+
 class UVUTensorProduct(torch.nn.Module):
     def __init__(
         self,
@@ -330,13 +336,23 @@ class UVUTensorProduct(torch.nn.Module):
             return _ag.TensorProductScatterFn.apply(node_feats, w_edge, self, data, avg, num_neigh)
         if self.impl == "fused":
             h2p, w2p = self.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, data)
-            return ops.tp_fused(
-                node_feats, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
+            rowptr = data[DataKey.AMD_ROWPTR]
+            split = None
+            if out_layout is None and HUB_SPLIT_LEN > 0 and node_feats.shape[0] < HUB_SPLIT_MAX_ROWS:
+                # small batch: the launch lasts as long as its longest CSR segment (one hub node walked serially by one
+                # wave): walk pieces of at most HUB_SPLIT_LEN edges as virtual nodes and sum them afterwards, in order
+                split = data.get("_amd_csr_split")
+                if split is None or split[3] is not rowptr:
+                    split = ops.csr_split(rowptr, data[DataKey.AMD_SRC].shape[0], HUB_SPLIT_LEN, num_neigh) + (rowptr,)
+                    data["_amd_csr_split"] = split
+            agg = ops.tp_fused(
+                node_feats, h2p, w2p, data[DataKey.AMD_SH], rowptr if split is None else split[0], data[DataKey.AMD_SRC],
                 out_layout[0] if out_layout is not None else self._tables.get("gentries", dev),
                 self._tables.get("gumap", dev), len(self.plan.fused_unit_map),
                 self.plan.fused_lds_floats_per_wave, out_layout[1] if out_layout is not None else self.plan.d_mid, avg,
-                num_neigh, a_split=self.a_split(r0, r1),
+                num_neigh if split is None else split[2], a_split=self.a_split(r0, r1),
             )
+            return agg if split is None else ops.segment_reduce(agg, split[1], mean=False)
         w_edge = self.weight_nn(data[DataKey.AMD_GEOM], int(nb), r0, r1)
         if self.impl == "blocks":
             return ops.tp_blocks(

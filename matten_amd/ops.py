@@ -119,6 +119,25 @@ def csr_build(edge_index: torch.Tensor, n_nodes: int, err: torch.Tensor = None) 
     return perm, rowptr, src, err
 
 
+def csr_split(rowptr: torch.Tensor, n_edges: int, max_len: int, num_neigh: torch.Tensor = None):
+    """-> (vrowptr[bound+1] i32, vseg[N+1] i64, vnn[bound] f32 or None): every CSR segment cut into virtual nodes of at
+    most max_len edges (include/matten_hip.h matten_csr_split); bound = N + E // max_len, no host sync"""
+    lib = _lib.load()
+    rowptr = _need(rowptr, torch.int32, "rowptr")
+    N = rowptr.shape[0] - 1
+    bound = int(lib.matten_csr_split_bound(N, n_edges, max_len))
+    dev = rowptr.device
+    vrowptr = torch.empty(bound + 1, dtype=torch.int32, device=dev)
+    vseg = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    vnn = None
+    if num_neigh is not None:
+        num_neigh = _need(num_neigh, torch.float32, "num_neigh")
+        vnn = torch.empty(bound, dtype=torch.float32, device=dev)
+    _lib.check(lib.matten_csr_split(_ptr(rowptr), N, n_edges, max_len, _ptr(vrowptr), _ptr(vseg), _ptr(num_neigh), _ptr(vnn),
+                                    _stream()), "matten_csr_split")
+    return vrowptr, vseg, vnn
+
+
 def group_by_key(key: torch.Tensor, n_keys: int, err: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> (order[n] i32: positions stably sorted by key, seg[n_keys+1] i32, err_flag[1] i32)"""
     lib = _lib.load()
@@ -480,7 +499,8 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
         raise ValueError(f"h2s must be [E,2,32] fp16 (ops.split_hidden / ops.radial_hidden), got {tuple(h2p.shape)}")
     w2p = _need(w2p, torch.float32, "w2p")
     sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
-    N, d_in = x.shape[0], x.stride(0)
+    # destination rows = segments of rowptr (virtual nodes when the segments were cut by ops.csr_split); x rows are sources
+    N, d_in = rowptr.shape[0] - 1, x.stride(0)
     if num_neigh is not None:
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
     if a_split is not None:

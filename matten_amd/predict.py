@@ -137,6 +137,29 @@ def pack_structures(structures: Sequence):
 
 _SIDE_STREAMS: Dict[Any, Any] = {}
 
+# atoms one forward may hold when evaluate_soa coalesces user batches (MATTEN_PREDICT_NODE_BUDGET; ~30 KB of device buffers
+# per atom at 30 neighbours: 2 GB at the default)
+NODE_BUDGET = int(__import__("os").environ.get("MATTEN_PREDICT_NODE_BUDGET", "65536"))
+
+
+def coalesce_batches(ptr, batch_size: int, node_budget: int = None):
+    """Crystal index ranges of the forwards evaluate_soa runs.  ``batch_size`` is the reference's knob for how many
+    structures share a forward (predict.py:155, default 200); a crystal's prediction does not depend on its batch mates
+    (tests: bitwise within a kernel path, ~1e-7 across the row-resident / streaming lin2 switch), so here it only bounds
+    memory: consecutive user batches are merged while the atoms of the merged batch stay within ``node_budget``.  The
+    reference's data set averages 4.7 atoms per crystal -- 200 of them are ~1000 atoms, a forward that is all launch
+    latency (~45 launches), while 65536 atoms fill the GPU.  A single user batch larger than the budget is kept as it is."""
+    node_budget = NODE_BUDGET if node_budget is None else node_budget
+    B = len(ptr) - 1
+    chunks, lo = [], 0
+    while lo < B:
+        hi = min(B, lo + batch_size)
+        while hi < B and ptr[min(B, hi + batch_size)] - ptr[lo] <= node_budget:
+            hi = min(B, hi + batch_size)
+        chunks.append(np.arange(lo, hi))
+        lo = hi
+    return chunks
+
 
 def _side_stream(device):
     """one persistent graph-construction stream per device (a fresh stream per call would also mean a fresh, empty
@@ -184,7 +207,7 @@ def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
                     ids = np.delete(ids, e.indices)
         return ids, None
 
-    chunks = [np.arange(lo, min(B, lo + batch_size)) for lo in range(0, B, batch_size)]
+    chunks = coalesce_batches(ptr, batch_size)
     model.eval()
     # the per-forward range checks are read one batch late (and all of them before the results leave): the host keeps
     # building the next batch instead of waiting for the flags of the one it has just enqueued

@@ -1318,3 +1318,62 @@ def test_fuzzed_models_on_poisoned_buffers_with_the_streaming_lin2_forced():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_models.py"), "24", "4"], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_hub_segments_are_walked_in_pieces(golden_dir, monkeypatch):
+    """Small batches cut every CSR segment into virtual nodes of at most HUB_SPLIT_LEN edges (matten_csr_split) so that
+    a hub -- the n100 sample has atoms with 80 neighbours, the average is 30 -- does not set the duration of every
+    tensor-product launch; the real node's neighbour sum is the ordered sum of its pieces.  Checked: the split tables
+    against a host evaluation (ragged degrees, empty segments, bound padding), the n100 forward with pieces of 32 / 5 /
+    whole segments against each other and the oracle, per-node neighbour normalisation, and that a crystal's result does
+    not depend on its batch mates (bitwise)."""
+    from matten_amd import ops
+    from matten_amd.data.graph import average_num_neighbors, collate, crystal_graph
+    from matten_amd.nn import utils as nnu
+    from oracle.matten_ref import data as rdata
+
+    # ---- the tables
+    deg = torch.tensor([0, 3, 70, 32, 33, 1, 0, 64, 5], dtype=torch.int64)
+    rowptr = torch.zeros(len(deg) + 1, dtype=torch.int32)
+    rowptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
+    E = int(rowptr[-1])
+    nn_host = torch.arange(1, len(deg) + 1, dtype=torch.float32)
+    vrow, vseg, vnn = ops.csr_split(rowptr.to(DEV), E, 32, nn_host.to(DEV))
+    vrow, vseg, vnn = vrow.cpu(), vseg.cpu(), vnn.cpu()
+    bound = len(deg) + E // 32
+    assert vrow.shape[0] == bound + 1 and vseg.shape[0] == len(deg) + 1
+    want_rows, want_seg = [], [0]
+    for n, d in enumerate(deg.tolist()):
+        k = max(1, -(-d // 32))
+        want_rows += [int(rowptr[n]) + 32 * i for i in range(k)]
+        want_seg.append(want_seg[-1] + k)
+    nv = want_seg[-1]
+    assert vseg.tolist() == want_seg and vrow[:nv].tolist() == want_rows and (vrow[nv:] == E).all()
+    for n in range(len(deg)):
+        assert (vnn[want_seg[n]:want_seg[n + 1]] == nn_host[n]).all()
+    # pieces tile the edge list: consecutive, each at most 32 long, the last of a node ending where the next node starts
+    lens = (vrow[1:nv + 1] - vrow[:nv])
+    assert int(lens.max()) <= 32 and int(lens.sum()) == E
+
+    # ---- the forward
+    structs = rdata.structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))
+    graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
+    assert max(int(g["num_neigh"].max()) for g in graphs) > 64      # (80: more than twice the average of 30)
+    species = sorted({int(z) for s in structs for z in s["atomic_numbers"]})
+    for avg in (average_num_neighbors(graphs), None):
+        hp = dict(PAPER, average_num_neighbors="auto" if avg else None)
+        ref, model = build_pair(hp, {"allowed_species": species, "average_num_neighbors": avg}, randomize_bn=True)
+        batch = collate(graphs, device=DEV)
+        outs = {}
+        with torch.no_grad():
+            for L in (32, 16, 5, 0):
+                monkeypatch.setattr(nnu, "HUB_SPLIT_LEN", L)
+                outs[L] = model(dict(batch))[0]["elastic_tensor_full"].clone()
+            want = ref.decode(collate(graphs))
+            monkeypatch.setattr(nnu, "HUB_SPLIT_LEN", 32)
+            sub = model(dict(collate(graphs[40:57], device=DEV)))[0]["elastic_tensor_full"]
+        close_blocks(outs[32], outs[0].cpu(), rtol=5e-6, floor=2e-6, what="pieces of 32 vs whole segments")
+        close_blocks(outs[16], outs[0].cpu(), rtol=5e-6, floor=2e-6, what="pieces of 16 vs whole segments")
+        close_blocks(outs[5], outs[0].cpu(), rtol=5e-6, floor=2e-6, what="pieces of 5 vs whole segments")
+        close_blocks(outs[32], want, what="n100 with hub splitting vs oracle", want64=_want64(ref, graphs))
+        assert torch.equal(sub, outs[32][40:57]), "a crystal's rows depend on its batch mates"

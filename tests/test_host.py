@@ -219,6 +219,25 @@ def test_two_rank_sharding_gathers_in_batch_order(tmp_path, n_items):
         assert torch.equal(torch.load(os.path.join(tmp_path, f"out{r}.pt")), want)
 
 
+def test_predict_coalesces_user_batches_within_the_node_budget():
+    """evaluate_soa merges consecutive user batches (reference predict.py:155 batch_size) while the merged forward stays
+    within the atom budget: every crystal exactly once, in order; a batch above the budget stays whole; batch_size still
+    caps a forward when the crystals are large."""
+    from matten_amd.predict import coalesce_batches
+
+    sizes = np.array([5] * 1000)
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    ch = coalesce_batches(ptr, 200, node_budget=65536)
+    assert len(ch) == 1 and (ch[0] == np.arange(1000)).all()
+    ch = coalesce_batches(ptr, 200, node_budget=2400)          # 480 crystals' worth: two user batches fit, three do not
+    assert [len(c) for c in ch] == [400, 400, 200] and (np.concatenate(ch) == np.arange(1000)).all()
+    big = np.concatenate([[0], np.cumsum(np.array([64] * 1000))])
+    ch = coalesce_batches(big, 200, node_budget=10000)          # a user batch is 12800 atoms: above the budget, kept whole
+    assert [len(c) for c in ch] == [200] * 5
+    ch = coalesce_batches(big, 7, node_budget=64 * 20)          # ragged tail
+    assert (np.concatenate(ch) == np.arange(1000)).all() and max(len(c) for c in ch) <= 21
+
+
 def test_predict_api_surface():
     import inspect
 

@@ -10,6 +10,12 @@ species = sorted({int(z) for s in n100 for z in s["atomic_numbers"]})
 model = ScalarTensorModel(backbone_hparams=dict(PAPER_HPARAMS), dataset_hparams={"allowed_species": species, "average_num_neighbors": 30.4}).to("cuda:0").eval()
 batch = batch_graphs_gpu([(s["cart_coords"], s["lattice"], s["atomic_numbers"]) for s in n100], 5.0, "cuda:0")
 with torch.no_grad():
-    for _ in range(30):
-        model(dict(batch))
+    if os.environ.get("N100_MODE") == "graph":
+        from matten_amd.graphs import GraphedForward
+        g = GraphedForward(model, batch)
+        for _ in range(30):
+            g(batch)
+    else:
+        for _ in range(30):
+            model(dict(batch))
 torch.cuda.synchronize()
