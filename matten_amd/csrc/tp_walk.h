@@ -523,7 +523,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 
 // Coupling masks worth a specialisation: only the scalar-block kind (all five couplings, or l2 <= 3 when the target has
 // no 4o) -- for every other kind the extra instantiations cost the rest of the kernel more than they gain (DESIGN.md
-// section 8: the register allocation of this one function is shared by all kinds).
+// round 2: the register allocation of this one function is shared by all kinds).
 template <int L1, int GI> struct HotMask { static constexpr unsigned M0 = 0, M1 = 0; };
 #ifndef TPF_NO_HOT_MASKS
 template <> struct HotMask<0, 0> { static constexpr unsigned M0 = 0x1f, M1 = 0xf; };

@@ -341,7 +341,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                 n_tiles16 = max(1, nodes_per_wave // 16)
                 # wave tile: [16 * n_tiles16 edge rows][weight columns + 4 (+ 32: units off the shared path park the
                 # edge's harmonics behind the weights; sized for them so that any unit order is valid)].  Without the 32
-                # a block needs 35.8 instead of 52 KB of LDS, but four blocks per CU do not pay.
+                # a block needs 35.8 instead of 52 KB of LDS, but four blocks per CU do not pay (docs/LAB_NOTES.md round 2).
                 lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(combos)) // 16)) + 32 + 4))
                 n_mt = -(-(mul_c * len(combos)) // 16)  # 16-column MFMA tiles of the entry's weight block
                 row = [l1 * TP_KIND_STRIDE + gi, plist[0].x_off + u0 * d1, mul_c, cu_log2, 0, len(fused_cols),

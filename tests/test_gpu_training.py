@@ -171,7 +171,7 @@ def test_hipgraph_forward_is_bit_identical_to_eager():
 
 def test_hipgraph_forward_above_a_million_edges():
     """1000 fcc-64 crystals = 1.15 M edges: more keys than rocPRIM's radix sort survives in a capture on this ROCm
-    (DESIGN.md section 8).  The CSR of a sparse graph is built by counting, without that sort, so the capture works;
+    (docs/LAB_NOTES.md round 2).  The CSR of a sparse graph is built by counting, without that sort, so the capture works;
     a DENSE graph of that size is refused up front."""
     from matten_amd.data import synthetic
     from matten_amd.data.graph import collate

@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT/matten_amd/csrc" || exit 1
 run() {  # $1 = label, $2 = rows, $3 = maxP, $4.. = flags
   label=$1; rows=$2; maxp=$3; shift 3
   MATTEN_CG_SHARED_ROWS=$rows MATTEN_CG_SHARED_MAX_P=$maxp python3 gen_cg.py > cg_gen.h
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I../../include -I. -DTPF_ONLY_HEAVY "$@" -c tp_fused.hip -o build/tp_fused.o 2>/dev/null || { echo "build failed"; return; }
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I../../include -I. -DMATTEN_LAB -DTPF_ONLY_HEAVY "$@" -c tp_fused.hip -o build/tp_fused.o 2>/dev/null || { echo "build failed"; return; }
   hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libmatten_hip.so
   echo "== $label"; PK=0 python3 ../../tools/fused_kind_bench.py 2>&1 | grep "l1=[234]" | awk '{s+=$(NF-1); print} END {printf "   sum %.3f ms\n", s}'
 }

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT/matten_amd/csrc" || exit 1
 make -j8 > /dev/null 2>&1
 for mb in 3 4 5; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I../../include -I. -DTPF_ONLY_LIGHT -DTPF_MIN_BLOCKS=$mb -c tp_fused.hip -o build/tp_fused.o 2>/dev/null
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I../../include -I. -DMATTEN_LAB -DTPF_ONLY_LIGHT -DTPF_MIN_BLOCKS=$mb -c tp_fused.hip -o build/tp_fused.o 2>/dev/null
   hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libmatten_hip.so
   for lds in 1856 1344; do
     echo "== min blocks $mb, lds floats per wave $lds"
