@@ -128,25 +128,13 @@ int matten_radial_mlp(const float* geom_sorted, int64_t n_edges, int n_basis, fl
                       float act_cst, void* w_edge, int out_is_bf16, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * 'uvu' TensorProduct + gather + scatter-add + neighbour normalisation, fused
+ * 'uvu' TensorProduct + gather + scatter-add + neighbour normalisation over MATERIALISED per-edge weights
  * (nn/utils.py:230-237,263; nn/conv.py:113-120):
- *   agg[n, slot(p,u,k)] = norm_n * sum_{e in in(n)} w[e, woff_p+u] * sum_i x[src_e, xoff_p+u*d1+i] * M_e^{t(p)}[i,k]
- *   M_e^{t}[i,k] = sqrt(2 l3+1) * sum_j C^{l1 l2 l3}_{ijk} Y_{l2,j}(e)
+ *   agg[n, slot(p,u,k)] = norm_n * sum_{e in in(n)} w[e, woff_p+u] * sqrt(2 l3+1) sum_ij C^{l1 l2 l3}_{ijk} x[src_e, xoff_p+u*d1+i] Y_{l2,j}(e)
  *   norm_n = 1/sqrt(avg_num_neighbors) if avg_num_neighbors > 0 else 1/sqrt(num_neigh[n])
- * Plan tables (built once per layer on the host, immutable):
- *   m_terms_idx[m_total, m_nterms] (uint8 index into Y), m_terms_coef[m_total, m_nterms]
- *   out_meta[d_mid] int4 {x_base, w_index, m_base, d1 | d3<<8}
- * ------------------------------------------------------------------------------------------ */
-int matten_tp_scatter(const float* x /*[N,d_in]*/, int64_t d_in, const float* w_edge /*[E,w_pad]*/, int64_t w_pad,
-                      const float* sh_sorted, int64_t sh_dim, const int32_t* rowptr, const int32_t* src_sorted,
-                      int64_t n_nodes, const uint8_t* m_terms_idx, const float* m_terms_coef, int64_t m_total,
-                      int64_t m_nterms, const int32_t* out_meta, int64_t d_mid, float avg_num_neighbors,
-                      const float* num_neigh, float* agg /*[N,d_mid]*/, matten_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------
- * Same operator as matten_tp_scatter (reference nn/utils.py:230-237,263 + nn/conv.py:113-120),
- * production kernel: one wave per (path, node group), a lane owns one output channel of one
- * destination node, CG coefficients are compile-time literals (l <= 4).
+ * One wave per (path, node group), a lane owns one output channel of one destination node, CG coefficients are
+ * compile-time literals (l <= 4).  The training forward (its adjoint reads the same w), and an independent implementation
+ * of the contraction the production kernel matten_tp_fused is tested against.
  *   path_entries[n_entries, 8] int32 {l1*25+l2*5+l3, x_off, w_off, out_off, mul(<=64), log2(lanes per node), 0, 0}
  *   unit_start[n_entries+1]   int32  prefix sum of waves per node tile (matten_tp_tile_nodes() nodes per tile)
  * ------------------------------------------------------------------------------------------ */
@@ -157,22 +145,6 @@ int matten_tp_paths(const float* x, int64_t d_in, const void* w_edge, int64_t w_
                     const int32_t* path_entries, const int32_t* unit_start, int64_t n_entries,
                     int64_t units_per_tile, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
                     float* agg /*[N,d_mid]*/, int w_is_bf16, matten_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------
- * Same operator again, production kernel v3: one wave per (input irrep block, l2 group, node
- * group); every coupling (l1,l2,l3) that reads the same input block is fed from one gather.
- *   group_entries[n_entries, 32] int32 {l1*2+g, x_off, mul(<=64), log2(lanes per node), mask, w_base, 0,0,
- *                                       reserved[12], out_off[12]}  (coupling order: cg_gen.h Group<l1,g>)
- *   w_edge columns are in the FUSED order: entry by entry, [u][c] with c over all couplings of the
- *   group (absent couplings are zero columns): lane (u) reads w_edge[e, w_base + u*NC .. +NC)
- *   unit_start[n_entries+1] int32 prefix sum of waves per node tile
- *   sh_sorted rows must be at least 25 floats apart and readable up to column 25
- * ------------------------------------------------------------------------------------------ */
-int matten_tp_blocks(const float* x, int64_t d_in, const float* w_edge, int64_t w_pad, const float* sh_sorted,
-                     int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted, int64_t n_nodes,
-                     const int32_t* group_entries, const int32_t* unit_start, int64_t n_entries,
-                     int64_t units_per_tile, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
-                     float* agg /*[N,d_mid]*/, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * lin2 of a conv layer as a row stream over COMPONENT-MAJOR neighbour sums (reference nn/conv.py:84-86,123:
@@ -226,7 +198,11 @@ int matten_agg_linear_gate_sets(void);
  *                         literal-coefficient CG contraction + CSR neighbour sum
  *   w2p[32, w_pad]: last layer weights pre-scaled (1/sqrt(32) * normalize2mom(silu)), columns in the
  *                   fused [entry][u][coupling] order of group_entries, w_pad >= w_cols + 16
- *   group_entries: as matten_tp_blocks, with mul * couplings <= 64 weight columns per entry
+ *   group_entries[n_entries, 32] int32 {l1*8+g, x_off, mul, log2(lanes per node), coupling mask, w_base, first A tile,
+ *                   A tiles, t_off[12], out_off[12]}: one entry per (input irrep block chunk, l2 group g); couplings in the
+ *                   order of cg_gen.h Group<l1,g>, weight columns [u][c] (absent couplings: zero columns), mul * couplings
+ *                   <= matten_tp_max_cols*(); out_off[c] = first float of channel 0 in the output row, t_off[c] = 0
+ *                   (the reference's mul_ir row) or the floats between two components (component-major row)
  *   unit_map[units_per_tile]: wave index inside a node tile -> flags | entry << 8 | node group (of 64 >> cu_log2 nodes);
  *                   flags: bit 24 = the unit's workgroup (four consecutive units) shares an LDS stage: same node
  *                   group and lanes per node -- or, with bit 26 (paired), units 0,1 on node group r and units 2,3 the
@@ -433,7 +409,7 @@ int matten_dense_rows(const float* x, int64_t n_in, const float* q, int64_t n_ou
  * model/model.py:276-372 shared_step -> loss.backward()).  fp32.
  * ========================================================================================== */
 
-/* adjoint of matten_tp_paths / matten_tp_scatter (w_edge in the reference column order):
+/* adjoint of matten_tp_paths (w_edge in the reference column order):
  *   dw[e,q]              = norm * sum_ijk C_ijk x[src,x_base+i] Y[e,y_off+j] G[dst,out_base+k]
  *   dx[src, x_base + i] += norm * w[e,q] * sum_jk C_ijk Y[e,y_off+j] G[dst,out_base+k]     (dx zero-initialised)
  *   col_meta[n_cols,4] int32 {x_base, out_base, nnz_begin, nnz_count | y_off<<16}; nnz_ijk[nnz,4] uint8 {i,j,k,0}

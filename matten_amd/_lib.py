@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -30,11 +30,9 @@ SIGNATURES = {
     "matten_species_embed": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_int64, P, P, P, P, P, P]),
     "matten_edge_geom": (c_int, [P, P, P, P, c_int64, P, P, c_int64, c_int64, c_int, c_int, c_float, c_float, P, P, c_int, P, P, P, P, P]),
     "matten_radial_mlp": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, P, c_int, c_int, c_float, P, c_int, P]),
-    "matten_tp_scatter": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, P, c_int64, c_float, P, P, P]),
     "matten_tp_tile_nodes": (c_int, []),
     "matten_tp_paths": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_float, P, P, c_int,
                                 P]),
-    "matten_tp_blocks": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_float, P, P, P]),
     "matten_radial_hidden_multi": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, c_int, P, P, c_int, P]),
     "matten_agg_linear_max_mt": (c_int, []),
     "matten_agg_linear_block_chunks": (c_int, []),

@@ -274,16 +274,17 @@ class UVUTensorProduct(torch.nn.Module):
         layer_sizes = [mlp_input_size] + mlp_num_hidden_layers * [mlp_hidden_size] + [self.weight_numel]
         # "fused" : production -- last radial-MLP layer on the matrix cores inside the TP kernel, the per-edge
         #           weights never reach memory; weight columns in [entry][u][coupling] order (plan.fused_cols)
-        # "blocks": same contraction kernel fed from a materialised w[E, W] (two-kernel architecture)
-        # "paths" : one wave per path (same literals, no fusion); "table": table-driven kernel; both read
-        #           the reference's weight layout and are kept as independent implementations for tests
+        # "paths" : one wave per path over a materialised w[E, W] (same literals, no fusion, the reference's weight
+        #           layout): the training forward, and an independent implementation for the tests
         self.impl = os.environ.get("MATTEN_TP_IMPL", "fused")
+        if self.impl not in ("fused", "paths"):
+            raise ValueError(f"MATTEN_TP_IMPL={self.impl!r}: 'fused' or 'paths' (the table-driven and block kernels of "
+                             "rounds 1-2 were removed in round 4)")
         self.weight_nn = RadialMLP(layer_sizes, act=mlp_activation,
-                                   out_cols=self.plan.fused_cols if self.impl in ("blocks", "fused") else None)
+                                   out_cols=self.plan.fused_cols if self.impl == "fused" else None)
         self._tables = DeviceTables(
-            m_idx=self.plan.m_terms_idx, m_coef=self.plan.m_terms_coef, out_meta=self.plan.out_meta,
             entries=self.plan.path_entries, unit_start=self.plan.unit_start,
-            gentries=self.plan.group_entries, gstart=self.plan.group_unit_start, gumap=self.plan.fused_unit_map,
+            gentries=self.plan.group_entries, gumap=self.plan.fused_unit_map,
             bw_col_meta=self.plan.bw_col_meta, bw_nnz_ijk=self.plan.bw_nnz_ijk, bw_nnz_c=self.plan.bw_nnz_c,
             bw_in_ptr=self.plan.bw_in_ptr, bw_in_cols=self.plan.bw_in_cols,
             bw_blocks=self.plan.bw_blocks, bw_paths=self.plan.bw_paths,
@@ -353,24 +354,13 @@ class UVUTensorProduct(torch.nn.Module):
                 num_neigh if split is None else split[2], a_split=self.a_split(r0, r1),
             )
             return agg if split is None else ops.segment_reduce(agg, split[1], mean=False)
+        # "paths": one wave per path over a materialised w[E, W] in the reference's column order (the training forward; kept
+        # selectable for inference as an independent implementation of the same contraction)
         w_edge = self.weight_nn(data[DataKey.AMD_GEOM], int(nb), r0, r1)
-        if self.impl == "blocks":
-            return ops.tp_blocks(
-                node_feats, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
-                self._tables.get("gentries", dev), self._tables.get("gstart", dev), self.plan.group_units_per_tile,
-                self.plan.d_mid, avg, num_neigh,
-            )
-        if self.impl == "paths":
-            return ops.tp_paths(
-                node_feats, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
-                self._tables.get("entries", dev), self._tables.get("unit_start", dev), self.plan.units_per_tile,
-                self.plan.d_mid, avg, num_neigh,
-            )
-        return ops.tp_scatter(
+        return ops.tp_paths(
             node_feats, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
-            self._tables.get("m_idx", dev), self._tables.get("m_coef", dev), self._tables.get("out_meta", dev),
-            avg_num_neighbors if avg_num_neighbors is not None else 0.0,
-            None if avg_num_neighbors is not None else data[DataKey.NUM_NEIGH],
+            self._tables.get("entries", dev), self._tables.get("unit_start", dev), self.plan.units_per_tile,
+            self.plan.d_mid, avg, num_neigh,
         )
 
 

@@ -334,27 +334,6 @@ def radial_mlp_bwd(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p,
     return small[: nb_pad * hidden].reshape(nb_pad, hidden), small[nb_pad * hidden:].reshape(hidden, hidden), d2
 
 
-def tp_scatter(x, w_edge, sh_sorted, rowptr, src_sorted, m_idx, m_coef, out_meta, avg_num_neighbors: float,
-               num_neigh=None) -> torch.Tensor:
-    lib = _lib.load()
-    x = _need(x, torch.float32, "node_features")
-    w_edge = _need(w_edge, torch.float32, "w_edge")
-    sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
-    N, d_in = x.shape
-    d_mid = out_meta.shape[0]
-    m_total, m_nterms = m_coef.shape
-    if num_neigh is not None:
-        num_neigh = _need(num_neigh, torch.float32, "num_neigh")
-    agg = torch.empty(N, d_mid, dtype=torch.float32, device=x.device)
-    with _timed(f"tp_scatter/d_mid={d_mid}"):
-        rc = lib.matten_tp_scatter(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
-                                   _ptr(rowptr), _ptr(src_sorted), N, _ptr(m_idx), _ptr(m_coef), m_total, m_nterms,
-                                   _ptr(out_meta), d_mid, float(avg_num_neighbors or 0.0), _ptr(num_neigh),
-                                   _ptr(agg), _stream())
-    _lib.check(rc, "matten_tp_scatter")
-    return agg
-
-
 def tp_paths(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, units_per_tile: int, d_mid: int,
              avg_num_neighbors: float, num_neigh=None) -> torch.Tensor:
     lib = _lib.load()
@@ -375,29 +354,6 @@ def tp_paths(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, unit
                                  entries.shape[0], units_per_tile, d_mid, float(avg_num_neighbors or 0.0),
                                  _ptr(num_neigh), _ptr(agg), int(w_edge.dtype == torch.bfloat16), _stream())
     _lib.check(rc, "matten_tp_paths")
-    return agg
-
-
-def tp_blocks(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, units_per_tile: int, d_mid: int,
-              avg_num_neighbors: float, num_neigh=None) -> torch.Tensor:
-    lib = _lib.load()
-    from .plan import TP_TILE_NODES
-
-    if lib.matten_tp_tile_nodes() != TP_TILE_NODES:
-        raise _lib.MattenHipError("plan.TP_TILE_NODES does not match the library's node tile")
-    x = _need(x, torch.float32, "node_features")
-    w_edge = _need(w_edge, torch.float32, "w_edge")
-    sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
-    N, d_in = x.shape
-    if num_neigh is not None:
-        num_neigh = _need(num_neigh, torch.float32, "num_neigh")
-    agg = torch.empty(N, d_mid, dtype=torch.float32, device=x.device)
-    with _timed(f"tp_scatter/d_mid={d_mid}"):
-        rc = lib.matten_tp_blocks(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
-                                  _ptr(rowptr), _ptr(src_sorted), N, _ptr(entries), _ptr(unit_start),
-                                  entries.shape[0], units_per_tile, d_mid, float(avg_num_neighbors or 0.0),
-                                  _ptr(num_neigh), _ptr(agg), _stream())
-    _lib.check(rc, "matten_tp_blocks")
     return agg
 
 
