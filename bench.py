@@ -538,6 +538,27 @@ def run_rank(args):
     assert os.environ.get("MATTEN_BENCH_NO_CHECK") == "1" or torch.isfinite(out).all()  # the env is for ablation builds only
 
     if calibration is not None:
+        # the shader clock the chip sustains UNDER THE FORWARD's load: a one-wave probe on a side stream watches the clocks
+        # while a few more (untimed) forwards run.  The fixed kernels of calibrate() run at full clock on boxes whose
+        # power-hungry tensor-product kernels clock 7 % lower: this is the number two BENCH lines are normalised by.
+        from matten_amd import _lib as _mlib
+
+        lib_ = _mlib.load()
+        probe_clocks = torch.zeros(2, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(dev)
+        n_probe = 6
+        window_ticks = int(1e8 * (n_probe - 1) * elapsed / args.steps)          # 100 MHz ticks of n_probe - 1 forwards
+        side.wait_stream(torch.cuda.current_stream(dev))
+        step()                                                                   # the load is up before the probe starts
+        with torch.cuda.stream(side):
+            _mlib.check(lib_.matten_calib_clock_probe(max(1, window_ticks), probe_clocks.data_ptr(), side.cuda_stream),
+                        "matten_calib_clock_probe")
+        for _ in range(n_probe):
+            step()
+        model.finish_input_checks()
+        torch.cuda.synchronize()
+        tk, rf = (int(v) for v in probe_clocks.tolist())
+        calibration["sclk_mhz_during_forward"] = 100.0 * tk / rf if rf else None
         calibration["after"] = calibrate(dev)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if via_host else dev)
@@ -654,9 +675,12 @@ def run_rank(args):
         if calibration is not None:
             result["calibration"] = dict(calibration, what=(
                 "fixed kernels (csrc/calib.hip) timed with HIP events right before and right after the timed region: "
-                "VALU issue rate + effective shader clock, HBM copy rate.  Compare ms_per_step / kernel_ms_per_launch "
-                "of two BENCH lines only after dividing by these (a box or DVFS state that runs the VALU loop x % slower "
-                "runs the VALU-bound tp_fused kernel about x % slower)"))
+                "VALU issue rate + effective shader clock, HBM copy rate; and sclk_mhz_during_forward = the average shader "
+                "clock a one-wave probe saw while untimed forwards of this workload ran.  Pool boxes run the fixed kernels "
+                "alike and the forward up to 9 % apart: compare ms_per_step x sclk_mhz_during_forward (= cycles per step) "
+                "between two BENCH lines, not ms_per_step alone"))
+            if calibration.get("sclk_mhz_during_forward"):
+                result["calibration"]["mcycles_per_step"] = result["ms_per_step"] * calibration["sclk_mhz_during_forward"] * 1e-3
         # ---- what binds tp_fused_kernel physically: fp32 VALU issue (the contract figure above charges bytes the kernel
         # never moves).  Instruction counts per launch from the committed PMC run, issue rate from THIS run's calibration.
         if dom:

@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -95,6 +95,7 @@ SIGNATURES = {
     "matten_calib_valu_insts_per_simd": (c_int64, [c_int64]),
     "matten_calib_valu": (c_int, [c_int64, P, P, P]),
     "matten_calib_copy": (c_int, [P, P, c_int64, P]),
+    "matten_calib_clock_probe": (c_int, [c_int64, P, P]),
 }
 
 _lib = None

@@ -52,7 +52,31 @@ __global__ __launch_bounds__(256) void calib_copy_kernel(const f32x4* __restrict
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
 }
 
+// One wave that does nothing but watch the two clocks for `ticks_100mhz` reference ticks (sleeping in between): launched on
+// a side stream while the benchmark's forwards run, it reports the AVERAGE shader clock the chip sustained under that load
+// (clocks[0] / clocks[1] x 100 MHz) -- what the fixed kernels above cannot tell: a box may run them at full clock and the
+// power-hungry tensor-product kernels 7 % lower.
+__global__ __launch_bounds__(64) void calib_clock_probe_kernel(unsigned long long ticks_100mhz, unsigned long long* __restrict__ clocks) {
+    unsigned long long t0, r0, t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+    do {
+        __builtin_amdgcn_s_sleep(127);
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+    } while (r1 - r0 < ticks_100mhz);
+    if (threadIdx.x == 0) {
+        clocks[0] = t1 - t0;
+        clocks[1] = r1 - r0;
+    }
+}
+
 }  // namespace
+
+extern "C" int matten_calib_clock_probe(int64_t ticks_100mhz, uint64_t* clocks, matten_stream_t stream_) {
+    if (ticks_100mhz <= 0 || ticks_100mhz > 100000000 || !clocks) return MATTEN_EINVAL;   // at most one second
+    calib_clock_probe_kernel<<<1, 64, 0, (hipStream_t)stream_>>>((unsigned long long)ticks_100mhz, (unsigned long long*)clocks);
+    MATTEN_LAUNCH_CHECK();
+    return MATTEN_OK;
+}
 
 extern "C" int64_t matten_calib_valu_insts_per_simd(int64_t iters) {
     // 2048 workgroups x 4 waves over 1024 SIMDs = 8 waves per SIMD, each iters x UNROLL x CHAINS FMAs

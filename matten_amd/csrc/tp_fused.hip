@@ -40,6 +40,44 @@ namespace {
 
 using namespace matten_walk;
 
+// ---- what a unit does with its neighbour sums: one row slice of agg[N, d_mid] per (node, channel) --------------------
+// (Measured and removed, docs/LAB_NOTES.md: a vector epilogue -- channel lanes exchanging accumulators through LDS for
+// 16-byte stores, +8 % -- and non-temporal stores, +20 %: what costs is the 1.1 GB of distinct bytes per launch.)
+// MERGED entries (plan.TP_KIND_MERGED: two adjacent two-channel blocks in one four-lane entry): lanes u = 0, 1 are the
+// first block's channels and use this record's offsets, lanes u = 2, 3 the second block's and use the record that follows
+// it in the entry array (its own coupling mask there too; the first half's own mask travels in that record's w_base word).
+constexpr int KIND_MERGED = 256;   // == plan.TP_KIND_MERGED
+struct StoreAgg {
+    template <class G>
+    __device__ __forceinline__ void store(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
+                                          float a_scale_inv, int node, int j, int u, bool valid) const {
+        if (TPF_LAB_NO_STORE ? (valid && acc[0] == 12345.678f) : valid) {
+            const float nn = a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node];
+            const float norm = a_scale_inv / sqrtf(nn);
+            float* orow = a.agg + (int64_t)node * a.d_mid;
+            const bool merged = (ge.kind & KIND_MERGED) != 0;          // wave-uniform
+            const GroupEntry& g2 = (&ge)[merged ? 1 : 0];
+            const bool second = merged && u >= 2;
+            const unsigned mask = merged ? (second ? g2.mask : (unsigned)g2.w_base) : ge.mask;
+            const int uc = second ? u - 2 : u;
+#pragma unroll
+            for (int cc = 0; cc < G::NC; ++cc) {
+                if ((mask >> cc) & 1u) {
+                    const int d3 = 2 * G::L3[cc] + 1;
+                    // t_off[cc] == 0: the reference's "mul_ir" row, [channel][component].  Otherwise the component-major
+                    // row of plan.plan_agg_linear: t_off[cc] floats between components, the channel lanes side by side
+                    const int ks = second ? g2.t_off[cc] : ge.t_off[cc];
+                    float* op = orow + (second ? g2.out_off[cc] : ge.out_off[cc]) + (ks ? uc : uc * d3);
+                    const int kstep = ks ? ks : 1;
+#pragma unroll
+                    for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
+                        if (k < d3) op[k * kstep] = acc[G::OFF[cc] + k] * norm;
+                }
+            }
+        }
+    }
+};
+
 template <int L1, int GI>
 __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, float* __restrict__ tile, int node,
                                           int lane, bool valid, int beg, int deg_node, int maxdeg) {
@@ -179,52 +217,8 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
         }
         __builtin_amdgcn_wave_barrier();  // LDS is in order per wave: the next chunk's stores follow these reads
     }
-    if (valid) {
-        const float nn = a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node];
-        const float norm = a_scale_inv / sqrtf(nn);  // undoes the power-of-two scale of the A tile
-        float* orow = a.agg + (int64_t)node * a.d_mid;
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) {
-            if ((mask >> cc) & 1u) {
-                const int d3 = 2 * G::L3[cc] + 1;
-                float* op = orow + ge.out_off[cc] + u * d3;
-#pragma unroll
-                for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
-                    if (k < d3) op[k] = acc[G::OFF[cc] + k] * norm;
-            }
-        }
-    }
+    StoreAgg{}.store<G>(a, ge, acc, a_scale_inv, node, j, u, valid);   // (a_scale_inv undoes the power-of-two scale of the A tile)
 }
-
-
-// ---- what a unit does with its neighbour sums: one row slice of agg[N, d_mid] per (node, channel) --------------------
-// (Measured and removed, docs/LAB_NOTES.md: a vector epilogue -- channel lanes exchanging accumulators through LDS for
-// 16-byte stores, +8 % -- and non-temporal stores, +20 %: what costs is the 1.1 GB of distinct bytes per launch.)
-struct StoreAgg {
-    template <class G>
-    __device__ __forceinline__ void store(const Args& a, const GroupEntry& ge, const float* __restrict__ acc,
-                                          float a_scale_inv, int node, int j, int u, bool valid) const {
-        if (TPF_LAB_NO_STORE ? (valid && acc[0] == 12345.678f) : valid) {
-            const float nn = a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[node];
-            const float norm = a_scale_inv / sqrtf(nn);
-            float* orow = a.agg + (int64_t)node * a.d_mid;
-#pragma unroll
-            for (int cc = 0; cc < G::NC; ++cc) {
-                if ((ge.mask >> cc) & 1u) {
-                    const int d3 = 2 * G::L3[cc] + 1;
-                    // t_off[cc] == 0: the reference's "mul_ir" row, [channel][component].  Otherwise the component-major
-                    // row of plan.plan_agg_linear: t_off[cc] floats between components, the channel lanes side by side
-                    const int ks = ge.t_off[cc];
-                    float* op = orow + ge.out_off[cc] + (ks ? u : u * d3);
-                    const int kstep = ks ? ks : 1;
-#pragma unroll
-                    for (int k = 0; k < 2 * matten::CG_LMAX + 1; ++k)
-                        if (k < d3) op[k * kstep] = acc[G::OFF[cc] + k] * norm;
-                }
-            }
-        }
-    }
-};
 
 #define MATTEN_RGS_ARGS a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}
 #define MATTEN_RGS(L1, GI, TT, TD, P) \
@@ -306,13 +300,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
             else run_loader_only(a, cu_log2, stage, beg, deg, maxdeg);
             return;
         }
-        switch (ge.kind) {
+        switch (ge.kind & (KIND_MERGED - 1)) {
             TPF_FOR_EACH_GROUP(MATTEN_GROUP_CASE_SHARED)
             default: break;
         }
         return;
     }
-    switch (ge.kind) {
+    switch (ge.kind & (KIND_MERGED - 1)) {
         TPF_FOR_EACH_GROUP(MATTEN_GROUP_CASE)
         default: break;
     }

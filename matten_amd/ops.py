@@ -422,6 +422,9 @@ def split_a_tiles(w2p: torch.Tensor, group_entries) -> Tuple[torch.Tensor, torch
     tiles, inv = [], []
     for row in np.asarray(group_entries).reshape(-1, 32):
         w_base, n_mt = int(row[5]), int(row[7])
+        if int(row[0]) < 0 or n_mt == 0:   # second-half record of a merged entry (plan.TP_KIND_MERGED): no tiles of its own
+            inv.append(torch.ones((), device=dev))
+            continue
         A = w2p[k_idx][:, :, w_base:w_base + 16 * n_mt]              # [g, kk, mt*16 + c]
         A = A.reshape(4, 8, n_mt, 16).permute(2, 0, 3, 1)            # [mt, g, c, kk]
         amax = A.abs().max()

@@ -42,6 +42,14 @@ ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
 
 LIGHT_LMAX = 1   # scalar and vector input blocks: every chunk of a block cut at 8 channels keeps 8 lanes per node
 
+# matten_tp_fused: two ADJACENT input blocks of equal degree and multiplicity 2 (the model's 2x3o + 2x3e) share one
+# four-lane entry (16 nodes per wave, one 16-row stage, half the matrix tiles of two two-lane entries walking 32 nodes
+# each).  The entry's record carries the kind with TP_KIND_MERGED set, the union of the two halves' coupling masks and
+# the first half's output offsets; the record that FOLLOWS it (kind -1, never scheduled) carries the second half's mask
+# and offsets and, in its w_base word, the first half's own mask.  MATTEN_TP_MERGE=0 keeps one entry per block.
+TP_KIND_MERGED = 256
+TP_MERGE = os.environ.get("MATTEN_TP_MERGE", "1") != "0"
+
 FUSED_UNIT_SHARED = 1 << 24       # the unit's workgroup stages hidden features / harmonics once for its four waves
 FUSED_UNIT_LOADER_ONLY = 1 << 25  # padding unit of a shared workgroup: feeds the stage, contracts nothing
 FUSED_UNIT_PAIRED = 1 << 26       # shared workgroup of TWO entries on TWO consecutive node groups (waves 0,1 | 2,3)
@@ -60,10 +68,12 @@ def fused_workgroups(group_entries, order: Optional[str] = None):
     out = []
     classes: Dict[int, List[int]] = {}
     for e in range(len(ent)):                      # classes by lanes per node, in order of first appearance
+        if int(ent[e][0]) < 0:
+            continue                               # second-half record of a merged entry: not a unit
         classes.setdefault(int(ent[e][3]), []).append(e)
     for cu_log2, members in classes.items():
         npw = max(1, 64 >> cu_log2)
-        run = sorted(members, key=lambda e: int(ent[e][0]))
+        run = sorted(members, key=lambda e: int(ent[e][0]) & (TP_KIND_MERGED - 1))
         if order != "node" or cu_log2 < 1:
             out.append((cu_log2, run, "plain"))
         elif npw <= 16 and os.environ.get("MATTEN_FUSED_PAIRED", "1") != "0":
@@ -169,6 +179,8 @@ class UVUPlan:
     fused_unit_map: np.ndarray = None   # int32 [fused units per tile]: unit -> flags | entry << 8 | node group
     group_entry_paths: List[Dict[int, int]] = None  # per group entry: coupling c -> index into paths
     group_entry_u0: List[int] = None                # per group entry: first channel within its input block
+    group_entry_mul: List[int] = None               # per group entry record: channels of ITS input block it covers (a merged
+                                                    # entry's two records: 2 and 2; otherwise the entry's mul)
     # adjoint tables (matten_tp_backward)
     bw_col_meta: np.ndarray = None    # int32 [W, 4] {x_base, out_base, nnz_begin, nnz_count | y_off << 16}
     bw_nnz_ijk: np.ndarray = None     # uint8 [nnz, 4]
@@ -319,49 +331,97 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
     cands1 = sorted({TP_MAX_COLS_L1, TP_MAX_COLS}, reverse=True)
     cols_l0, cols_l1 = min(((c0, c1) for c0 in cands0 for c1 in cands1),
                            key=lambda c: (_padding(*c), -c[0] - c[1]))
-    for i_in1, plist in by_block.items():
+    gentry_mul: List[int] = []
+    # adjacent blocks of equal degree and multiplicity 2 share an entry (see TP_KIND_MERGED)
+    block_ids = list(by_block.keys())
+    partner: Dict[int, int] = {}
+    if TP_MERGE:
+        k = 0
+        while k + 1 < len(block_ids):
+            pa, pb = by_block[block_ids[k]][0], by_block[block_ids[k + 1]][0]
+            if (pa.mul == 2 and pb.mul == 2 and pa.l1 == pb.l1 and pa.l1 >= 2
+                    and pb.x_off == pa.x_off + pa.mul * (2 * pa.l1 + 1)):
+                partner[block_ids[k]] = block_ids[k + 1]
+                k += 2
+            else:
+                k += 1
+    second = set(partner.values())
+
+    def add_entry(l1, gi, combos, x_off, u0, mul_c, cu_log2, halves):
+        """halves: [(channels of the half, {(l2, l3): path})]; one half = a plain entry"""
+        nonlocal fused_a_tiles, lds_need
+        d1_ = 2 * l1 + 1
+        nodes_per_wave = max(1, 64 // (1 << cu_log2))
+        n_tiles16 = max(1, nodes_per_wave // 16)
+        # wave tile: [16 * n_tiles16 edge rows][weight columns + 4 (+ 32: units off the shared path park the
+        # edge's harmonics behind the weights; sized for them so that any unit order is valid)].  Without the 32
+        # a block needs 35.8 instead of 52 KB of LDS, but four blocks per CU do not pay (docs/LAB_NOTES.md round 2).
+        lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(combos)) // 16)) + 32 + 4))
+        n_mt = -(-(mul_c * len(combos)) // 16)  # 16-column MFMA tiles of the entry's weight block
+        merged = len(halves) == 2
+        rows = []
+        for h, (mul_h, present) in enumerate(halves):
+            row = [-1, 0, mul_h, cu_log2, 0, 0, 0, 0] + [0] * 24
+            mask = 0
+            for c, key in enumerate(combos):
+                if key in present:
+                    pth = present[key]
+                    mask |= 1 << c
+                    row[8 + 12 + c] = pth.out_off + u0 * (2 * pth.l3 + 1)
+            row[4] = mask
+            rows.append(row)
+        head = rows[0]
+        head[0] = l1 * TP_KIND_STRIDE + gi + (TP_KIND_MERGED if merged else 0)
+        head[1], head[2], head[5], head[6], head[7] = x_off + u0 * d1_, mul_c, len(fused_cols), fused_a_tiles, n_mt
+        if merged:
+            rows[1][5] = head[4]                 # the first half's own mask travels in the continuation record
+            head[4] |= rows[1][4]                # the walk contracts the union (absent couplings: zero weight columns)
+        fused_a_tiles += n_mt
+        # fused weight layout of this entry: [u][c] -> column of the reference's weight row (-1: absent)
+        ubase = 0
+        for (mul_h, present) in halves:
+            for uu in range(mul_h):
+                for key in combos:
+                    fused_cols.append(present[key].w_off + u0 + uu if key in present else -1)
+            ubase += mul_h
+        for r_, (mul_h, present) in zip(rows, halves):
+            gentries.append(r_)
+            gentry_paths.append({c: paths.index(present[key]) for c, key in enumerate(combos) if key in present})
+            gentry_u0.append(u0)
+            gentry_mul.append(mul_h)
+        gstart.append(gstart[-1] + -(-TP_TILE_NODES // nodes_per_wave))
+
+    for i_in1 in block_ids:
+        if i_in1 in second:
+            continue
+        plist = by_block[i_in1]
         l1, mul = plist[0].l1, plist[0].mul
-        d1 = 2 * l1 + 1
         for gi, (lo, hi) in enumerate(TP_GROUPS[l1]):
             combos = [(l2, l3) for l2 in range(lo, hi + 1) for l3 in range(abs(l1 - l2), min(4, l1 + l2) + 1)]
             present = {(p.l2, p.l3): p for p in plist if lo <= p.l2 <= hi}
-            if not present:
-                continue
-            # channels per entry: a power of two <= 64 whose [u][c] weight block stays <= 64 columns, so the
-            # fused kernel keeps the whole A operand (4 MFMA tiles x 8 k-steps) in registers
-            cap = _cap(l1, len(combos), cols_l0, cols_l1)
-            for u0 in range(0, mul, cap):
-                mul_c = min(cap, mul - u0)
-                # at least two lanes per node (a multiplicity-1 entry idles one of them): at most 32 nodes, i.e. two
-                # 16-edge MFMA tiles, per wave and chunk, which is what the fused kernel's shared LDS stage holds
-                cu_log2 = max(1, (mul_c - 1).bit_length())
-                if l1 <= LIGHT_LMAX and cap == 8 and mul >= 8:
-                    cu_log2 = 3  # (a ragged last chunk joins its block's lanes-per-node class: one workgroup shape per block)
-                nodes_per_wave = max(1, 64 // (1 << cu_log2))
-                n_tiles16 = max(1, nodes_per_wave // 16)
-                # wave tile: [16 * n_tiles16 edge rows][weight columns + 4 (+ 32: units off the shared path park the
-                # edge's harmonics behind the weights; sized for them so that any unit order is valid)].  Without the 32
-                # a block needs 35.8 instead of 52 KB of LDS, but four blocks per CU do not pay (docs/LAB_NOTES.md round 2).
-                lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(combos)) // 16)) + 32 + 4))
-                n_mt = -(-(mul_c * len(combos)) // 16)  # 16-column MFMA tiles of the entry's weight block
-                row = [l1 * TP_KIND_STRIDE + gi, plist[0].x_off + u0 * d1, mul_c, cu_log2, 0, len(fused_cols),
-                       fused_a_tiles, n_mt] + [0] * 24
-                fused_a_tiles += n_mt
-                mask = 0
-                for c, key in enumerate(combos):
-                    if key in present:
-                        pth = present[key]
-                        mask |= 1 << c
-                        row[8 + 12 + c] = pth.out_off + u0 * (2 * pth.l3 + 1)
-                row[4] = mask
-                # fused weight layout of this entry: [u][c] -> column of the reference's weight row (-1: absent)
-                for uu in range(mul_c):
-                    for key in combos:
-                        fused_cols.append(present[key].w_off + u0 + uu if key in present else -1)
-                gentries.append(row)
-                gentry_paths.append({c: paths.index(present[key]) for c, key in enumerate(combos) if key in present})
-                gentry_u0.append(u0)
-                gstart.append(gstart[-1] + -(-TP_TILE_NODES // nodes_per_wave))
+            todo = [(plist, present)]
+            if i_in1 in partner:
+                plist_b = by_block[partner[i_in1]]
+                present_b = {(p.l2, p.l3): p for p in plist_b if lo <= p.l2 <= hi}
+                if present and present_b and _cap(l1, len(combos), cols_l0, cols_l1) >= 4:
+                    add_entry(l1, gi, combos, plist[0].x_off, 0, 4, 2, [(2, present), (2, present_b)])
+                    continue
+                todo.append((plist_b, present_b))
+            for pl, pres in todo:
+                if not pres:
+                    continue
+                mul_b = pl[0].mul
+                # channels per entry: a power of two <= 64 whose [u][c] weight block stays <= 64 columns, so the
+                # fused kernel keeps the whole A operand (4 MFMA tiles x 8 k-steps) in registers
+                cap = _cap(l1, len(combos), cols_l0, cols_l1)
+                for u0 in range(0, mul_b, cap):
+                    mul_c = min(cap, mul_b - u0)
+                    # at least two lanes per node (a multiplicity-1 entry idles one of them): at most 32 nodes, i.e. two
+                    # 16-edge MFMA tiles, per wave and chunk, which is what the fused kernel's shared LDS stage holds
+                    cu_log2 = max(1, (mul_c - 1).bit_length())
+                    if l1 <= LIGHT_LMAX and cap == 8 and mul_b >= 8:
+                        cu_log2 = 3  # (a ragged last chunk joins its block's lanes-per-node class: one workgroup shape per block)
+                    add_entry(l1, gi, combos, pl[0].x_off, u0, mul_c, cu_log2, [(mul_c, pres)])
     # ---- adjoint tables: per weight column its path geometry and the non-zeros of its coupling tensor ----
     nnz_begin: Dict[Tuple[int, int, int], Tuple[int, int]] = {}
     nnz_ijk, nnz_c = [], []
@@ -406,7 +466,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         group_units_per_tile=gstart[-1], fused_cols=np.array(fused_cols, dtype=np.int64),
         fused_lds_floats_per_wave=(lds_need + 3) // 4 * 4,
         fused_unit_map=fused_unit_map(np.array(gentries, dtype=np.int64)), fused_a_tiles=fused_a_tiles,
-        group_entry_paths=gentry_paths, group_entry_u0=gentry_u0,
+        group_entry_paths=gentry_paths, group_entry_u0=gentry_u0, group_entry_mul=gentry_mul,
     )
 
 
@@ -821,7 +881,7 @@ def plan_agg_linear(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[AggLin
             ios = [io for io, (_, iro) in enumerate(irreps_out) if iro == ir3]
             if len(ios) != 1:
                 return None
-            pieces.setdefault(ios[0], []).append((e, c, int(ent[e][2])))
+            pieces.setdefault(ios[0], []).append((e, c, int(uvu.group_entry_mul[e])))
     if any(io not in pieces for io in range(len(irreps_out)) if irreps_out[io].dim > 0):
         return None
     io_rows, gather_parts, scale_parts = [], [], []

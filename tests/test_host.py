@@ -350,6 +350,8 @@ def test_fused_unit_map_covers_every_entry_and_node_group_once():
             work = [(int(v) >> 8 & 0xFFFF, int(v) & 255) for v in m if not int(v) & mp.FUSED_UNIT_LOADER_ONLY]
             want = set()
             for e, row in enumerate(p.group_entries):
+                if int(row[0]) < 0:
+                    continue   # second-half record of a merged entry (plan.TP_KIND_MERGED): carried by the unit before it
                 npw = max(1, 64 >> int(row[3]))
                 want |= {(e, r) for r in range(-(-mp.TP_TILE_NODES // npw))}
             assert len(work) == len(set(work)) and set(work) == want
@@ -390,6 +392,9 @@ def test_split_a_tiles_reconstructs_the_last_radial_layer():
     assert torch.isfinite(frag.float()).all()
     for e, row in enumerate(p.group_entries):
         w_base, t0, n_mt = int(row[5]), int(row[6]), int(row[7])
+        if int(row[0]) < 0:      # second-half record of a merged entry: no weight tiles of its own, scale 1
+            assert n_mt == 0 and float(inv[e]) == 1.0
+            continue
         assert n_mt == -(-(int(row[2]) * bin(int(row[4]) & 0xFFFFFFFF).count("1")) // 16) or n_mt >= 1
         block = w2p[:, w_base:w_base + 16 * n_mt]
         scale = 1.0 / inv[e].item()
@@ -718,7 +723,7 @@ def test_agg_linear_plan_reproduces_lin2_on_the_host():
         ent = ap.entries
         written = np.zeros(ap.ld, dtype=int)
         for e in range(len(ent)):
-            mul = int(ent[e][2])
+            mul = int(uvu.group_entry_mul[e])    # channels of the record OWN block (merged entries: 2 + 2 over two records)
             for c, pi in uvu.group_entry_paths[e].items():
                 pth = uvu.paths[pi]
                 d3 = 2 * pth.l3 + 1
