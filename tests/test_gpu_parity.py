@@ -1101,6 +1101,30 @@ def test_conv_fused_kernel_matches_two_kernel_path(monkeypatch, gate_fuse):
             close(outs[True][name], outs[False][name], 2e-5, f"{name}: conv-tile vs two-kernel")
 
 
+def test_conv_tile_kernel_on_the_n100_sample(golden_dir, monkeypatch):
+    """matten_conv_tile on the reference's n100 example set: 73 species in 473 atoms (almost every tile is a padded
+    single-species run of 1-16 nodes), degrees from 12 to 80, blocks of 64 nodes; against the two-kernel path and the oracle."""
+    from matten_amd.data.graph import average_num_neighbors, collate, crystal_graph
+    from matten_amd.nn import conv as pconv
+    from oracle.matten_ref import data as rdata
+
+    structs = rdata.structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))
+    graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
+    species = sorted({int(z) for s in structs for z in s["atomic_numbers"]})
+    ref, model = build_pair(PAPER, {"allowed_species": species, "average_num_neighbors": average_num_neighbors(graphs)},
+                            randomize_bn=True)
+    monkeypatch.setattr(pconv, "CONV_TILE_BLOCK", 64)
+    batch = collate(graphs, device=DEV)
+    outs = {}
+    with torch.no_grad():
+        for on in (True, False):
+            _tile_switch(monkeypatch, pconv, on)
+            outs[on] = model(dict(batch))[0]["elastic_tensor_full"].clone()
+        want = ref.decode(collate(graphs))
+    close_blocks(outs[True], outs[False].cpu(), rtol=5e-6, floor=2e-6, what="n100: conv-tile vs two-kernel")
+    close_blocks(outs[True], want, what="n100: conv-tile vs oracle", want64=_want64(ref, graphs))
+
+
 def test_conv_tile_kernel_at_the_bench_batch(monkeypatch):
     """the same comparison on the 1000-crystal fcc-64 batch of BASELINE configs[2] (64 000 nodes, 1.15 M edges; default
     block size, Gate + BatchNorm inside the kernel, dead-output view of the last layer): conv-tile vs two-kernel model
