@@ -350,7 +350,32 @@ def extras(dev):
         return loss
 
     t_l, _ = timed(large_step, 5, 10)
-    El = int(tbl["edge_index"].shape[1])
+    El, Nl = int(tbl["edge_index"].shape[1]), int(tbl["pos"].shape[0])
+    # kernel times of the large step (HIP events), for the roofline of its dominant kernel at a size that fills the GPU
+    ops.enable_event_timing(True)
+    for _ in range(3):
+        large_step()
+    torch.cuda.synchronize()
+    ev_l = {k: sum(v) / len(v) for k, v in ops.event_timings_ms().items()}
+    ops.enable_event_timing(False)
+    convs_l = [m for m in m_l.backbone.modules() if type(m).__name__ == "PointConv"]
+    convs_l = [m._view if (getattr(m, "_view", None) is not None) else m for m in convs_l]
+    bw_l = []
+    for c in convs_l:
+        pl = c.tp.plan
+        kk = next((k for k in ev_l if k.startswith("tp_backward") and k.endswith(f"d_mid={pl.d_mid}/d_in={pl.d_in}")), None)
+        if kk:
+            bw_l.append(((8.0 + 12.0 + 8.0 * pl.weight_numel + 4.0 * (2 * pl.d_in + pl.d_mid) / (El / Nl)) * El, ev_l[kk]))
+    roof_l = None
+    if bw_l:
+        bm, mm = sum(b for b, _ in bw_l) / len(bw_l), sum(t for _, t in bw_l) / len(bw_l)
+        roof_l = {"kernel": "tp_backward (adjoint of the uvu tensor product: reads w, writes dw; mean over the conv layers)",
+                  "bound": "hbm", "achieved": bm / (mm * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                  "frac": bm / (mm * 1e-3) / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_launch": bm,
+                  "avg_launch_ms": mm,
+                  "contract": "ids 8 + vector 12 + w read 4 W + dw written 4 W + (x, dx rows: 2 d_in; grad rows: d_mid) / deg per "
+                              "(edge, layer)"}
+    kern_l = {k: v for k, v in ev_l.items() if k.startswith(("tp_backward", "tp_scatter", "radial_mlp", "species_linear_wgrad"))}
     del m_l, opt_l, tbl
     Et, Nt = int(tb["edge_index"].shape[1]), int(tb["pos"].shape[0])
     rec = {
@@ -363,8 +388,9 @@ def extras(dev):
         "bf16": {"ms_per_step_hipgraph": 1e3 * t_b,
                  "what": "opt-in bf16 STORAGE of the per-edge tensors (radial weights w[E,W] and dL/dw), fp32 arithmetic, "
                          "node features / BatchNorm statistics / parameters fp32 (MATTEN_EDGE_STORAGE=bf16)"},
-        "batch2048": {"crystals": BL, "edges": El, "ms_per_step_eager": 1e3 * t_l, "crystals_per_sec": BL / t_l,
-                      "dtype": "f32", "data": "the n100 sample tiled to 2048 crystals"},
+        "batch2048": {"crystals": BL, "atoms": Nl, "edges": El, "ms_per_step_eager": 1e3 * t_l, "crystals_per_sec": BL / t_l,
+                      "dtype": "f32", "data": "the n100 sample tiled to 2048 crystals", "roofline": roof_l,
+                      "kernel_ms_per_launch": kern_l},
         "data": "synthetic-Zenodo-like (first 32 crystals of the reference's n100 example, random targets)",
         "note": "with l <= 2 features the 4e output has no path: 9 of the 21 components are identically 0 (SURVEY 8d)",
         "kernel_ms_per_launch_eager": {k: v for k, v in ev.items()
