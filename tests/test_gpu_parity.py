@@ -1318,15 +1318,23 @@ def test_species_linear_selfcheck_runs_and_detects_a_wrong_result(monkeypatch):
     selfcheck.check_species_linear(DEV)
 
 
-def test_fuzzed_models_on_poisoned_buffers_with_the_streaming_lin2_forced():
-    """tests/fuzz_models.py (random irreps / multiplicities / depth / normalisation on random small crystals, product vs
-    oracle) with every torch.empty buffer starting as NaN (NAN_EMPTY=1) and the component-major neighbour-sum row + the
-    streaming lin2 forced for every batch size (MATTEN_AGG_KM_MIN_ROWS=0): the mode that found the alignment holes of
-    non-power-of-two multiplicities (plan.plan_agg_linear); part of the regular GPU suite since round 4."""
+@pytest.mark.parametrize("mode", ["streaming_lin2", "conv_tile", "hub_pieces_of_3"])
+def test_fuzzed_models_on_poisoned_buffers(mode):
+    """tests/fuzz_models.py (random irreps / multiplicities incl. non-powers of two / depth / normalisation on random small
+    crystals, product vs oracle) with every torch.empty buffer starting as NaN (NAN_EMPTY=1) and one opt-in or
+    size-dependent path forced for every layer and batch size:
+      streaming_lin2   component-major neighbour sums + matten_agg_linear (the mode that found the alignment holes of
+                       non-power-of-two multiplicities, plan.plan_agg_linear; MATTEN_AGG_KM_MIN_ROWS=0)
+      conv_tile        matten_conv_tile on 32-node blocks (MATTEN_CONV_TILE=1, thresholds 0)
+      hub_pieces_of_3  every CSR segment walked in pieces of 3 edges (MATTEN_HUB_SPLIT_LEN=3)"""
     import subprocess
     import sys
 
-    env = dict(os.environ, NAN_EMPTY="1", MATTEN_AGG_KM_MIN_ROWS="0")
+    extra = {"streaming_lin2": {"MATTEN_AGG_KM_MIN_ROWS": "0"},
+             "conv_tile": {"MATTEN_CONV_TILE": "1", "MATTEN_CONV_TILE_MIN_ROWS": "0", "MATTEN_CONV_TILE_MIN_DMID": "0",
+                           "MATTEN_CONV_TILE_BLOCK": "32"},
+             "hub_pieces_of_3": {"MATTEN_HUB_SPLIT_LEN": "3"}}[mode]
+    env = dict(os.environ, NAN_EMPTY="1", **extra)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_models.py"), "24", "4"], env=env,
                        capture_output=True, text=True, timeout=900)
