@@ -356,11 +356,11 @@ int matten_segment_minmax_bwd(const float* dy, int64_t dim, const int64_t* arg, 
  * matten_tp_backward (fp32, or bf16 when dw_is_bf16; only the first w_cols columns are read as data).
  * Outputs are PARTIAL sums the caller adds up (fixed order, no atomics):
  *   part_small[matten_radial_mlp_bwd_small_slices(E)][nb_pad*32 + 32*32]: scale0 d/dW0p [nb_pad,32], scale1 d/dW1p [32,32]
- *   part_w2[matten_radial_mlp_bwd_w2_ranges(E)][32][w_pad]:               scale2 d/dW2p
+ *   part_w2[matten_radial_mlp_bwd_w2_ranges(E, w_pad)][32][w_pad]:        scale2 d/dW2p
  *   h2_scratch[E, 32]: workspace (the recomputed hidden features, written by the first kernel, read by the second)
  * ------------------------------------------------------------------------------------------ */
 int64_t matten_radial_mlp_bwd_small_slices(int64_t n_edges);
-int64_t matten_radial_mlp_bwd_w2_ranges(int64_t n_edges);
+int64_t matten_radial_mlp_bwd_w2_ranges(int64_t n_edges, int64_t w_pad);
 int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                           const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden, int w_pad,
                           int w_cols, const void* dw, int64_t dw_ld, int dw_is_bf16, float* h2_scratch,

@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -62,7 +62,7 @@ SIGNATURES = {
     "matten_species_linear": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
     "matten_species_linear_rows": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
     "matten_radial_mlp_bwd_small_slices": (c_int64, [c_int64]),
-    "matten_radial_mlp_bwd_w2_ranges": (c_int64, [c_int64]),
+    "matten_radial_mlp_bwd_w2_ranges": (c_int64, [c_int64, c_int64]),
     "matten_radial_mlp_bwd": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, P, c_int, c_int, c_int, P, c_int64,
                                       c_int, P, P, P, c_float, c_float, c_float, P, P, P]),
     "matten_radial_pack": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P, P, P, P]),

@@ -131,6 +131,10 @@ class RadialMLPFn(torch.autograd.Function):
         return d0[:nb], d1, d2[:, :W], None, None, None, None, None
 
 
+# training forward: batches below this many nodes walk their CSR segments in pieces (see TensorProductScatterFn.forward)
+TRAIN_HUB_SPLIT_MAX_ROWS = int(os.environ.get("MATTEN_HUB_SPLIT_MAX_ROWS_TRAIN", "65536"))
+
+
 class TensorProductScatterFn(torch.autograd.Function):
     """agg = sum_{edges -> n} uvu(x[src], Y, w) * norm   with w[E,W] in the reference column order."""
 
@@ -144,9 +148,21 @@ class TensorProductScatterFn(torch.autograd.Function):
         ctx.graph = (data[DataKey.AMD_SH], data[DataKey.AMD_SRC], data["_amd_dst_sorted"])
         ctx.out_csr = data.get("_amd_out_csr")
         ctx.save_for_backward(x, w_edge)
-        return ops.tp_paths(x, w_edge, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
-                            mod._tables.get("entries", dev), mod._tables.get("unit_start", dev), p.units_per_tile,
-                            p.d_mid, avg, num_neigh)
+        # the forward walks a destination node's CSR segment serially: irregular batches (real crystals: 30 neighbours on
+        # average, 80 in the one-atom cells) are cut into pieces of <= HUB_SPLIT_LEN edges and summed in order afterwards,
+        # like the inference forward of small batches (nn/utils.py); the adjoint is per edge and does not care
+        from .nn import utils as nnu
+
+        rowptr, split = data[DataKey.AMD_ROWPTR], None
+        if nnu.HUB_SPLIT_LEN > 0 and x.shape[0] < TRAIN_HUB_SPLIT_MAX_ROWS:
+            split = data.get("_amd_csr_split")
+            if split is None or split[3] is not rowptr:
+                split = ops.csr_split(rowptr, data[DataKey.AMD_SRC].shape[0], nnu.HUB_SPLIT_LEN, num_neigh) + (rowptr,)
+                data["_amd_csr_split"] = split
+        agg = ops.tp_paths(x, w_edge, data[DataKey.AMD_SH], rowptr if split is None else split[0], data[DataKey.AMD_SRC],
+                           mod._tables.get("entries", dev), mod._tables.get("unit_start", dev), p.units_per_tile,
+                           p.d_mid, avg, num_neigh if split is None else split[2])
+        return agg if split is None else ops.segment_reduce(agg, split[1], mean=False)
 
     @staticmethod
     def backward(ctx, g):

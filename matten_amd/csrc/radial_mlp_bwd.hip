@@ -32,18 +32,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HID = 32;
 constexpr int BW_WAVES = 4;
-constexpr int BW_TILES_MAX = 8;      // 16-edge tiles per wave of radial_mlp_bwd_edges: fewer on small graphs (see bw_tiles)
+#ifndef BW_WAVES_TARGET
+#define BW_WAVES_TARGET 2048   // waves' worth of tiles before a wave takes more than one
+#endif
+#ifndef BW_TILES_MAX_N
+#define BW_TILES_MAX_N 8
+#endif
+constexpr int BW_TILES_MAX = BW_TILES_MAX_N;      // 16-edge tiles per wave of radial_mlp_bwd_edges: fewer on small graphs (see bw_tiles)
 constexpr int TS = 17;               // row stride of the LDS transpose tiles (16 edges + 1: bank spread)
 constexpr int W2_RANGE_MAX = 4096;   // edges per partial sum of radial_mlp_bwd_w2: fewer on small graphs (see w2_range)
 
 // Small graphs (a training batch of 32 crystals has ~4 k edges) need the parallelism more than the short partial lists:
 // a wave takes one tile / a range is 256 edges until there are ~2000 waves' worth of work.
 inline int bw_tiles(int64_t n_edges) {
-    const int64_t t = n_edges / (16 * 2048);
+    const int64_t t = n_edges / (16 * BW_WAVES_TARGET);
     return (int)(t < 1 ? 1 : (t > BW_TILES_MAX ? BW_TILES_MAX : t));
 }
-inline int w2_range(int64_t n_edges) {
-    int64_t r = (n_edges / 64 + 15) / 16 * 16;
+// enough (column group, edge range) workgroups to fill the chip (~1024): a launch with 48 weight columns has ONE column
+// group, and 72 ranges of 4096 edges each left 184 CUs idle while three waves per workgroup walked 256 dependent steps
+// (0.31 ms for the first conv layer's 48 columns at 293 k edges; LAB_NOTES round 4)
+inline int w2_range(int64_t n_edges, int64_t w_pad) {
+    const int64_t groups = (w_pad + 16 * BW_WAVES - 1) / (16 * BW_WAVES);
+    int64_t r = (n_edges * groups / 1024 + 15) / 16 * 16;
     return (int)(r < 256 ? 256 : (r > W2_RANGE_MAX ? W2_RANGE_MAX : r));
 }
 
@@ -292,7 +302,9 @@ __global__ __launch_bounds__(1024) void radial_mlp_bwd_reduce(const float* __res
 extern "C" int64_t matten_radial_mlp_bwd_small_slices(int64_t n_edges) {
     return matten_cdiv(matten_cdiv(n_edges, bw_tiles(n_edges) * 16), BW_WAVES) * BW_WAVES;
 }
-extern "C" int64_t matten_radial_mlp_bwd_w2_ranges(int64_t n_edges) { return matten_cdiv(n_edges, w2_range(n_edges)); }
+extern "C" int64_t matten_radial_mlp_bwd_w2_ranges(int64_t n_edges, int64_t w_pad) {
+    return matten_cdiv(n_edges, w2_range(n_edges, w_pad));
+}
 
 extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, int n_basis, float r_start, float r_end,
                                      const float* w0p, int nb_pad, const float* w1p, const float* w2p, int hidden,
@@ -321,20 +333,20 @@ extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, 
 #undef LAUNCH_K
 #undef LAUNCH
     MATTEN_LAUNCH_CHECK();
-    dim3 grid2((unsigned)matten_cdiv(w_pad, 16 * BW_WAVES), (unsigned)matten_radial_mlp_bwd_w2_ranges(n_edges));
+    dim3 grid2((unsigned)matten_cdiv(w_pad, 16 * BW_WAVES), (unsigned)matten_radial_mlp_bwd_w2_ranges(n_edges, w_pad));
     if (dw_is_bf16)
         radial_mlp_bwd_w2<true><<<grid2, BW_WAVES * 64, 0, stream>>>(h2_scratch, dw, dw_ld, n_edges, w_pad, part_w2,
-                                                                     w2_range(n_edges), scale2);
+                                                                     w2_range(n_edges, w_pad), scale2);
     else
         radial_mlp_bwd_w2<false><<<grid2, BW_WAVES * 64, 0, stream>>>(h2_scratch, dw, dw_ld, n_edges, w_pad, part_w2,
-                                                                      w2_range(n_edges), scale2);
+                                                                      w2_range(n_edges, w_pad), scale2);
     MATTEN_LAUNCH_CHECK();
     if (grad_small || grad_w2) {   // the final, ordered sums in the same call (both or neither)
         if (!grad_small || !grad_w2) return MATTEN_EINVAL;
         const int small_len = nb_pad * HID + HID * HID, w2_len = HID * w_pad;
         radial_mlp_bwd_reduce<<<dim3((unsigned)matten_cdiv(std::max(small_len, w2_len), 64), 2), 1024, 0, stream>>>(
             part_small, matten_radial_mlp_bwd_small_slices(n_edges), small_len, part_w2,
-            matten_radial_mlp_bwd_w2_ranges(n_edges), w2_len, grad_small, grad_w2);
+            matten_radial_mlp_bwd_w2_ranges(n_edges, w_pad), w2_len, grad_small, grad_w2);
         MATTEN_LAUNCH_CHECK();
     }
     return MATTEN_OK;

@@ -315,7 +315,7 @@ def radial_mlp_bwd(geom_sorted, n_basis: int, r_start: float, r_end: float, w0p,
     nb_pad, hidden = w0p.shape
     w_pad = w2p.shape[1]
     dev = geom_sorted.device
-    n_small, n_rng = lib.matten_radial_mlp_bwd_small_slices(E), lib.matten_radial_mlp_bwd_w2_ranges(E)
+    n_small, n_rng = lib.matten_radial_mlp_bwd_small_slices(E), lib.matten_radial_mlp_bwd_w2_ranges(E, w_pad)
     h2 = torch.empty(E, hidden, dtype=torch.float32, device=dev)
     part_small = torch.empty(max(n_small, 1), nb_pad * hidden + hidden * hidden, dtype=torch.float32, device=dev)
     part_w2 = torch.empty(max(n_rng, 1), hidden, w_pad, dtype=torch.float32, device=dev)
@@ -344,7 +344,8 @@ def tp_paths(x, w_edge, sh_sorted, rowptr, src_sorted, entries, unit_start, unit
     x = _need(x, torch.float32, "node_features")
     w_edge = _edge_dtype(w_edge, "w_edge")
     sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
-    N, d_in = x.shape
+    # destination rows = segments of rowptr (virtual nodes when the segments were cut by ops.csr_split); x rows are sources
+    N, d_in = rowptr.shape[0] - 1, x.shape[1]
     if num_neigh is not None:
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
     agg = torch.empty(N, d_mid, dtype=torch.float32, device=x.device)

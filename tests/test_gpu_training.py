@@ -81,9 +81,19 @@ def test_training_step_matches_oracle_autograd(golden_dir, hp_name):
 
     opt_r.step()
     opt_m.step()
+    # Adam's first step moves every element by lr * g' / (|g'| + eps) = lr * sign(g'), g' = g + weight_decay * p: an
+    # element whose g' lies inside the rounding noise between two fp32 evaluations of the same sum over ~10^4 edges (the
+    # gradients above agree to 3e-3 of the tensor's largest; measured up to 1.8e-3 for the first radial MLP) may move by
+    # 2 lr either way in ANY two correct implementations -- which ones do depends on the summation order, e.g. on the
+    # length of the CSR pieces the forward walks.  Compare where the reference gradient is well above that noise;
+    # elsewhere only require that the step stayed within +- lr.
     for k, p in ref.named_parameters():
         if p.grad is not None:
-            _close(named[k], p, 2e-3, f"param after Adam {k}")
+            g = grads_r[k] + 1e-5 * (p.detach() + 0.0)      # (p is already stepped; the shift of 1e-2 * 1e-5 is far below the mask)
+            solid = (g.abs() >= 1e-2 * grads_r[k].abs().max()).to(named[k].device)
+            got, want = named[k].detach(), p.detach().to(named[k].device)
+            _close(torch.where(solid, got, want), want, 2e-3, f"param after Adam {k}")
+            assert ((got - want).abs() <= 2.0 * 1e-2 + 1e-6).all(), k
 
 
 def test_eval_after_training_uses_running_stats(golden_dir):
