@@ -270,29 +270,32 @@ __global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_w2(const float* 
         for (int r = 0; r < 4; ++r) out[(int64_t)(16 * t + 4 * g + r) * w_pad + q0 + c] = acc[t][r] * s2;
 }
 
-// out[i] = sum over the n partial rows part[s][i] in a FIXED order: a workgroup owns 64 columns, its 16 thread groups take
-// every 16th row each (sequentially), and group 0 adds the 16 group sums in group order.  grid.y = 0: the small
-// gradients, 1: dW2.
-__global__ __launch_bounds__(1024) void radial_mlp_bwd_reduce(const float* __restrict__ part_small, int64_t n_small,
+// out[i] = sum over the n partial rows part[s][i] in a FIXED order: a workgroup owns RED_COLS columns, its RED_GROUPS thread
+// groups take every RED_GROUPS-th row each (sequentially), and group 0 adds the group sums in group order.  grid.y = 0: the
+// small gradients, 1: dW2.  (16 columns x 64 groups: with ~1000 partial rows -- radial_mlp_bwd_w2 cuts the edges into as
+// many ranges as fill the chip -- a thread adds 16 rows instead of 64: the kernel is a chain of dependent loads.)
+constexpr int RED_COLS = 16, RED_GROUPS = 64;
+__global__ __launch_bounds__(RED_COLS * RED_GROUPS) void radial_mlp_bwd_reduce(const float* __restrict__ part_small, int64_t n_small,
                                                               int small_len, const float* __restrict__ part_w2,
                                                               int64_t n_rng, int w2_len, float* __restrict__ out_small,
                                                               float* __restrict__ out_w2) {
-    __shared__ float red[16][64];
+    __shared__ float red[RED_GROUPS][RED_COLS];
     const float* part = blockIdx.y ? part_w2 : part_small;
     const int64_t n = blockIdx.y ? n_rng : n_small;
     const int len = blockIdx.y ? w2_len : small_len;
     float* out = blockIdx.y ? out_w2 : out_small;
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-    if (blockIdx.x * 64 >= len) return;
+    const int lc = threadIdx.x % RED_COLS, grp = threadIdx.x / RED_COLS;
+    const int col = blockIdx.x * RED_COLS + lc;
+    if (blockIdx.x * RED_COLS >= len) return;
     float v = 0.0f;
     if (col < len)
-        for (int64_t s = grp; s < n; s += 16) v += part[s * len + col];
-    red[grp][threadIdx.x & 63] = v;
+        for (int64_t s = grp; s < n; s += RED_GROUPS) v += part[s * len + col];
+    red[grp][lc] = v;
     __syncthreads();
     if (grp == 0 && col < len) {
-        float t = red[0][threadIdx.x];
-#pragma unroll
-        for (int gq = 1; gq < 16; ++gq) t += red[gq][threadIdx.x];
+        float t = red[0][lc];
+#pragma unroll 8
+        for (int gq = 1; gq < RED_GROUPS; ++gq) t += red[gq][lc];
         out[col] = t;
     }
 }
@@ -344,7 +347,7 @@ extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, 
     if (grad_small || grad_w2) {   // the final, ordered sums in the same call (both or neither)
         if (!grad_small || !grad_w2) return MATTEN_EINVAL;
         const int small_len = nb_pad * HID + HID * HID, w2_len = HID * w_pad;
-        radial_mlp_bwd_reduce<<<dim3((unsigned)matten_cdiv(std::max(small_len, w2_len), 64), 2), 1024, 0, stream>>>(
+        radial_mlp_bwd_reduce<<<dim3((unsigned)matten_cdiv(std::max(small_len, w2_len), RED_COLS), 2), RED_COLS * RED_GROUPS, 0, stream>>>(
             part_small, matten_radial_mlp_bwd_small_slices(n_edges), small_len, part_w2,
             matten_radial_mlp_bwd_w2_ranges(n_edges, w_pad), w2_len, grad_small, grad_w2);
         MATTEN_LAUNCH_CHECK();
