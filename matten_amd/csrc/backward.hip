@@ -131,7 +131,7 @@ __global__ void tp_backward_grouped_kernel(const float* __restrict__ x, int d_in
 // channels w as N and four rows of the species per instruction (lane group g = row), one instruction per component k.
 // A workgroup owns (species, row slice, segment); its four waves take every fourth row quad and keep up to 4 x 4 output
 // tiles in registers, then add their fragments through LDS in wave order: the summation order is fixed (no atomics).
-// With several row slices per species the slices write partial sums that wgrad_reduce_kernel adds in slice order.
+// At large batches a species' rows are cut into slices whose partial sums wgrad_reduce_kernel adds in slice order.
 // (The first version was one thread per weight walking the species' rows with 4-byte strided reads: 2.0 ms of an
 // 11 ms batch-2048 step.)
 // ------------------------------------------------------------------------------------------------
@@ -143,6 +143,77 @@ typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
 #define MATTEN_WG_TB 4
 #endif
 constexpr int WG_TB = MATTEN_WG_TB;   // tile block: WG_TB x WG_TB tiles of 16 x 16 weights per pass over the rows
+// lab switches (tools/wgrad_ablate.sh): only with -DMATTEN_LAB
+#if !defined(MATTEN_LAB) && (defined(MATTEN_WG_NO_MFMA) || defined(MATTEN_WG_NO_LOAD) || defined(MATTEN_WG_FORCE_SLICES))
+#error "MATTEN_WG_* ablation switches need -DMATTEN_LAB"
+#endif
+#ifdef MATTEN_WG_NO_MFMA
+#define WG_MFMA(a, b, c) ((c) + wg_f32x4{(a) * (b), 0.f, 0.f, 0.f})
+#else
+#define WG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+#ifdef MATTEN_WG_NO_LOAD
+#define WG_LD(p) ((float)(uintptr_t)(&(p)) * 1e-9f)
+#else
+#define WG_LD(p) (p)
+#endif
+// Row slices.  Real data sets are far from uniform over species (the commonest of the 73 elements of the reference's
+// sample owns 7 % of the rows, the rarest 0.2 %), and a workgroup costs ~12 ns of dispatch even when it leaves at once
+// (measured: 16 slices for every species = 7008 workgroups per call, 84 us of pure dispatch), so a species' rows are cut
+// into slices of WG_SLICE_ROWS rows and the grid is the COMPACT list of (species, slice) items: item i belongs to the
+// species whose running slice count covers i (every species owns at least one item and writes zeros when it has no
+// rows).  n_items <= n_species + n_rows / WG_SLICE_ROWS, the grid size; the excess items leave.
+#ifndef MATTEN_WG_SLICE_ROWS
+#define MATTEN_WG_SLICE_ROWS 128
+#endif
+constexpr int WG_SLICE_ROWS = MATTEN_WG_SLICE_ROWS;
+constexpr int WG_SLICED_MIN_ROWS = 4 * WG_SLICE_ROWS;   // below: one workgroup per species writing dwp directly
+__host__ __device__ __forceinline__ int wgrad_items_of(int count) {
+    return count > WG_SLICE_ROWS ? (count + WG_SLICE_ROWS - 1) / WG_SLICE_ROWS : 1;
+}
+// (species, slice) of item `item`, found by wave 0 with a 64-wide prefix sum over the species' item counts; species -1:
+// no such item.  seg == nullptr: one species of n_rows rows.
+__device__ __forceinline__ int2 wgrad_find_item(const int32_t* __restrict__ seg, int n_species, int n_rows, int item) {
+    __shared__ int2 found;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int run = 0;
+        int2 f = make_int2(-1, 0);
+        for (int base = 0; base < n_species; base += 64) {
+            const int t = base + lane;
+            const int cnt = t < n_species ? (seg ? seg[t + 1] - seg[t] : n_rows) : 0;
+            const int mine = t < n_species ? wgrad_items_of(cnt) : 0;
+            int incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            const int rel = item - run;
+            const unsigned long long hit = __ballot(t < n_species && rel >= incl - mine && rel < incl);
+            if (hit) {
+                const int l = __ffsll((long long)hit) - 1;
+                f = make_int2(base + l, rel - (__shfl(incl, l, 64) - __shfl(mine, l, 64)));
+                break;
+            }
+            run += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) found = f;
+    }
+    __syncthreads();
+    return found;
+}
+// first item of species s (the sum of the item counts before it) -- wgrad_reduce_kernel
+__device__ __forceinline__ int wgrad_first_item(const int32_t* __restrict__ seg, int n_rows, int s) {
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int v = 0;
+    for (int t = threadIdx.x; t < s; t += blockDim.x) v += wgrad_items_of(seg ? seg[t + 1] - seg[t] : n_rows);
+    if (v) atomicAdd(&total, v);   // integers: the order does not matter
+    __syncthreads();
+    return total;
+}
 
 // rows lo + 4 wave + g, + 16, ... of the slice: D = 2 l + 1 components per channel (0: run-time count)
 template <int D>
@@ -165,12 +236,12 @@ __device__ __forceinline__ void wgrad_rows(const float* __restrict__ x, int d_in
 #pragma unroll
                 for (int i = 0; i < WG_TB; ++i) {
                     const int u = 16 * (mt0 + i) + c;
-                    a[k][i] = (ok && u < L.mul_in) ? xr[u * D + k] : 0.0f;
+                    a[k][i] = (ok && u < L.mul_in) ? WG_LD(xr[u * D + k]) : 0.0f;
                 }
 #pragma unroll
                 for (int j = 0; j < WG_TB; ++j) {
                     const int w = 16 * (nt0 + j) + c;
-                    b[k][j] = (ok && w < L.mo) ? gr[w * D + k] : 0.0f;
+                    b[k][j] = (ok && w < L.mo) ? WG_LD(gr[w * D + k]) : 0.0f;
                 }
             }
 #pragma unroll
@@ -180,7 +251,7 @@ __device__ __forceinline__ void wgrad_rows(const float* __restrict__ x, int d_in
                     if (mt0 + i < MT && nt0 + j < NT) {
 #pragma unroll
                         for (int k = 0; k < D; ++k)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][i], b[k][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = WG_MFMA(a[k][i], b[k][j], acc[i][j]);
                     }
         } else {
             for (int k = 0; k < d; ++k) {
@@ -188,19 +259,19 @@ __device__ __forceinline__ void wgrad_rows(const float* __restrict__ x, int d_in
 #pragma unroll
                 for (int i = 0; i < WG_TB; ++i) {
                     const int u = 16 * (mt0 + i) + c;
-                    a[i] = (ok && u < L.mul_in) ? xr[u * d + k] : 0.0f;
+                    a[i] = (ok && u < L.mul_in) ? WG_LD(xr[u * d + k]) : 0.0f;
                 }
 #pragma unroll
                 for (int j = 0; j < WG_TB; ++j) {
                     const int w = 16 * (nt0 + j) + c;
-                    b[j] = (ok && w < L.mo) ? gr[w * d + k] : 0.0f;
+                    b[j] = (ok && w < L.mo) ? WG_LD(gr[w * d + k]) : 0.0f;
                 }
 #pragma unroll
                 for (int i = 0; i < WG_TB; ++i)
 #pragma unroll
                     for (int j = 0; j < WG_TB; ++j)
                         if (mt0 + i < MT && nt0 + j < NT)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = WG_MFMA(a[i], b[j], acc[i][j]);
             }
         }
     }
@@ -211,21 +282,26 @@ __global__ __launch_bounds__(256) void species_linear_wgrad_kernel(const float* 
                                                                    const int32_t* __restrict__ order,
                                                                    const int32_t* __restrict__ seg, int n_rows,
                                                                    const LinSeg* __restrict__ segs, int w_stride,
-                                                                   float* __restrict__ out, int slices) {
+                                                                   float* __restrict__ out, int n_species, int sliced) {
     __shared__ __attribute__((aligned(16))) float red[4][256];
-    const int n_species = (int)gridDim.x / slices;
-    const int s = (int)blockIdx.x / slices, z = (int)blockIdx.x - s * slices;
+    // sliced != 0: blockIdx.x is an item of the compact (species, slice) list and the workgroup writes partial row
+    // blockIdx.x; else blockIdx.x is the species and the workgroup writes dwp
+    int s = blockIdx.x, z = 0;
+    if (sliced) {
+        const int2 it = wgrad_find_item(seg, n_species, n_rows, (int)blockIdx.x);
+        if (it.x < 0) return;
+        s = it.x, z = it.y;
+    }
     const LinSeg L = segs[blockIdx.y];
     int lo = seg ? seg[s] : 0, hi = seg ? seg[s + 1] : n_rows;
-    if (slices > 1) {
-        const int per = (hi - lo + slices - 1) / slices;
-        lo += z * per;
-        hi = min(hi, lo + per);
+    if (sliced) {
+        lo += z * WG_SLICE_ROWS;
+        hi = min(hi, lo + WG_SLICE_ROWS);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int MT = (L.mul_in + 15) >> 4, NT = (L.mo + 15) >> 4;
-    float* outp = out + ((int64_t)z * n_species + s) * w_stride + L.w_off;
+    float* outp = out + (int64_t)(sliced ? (int)blockIdx.x : s) * w_stride + L.w_off;
     for (int mt0 = 0; mt0 < MT; mt0 += WG_TB) {
         for (int nt0 = 0; nt0 < NT; nt0 += WG_TB) {
             wg_f32x4 acc[WG_TB][WG_TB];
@@ -260,14 +336,17 @@ __global__ __launch_bounds__(256) void species_linear_wgrad_kernel(const float* 
     }
 }
 
-// dWp[s, q] = sum over slices z (in order) of partial[z, s, q], for the weights of this call's segments
+// dWp[s, q] = sum over the species' items (in slice order) of partial[item, q], for the weights of this call's segments
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const LinSeg* __restrict__ segs, int w_stride,
-                                    int slices, float* __restrict__ dwp) {
-    const int s = blockIdx.x, n_species = gridDim.x;
+                                    const int32_t* __restrict__ seg, int n_rows, float* __restrict__ dwp) {
+    const int s = blockIdx.x;
     const LinSeg L = segs[blockIdx.y];
+    const int first = wgrad_first_item(seg, n_rows, s);
+    const int nz = wgrad_items_of(seg ? seg[s + 1] - seg[s] : n_rows);
+    const float* p0 = partial + (int64_t)first * w_stride + L.w_off;
     for (int p = threadIdx.x; p < L.mul_in * L.mo; p += blockDim.x) {
         float v = 0.0f;
-        for (int z = 0; z < slices; ++z) v += partial[((int64_t)z * n_species + s) * w_stride + L.w_off + p];
+        for (int z = 0; z < nz; ++z) v += p0[(int64_t)z * w_stride + p];
         dwp[(int64_t)s * w_stride + L.w_off + p] = v;
     }
 }
@@ -408,7 +487,18 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, int dim, int64_t n_
     }
     float s = 0.0f;
     if (ch.z) {
-        for (int64_t n = threadIdx.x; n < n_rows; n += blockDim.x) s += x[n * dim + ch.x];
+        {   // four rows in flight per thread (a thread's rows are dim floats apart: every load is its own cache line, the
+            // loop is a chain of load latencies), partial sums combined in a fixed order
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            const int64_t step = blockDim.x;
+            int64_t n = threadIdx.x;
+            for (; n + 3 * step < n_rows; n += 4 * step) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s4[r] += x[(n + r * step) * dim + ch.x];
+            }
+            for (int r = 0; n < n_rows; n += step, ++r) s4[r] += x[n * dim + ch.x];
+            s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        }
         red[threadIdx.x] = s;
         __syncthreads();
         for (int o = blockDim.x / 2; o > 0; o >>= 1) {
@@ -420,11 +510,25 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, int dim, int64_t n_
     }
     const float mu = ch.z ? s : 0.0f;
     float q = 0.0f;
-    for (int64_t n = threadIdx.x; n < n_rows; n += blockDim.x)
-        for (int k = 0; k < d; ++k) {
-            float v = x[n * dim + ch.x + k] - mu;
-            q = fmaf(v, v, q);
-        }
+    {
+        float q4[4] = {0.f, 0.f, 0.f, 0.f};
+        const int64_t step = blockDim.x;
+        int64_t n = threadIdx.x;
+        for (; n + 3 * step < n_rows; n += 4 * step)
+            for (int k = 0; k < d; ++k) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = x[(n + r * step) * dim + ch.x + k] - mu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q4[r] = fmaf(v[r], v[r], q4[r]);
+            }
+        for (int r = 0; n < n_rows; n += step, ++r)
+            for (int k = 0; k < d; ++k) {
+                const float v = x[n * dim + ch.x + k] - mu;
+                q4[r] = fmaf(v, v, q4[r]);
+            }
+        q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+    }
     red[threadIdx.x] = q;
     __syncthreads();
     for (int o = blockDim.x / 2; o > 0; o >>= 1) {
@@ -479,12 +583,33 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* _
     }
     const float mu = mean[c];
     float a = 0.0f, b = 0.0f;
-    for (int64_t n = threadIdx.x; n < n_rows; n += blockDim.x)
-        for (int k = 0; k < ch.y; ++k) {
-            const float g = dy[n * dim + ch.x + k];
-            a = fmaf(g, x[n * dim + ch.x + k] - mu, a);
-            b += g;
-        }
+    {   // four rows in flight per thread (see bn_stats_kernel), partial sums combined in a fixed order
+        float a4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+        const int64_t step = blockDim.x;
+        int64_t n = threadIdx.x;
+        for (; n + 3 * step < n_rows; n += 4 * step)
+            for (int k = 0; k < ch.y; ++k) {
+                float g[4], xv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    g[r] = dy[(n + r * step) * dim + ch.x + k];
+                    xv[r] = x[(n + r * step) * dim + ch.x + k];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a4[r] = fmaf(g[r], xv[r] - mu, a4[r]);
+                    b4[r] += g[r];
+                }
+            }
+        for (int r = 0; n < n_rows; n += step, ++r)
+            for (int k = 0; k < ch.y; ++k) {
+                const float g = dy[n * dim + ch.x + k];
+                a4[r] = fmaf(g, x[n * dim + ch.x + k] - mu, a4[r]);
+                b4[r] += g;
+            }
+        a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+    }
     ra[threadIdx.x] = a;
     rb[threadIdx.x] = b;
     __syncthreads();
@@ -583,11 +708,16 @@ extern "C" int matten_tp_backward(const float* x, int64_t d_in, const void* w_ed
     return MATTEN_OK;
 }
 
-// Row slices per species (~128 rows each, at most 64).  ONE slice: the workgroups write dwp directly; several: they write
-// partial[slices, n_species, w_stride] and a second launch adds the slices in order.  Either way every packed weight
-// of the table's segments is written exactly once (dwp need not be initialised) and the summation order is fixed.
+// Number of partial-sum rows (of w_stride floats) a call needs.  ONE: none -- one workgroup per species writes dwp
+// directly; more: the bound of the compact (species, slice) item list (see WG_SLICE_ROWS), whose workgroups write
+// partial[item, w_stride] and a second launch adds a species' items in order.  Either way every packed weight of the
+// table's segments is written exactly once (dwp need not be initialised) and the summation order is fixed.
 extern "C" int64_t matten_species_linear_wgrad_slices(int64_t n_rows, int64_t n_species) {
-    return std::min<int64_t>(64, std::max<int64_t>(1, n_rows / (128 * std::max<int64_t>(1, n_species))));
+#ifdef MATTEN_WG_FORCE_SLICES
+    if (MATTEN_WG_FORCE_SLICES == 1) return 1;
+#endif
+    if (n_rows < WG_SLICED_MIN_ROWS) return 1;
+    return std::max<int64_t>(1, n_species) + n_rows / WG_SLICE_ROWS;
 }
 
 extern "C" int matten_species_linear_wgrad(const float* x, int64_t d_in, const float* dy, int64_t d_out,
@@ -600,17 +730,17 @@ extern "C" int matten_species_linear_wgrad(const float* x, int64_t d_in, const f
     if (!x || !dy || !segs || !dwp) return MATTEN_EINVAL;
     if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
     if (!order && n_species != 1) return MATTEN_EINVAL;
-    const int64_t slices = matten_species_linear_wgrad_slices(n_rows, n_species);
-    if (slices > 1 && !partial) return MATTEN_EINVAL;
-    if (n_species * slices >= ((int64_t)1 << 31) || n_segs > 65535) return MATTEN_EINVAL;
-    dim3 grid((unsigned)(n_species * slices), (unsigned)n_segs);
+    const int64_t items = matten_species_linear_wgrad_slices(n_rows, n_species);
+    if (items > 1 && !partial) return MATTEN_EINVAL;
+    if (items >= ((int64_t)1 << 31) || n_species >= ((int64_t)1 << 31) || n_segs > 65535) return MATTEN_EINVAL;
+    dim3 grid((unsigned)(items > 1 ? items : n_species), (unsigned)n_segs);
     species_linear_wgrad_kernel<<<grid, 256, 0, stream>>>(x, (int)d_in, dy, (int)d_out, order, seg, (int)n_rows,
-                                                          (const LinSeg*)segs, (int)w_stride, slices > 1 ? partial : dwp,
-                                                          (int)slices);
+                                                          (const LinSeg*)segs, (int)w_stride, items > 1 ? partial : dwp,
+                                                          (int)n_species, items > 1 ? 1 : 0);
     MATTEN_LAUNCH_CHECK();
-    if (slices > 1) {
+    if (items > 1) {
         wgrad_reduce_kernel<<<dim3((unsigned)n_species, (unsigned)n_segs), 256, 0, stream>>>(
-            partial, (const LinSeg*)segs, (int)w_stride, (int)slices, dwp);
+            partial, (const LinSeg*)segs, (int)w_stride, seg, (int)n_rows, dwp);
         MATTEN_LAUNCH_CHECK();
     }
     return MATTEN_OK;

@@ -766,10 +766,10 @@ def species_linear_wgrad(x, dy, species_order, n_species: int, seg_tables, w_str
     dy = _need(dy, torch.float32, "dy")
     order, seg = species_order if species_order is not None else (None, None)
     # every packed weight is written exactly once (nothing to pre-zero); large batches cut the species' rows into slices
-    # whose partial sums the library adds in slice order
-    slices = lib.matten_species_linear_wgrad_slices(x.shape[0], n_species)
+    # (a compact list of (species, slice) items) whose partial sums the library adds in slice order
+    items = lib.matten_species_linear_wgrad_slices(x.shape[0], n_species)
     dwp = torch.empty(n_species, w_stride, dtype=torch.float32, device=x.device)
-    partial = torch.empty(slices, n_species, w_stride, dtype=torch.float32, device=x.device) if slices > 1 else None
+    partial = torch.empty(items, w_stride, dtype=torch.float32, device=x.device) if items > 1 else None
     for segs in seg_tables:
         _lib.check(
             lib.matten_species_linear_wgrad(_ptr(x), x.shape[1], _ptr(dy), dy.shape[1], _ptr(order), _ptr(seg),
