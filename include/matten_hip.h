@@ -481,14 +481,20 @@ int matten_gate_bwd(const float* x, int64_t d_in, const int32_t* meta, int64_t d
  *   chan[n_chan,4] int32 {column offset, 2l+1, is_0e, index into bias / running_mean or -1}; col2chan[dim]
  *   fwd: mean[c] (0e only, else 0), nu[c] = mean_n mean_k (x-mean)^2, y = (x-mean) rsqrt(nu+eps) weight[c] (+ bias)
  *   bwd: dx (A, B are [n_chan] scratch that return sum dy (x-mean) and sum dy: dweight = A rsqrt(nu+eps), dbias = B) */
+int64_t matten_bn_scratch_floats(int64_t n_rows, int64_t dim);
 int matten_bn_train_fwd(const float* x, int64_t dim, int64_t n_rows, const int32_t* col2chan, const int32_t* chan,
                         int64_t n_chan, const float* weight, const float* bias, float eps, float* mean, float* nu,
-                        float* y, float* running_mean, float* running_var, float momentum, matten_stream_t stream);
+                        float* y, float* running_mean, float* running_var, float momentum, float* scratch,
+                        matten_stream_t stream);
+/* scratch [matten_bn_scratch_floats(n_rows, dim)] (fwd and bwd; may be NULL when that is 0): large batches reduce in two
+ * stages, per-(16-row block, column) partial records first, merged per channel in a fixed order (0e channels by the
+ * pairwise mean / squared-deviation update, so no E[x^2] - mean^2 cancellation) */
 /* running_mean [number of 0e channels] / running_var [n_chan] (both or neither, may be NULL): updated in place by the
  * statistics kernel, running = (1 - momentum) running + momentum batch (e3nn BatchNorm in training mode) */
 int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows, const int32_t* col2chan,
                         const int32_t* chan, int64_t n_chan, const float* mean, const float* nu, const float* weight,
-                        float eps, float* A, float* B, float* dx, float* dweight, float* dbias, matten_stream_t stream);
+                        float eps, float* A, float* B, float* dx, float* dweight, float* dbias, float* scratch,
+                        matten_stream_t stream);
 /* dweight [n_chan] = A rsqrt(nu + eps), dbias [number of 0e channels] = B of the 0e channels (both or neither, may be NULL) */
 
 /* e3nn NormActivation as the reference configures it (nn/utils.py:142-150: nonlinearity_type "norm"; normalize = True,

@@ -78,8 +78,9 @@ SIGNATURES = {
     "matten_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float, P]),
     "matten_species_linear_wgrad": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int64, P, c_int64, c_int64, P, P, P]),
     "matten_gate_bwd": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, P, P]),
-    "matten_bn_train_fwd": (c_int, [P, c_int64, c_int64, P, P, c_int64, P, P, c_float, P, P, P, P, P, c_float, P]),
-    "matten_bn_train_bwd": (c_int, [P, P, c_int64, c_int64, P, P, c_int64, P, P, P, c_float, P, P, P, P, P, P]),
+    "matten_bn_scratch_floats": (c_int64, [c_int64, c_int64]),
+    "matten_bn_train_fwd": (c_int, [P, c_int64, c_int64, P, P, c_int64, P, P, c_float, P, P, P, P, P, c_float, P, P]),
+    "matten_bn_train_bwd": (c_int, [P, P, c_int64, c_int64, P, P, c_int64, P, P, P, c_float, P, P, P, P, P, P, P]),
     "matten_norm_act": (c_int, [P, c_int64, c_int64, P, c_int64, c_int, c_float, P, P, P, P, c_float, P, P]),
     "matten_norm_act_bwd": (c_int, [P, P, c_int64, c_int64, P, c_int64, c_int, c_float, P, P]),
     "matten_instance_norm_fwd": (c_int, [P, c_int64, c_int64, P, P, c_int64, P, P, c_int64, P, P, c_float, P, P, P, P]),

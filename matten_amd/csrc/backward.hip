@@ -546,6 +546,148 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, int dim, int64_t n_
     }
 }
 
+// ---- whole-batch statistics at large row counts: two stages, thread = column -------------------------------------
+// bn_stats_kernel gives a channel to a workgroup whose threads walk rows: neighbouring lanes read addresses one ROW
+// apart, every 4-byte load pulls its own cache line (32x the bytes through L1/L2: 47 us at 9652 rows x 200 columns).
+// Here a workgroup takes BN_RB consecutive rows and thread j the column j: coalesced row reads, one partial record per
+// (row block, column); a second launch merges a channel's records in a fixed order.  Centred (0e) columns carry
+// (block mean, block sum of squared deviations) merged pairwise with the parallel-variance formula (no E[x^2] - mean^2
+// cancellation), the others the block sum of squares.
+constexpr int BN_RB = 16;             // rows per block
+constexpr int BN_COLS_MIN_ROWS = 2048;   // below: the one-launch kernels
+__global__ __launch_bounds__(256) void bn_stats_cols_kernel(const float* __restrict__ x, int dim, int64_t n_rows,
+                                                            const int32_t* __restrict__ col2chan,
+                                                            const int4* __restrict__ chan, float2* __restrict__ part) {
+    const int64_t r0 = (int64_t)blockIdx.x * BN_RB;
+    const int nr = (int)min((int64_t)BN_RB, n_rows - r0);
+    for (int col = threadIdx.x; col < dim; col += blockDim.x) {
+        float v[BN_RB];
+#pragma unroll
+        for (int r = 0; r < BN_RB; ++r) v[r] = r < nr ? x[(r0 + r) * dim + col] : 0.0f;
+        float m = 0.0f, q = 0.0f;
+        if (chan[col2chan[col]].z) {
+#pragma unroll
+            for (int r = 0; r < BN_RB; ++r) m += v[r];
+            m /= (float)nr;
+#pragma unroll
+            for (int r = 0; r < BN_RB; ++r) {
+                const float dlt = r < nr ? v[r] - m : 0.0f;
+                q = fmaf(dlt, dlt, q);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < BN_RB; ++r) q = fmaf(v[r], v[r], q);
+        }
+        part[(int64_t)blockIdx.x * dim + col] = make_float2(m, q);
+    }
+}
+
+// (count, mean, M2) of two disjoint sets -> of their union
+__device__ __forceinline__ void bn_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+    if (nb == 0.0f) return;
+    const float n = na + nb, dlt = mb - ma;
+    ma = fmaf(dlt, nb / n, ma);
+    qa = qa + qb + dlt * dlt * (na * nb / n);
+    na = n;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float2* __restrict__ part, int dim, int64_t n_rows,
+                                                              int n_blocks, const int4* __restrict__ chan,
+                                                              float* __restrict__ mean, float* __restrict__ nu,
+                                                              float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float momentum) {
+    __shared__ float rn[256], rm[256], rq[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int4 ch = chan[c];
+    float n = 0.0f, m = 0.0f, q = 0.0f;
+    if (ch.z) {   // one column: thread t merges blocks t, t + 256, ... in order
+        for (int b = t; b < n_blocks; b += 256) {
+            const float2 p = part[(int64_t)b * dim + ch.x];
+            bn_merge(n, m, q, (float)min((int64_t)BN_RB, n_rows - (int64_t)b * BN_RB), p.x, p.y);
+        }
+    } else {
+        const int items = n_blocks * ch.y;
+        for (int i = t; i < items; i += 256) q += part[(int64_t)(i / ch.y) * dim + ch.x + i % ch.y].y;
+    }
+    rn[t] = n, rm[t] = m, rq[t] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            if (ch.z) {
+                bn_merge(rn[t], rm[t], rq[t], rn[t + o], rm[t + o], rq[t + o]);
+            } else {
+                rq[t] += rq[t + o];
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float mu = ch.z ? rm[0] : 0.0f;
+        const float v = rq[0] / ((float)n_rows * (float)ch.y);
+        mean[c] = mu;
+        nu[c] = v;
+        if (running_var) {
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * v;
+            if (ch.z) running_mean[ch.w] = (1.0f - momentum) * running_mean[ch.w] + momentum * mu;
+        }
+    }
+}
+
+// adjoint reductions, same two stages: part[block, column] = (sum dy (x - mean), sum dy) over the block's rows
+__global__ __launch_bounds__(256) void bn_bwd_cols_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          int dim, int64_t n_rows, const int32_t* __restrict__ col2chan,
+                                                          const float* __restrict__ mean, float2* __restrict__ part) {
+    const int64_t r0 = (int64_t)blockIdx.x * BN_RB;
+    const int nr = (int)min((int64_t)BN_RB, n_rows - r0);
+    for (int col = threadIdx.x; col < dim; col += blockDim.x) {
+        const float mu = mean[col2chan[col]];
+        float xv[BN_RB], g[BN_RB];
+#pragma unroll
+        for (int r = 0; r < BN_RB; ++r) {
+            xv[r] = r < nr ? x[(r0 + r) * dim + col] : mu;
+            g[r] = r < nr ? dy[(r0 + r) * dim + col] : 0.0f;
+        }
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int r = 0; r < BN_RB; ++r) {
+            a = fmaf(g[r], xv[r] - mu, a);
+            b += g[r];
+        }
+        part[(int64_t)blockIdx.x * dim + col] = make_float2(a, b);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float2* __restrict__ part, int dim, int n_blocks,
+                                                            const int4* __restrict__ chan, float* __restrict__ A,
+                                                            float* __restrict__ B, const float* __restrict__ nu,
+                                                            float eps, float* __restrict__ dweight,
+                                                            float* __restrict__ dbias) {
+    __shared__ float ra[256], rb[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int4 ch = chan[c];
+    float a = 0.0f, b = 0.0f;
+    const int items = n_blocks * ch.y;
+    for (int i = t; i < items; i += 256) {
+        const float2 p = part[(int64_t)(i / ch.y) * dim + ch.x + i % ch.y];
+        a += p.x;
+        b += p.y;
+    }
+    ra[t] = a, rb[t] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) ra[t] += ra[t + o], rb[t] += rb[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        A[c] = ra[0];
+        B[c] = rb[0];
+        if (dweight) {
+            dweight[c] = ra[0] * rsqrtf(nu[c] + eps);
+            if (ch.z) dbias[ch.w] = rb[0];
+        }
+    }
+}
+
 // y = (x - mean) * rsqrt(nu + eps) * weight + bias(0e only)
 __global__ void bn_apply_kernel(const float* __restrict__ x, int dim, int64_t n_rows, const int32_t* __restrict__ col2chan,
                                 const int4* __restrict__ chan, const float* __restrict__ mean,
@@ -789,16 +931,33 @@ extern "C" int matten_norm_act_bwd(const float* x, const float* dy, int64_t dim,
     return MATTEN_OK;
 }
 
+// floats of scratch the whole-batch BatchNorm calls need (0: none -- small batches run the one-launch reductions)
+extern "C" int64_t matten_bn_scratch_floats(int64_t n_rows, int64_t dim) {
+    return n_rows >= BN_COLS_MIN_ROWS ? 2 * matten_cdiv(n_rows, BN_RB) * dim : 0;
+}
+
 extern "C" int matten_bn_train_fwd(const float* x, int64_t dim, int64_t n_rows, const int32_t* col2chan,
                                    const int32_t* chan, int64_t n_chan, const float* weight, const float* bias,
                                    float eps, float* mean, float* nu, float* y, float* running_mean,
-                                   float* running_var, float momentum, matten_stream_t stream_) {
+                                   float* running_var, float momentum, float* scratch, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows <= 0 || dim <= 0 || n_chan <= 0) return MATTEN_EINVAL;
     if (!x || !col2chan || !chan || !weight || !bias || !mean || !nu || !y) return MATTEN_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MATTEN_EINVAL;
-    bn_stats_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, (int)dim, n_rows, (const int4*)chan, mean, nu, nullptr,
-                                                          running_mean, running_var, momentum);
+    if (matten_bn_scratch_floats(n_rows, dim) > 0) {
+        if (!scratch) return MATTEN_EINVAL;
+        const int64_t n_blocks = matten_cdiv(n_rows, BN_RB);
+        if (n_blocks >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+        bn_stats_cols_kernel<<<(unsigned)n_blocks, 256, 0, stream>>>(x, (int)dim, n_rows, col2chan, (const int4*)chan,
+                                                                     (float2*)scratch);
+        MATTEN_LAUNCH_CHECK();
+        bn_stats_finish_kernel<<<(unsigned)n_chan, 256, 0, stream>>>((const float2*)scratch, (int)dim, n_rows,
+                                                                     (int)n_blocks, (const int4*)chan, mean, nu,
+                                                                     running_mean, running_var, momentum);
+    } else {
+        bn_stats_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, (int)dim, n_rows, (const int4*)chan, mean, nu, nullptr,
+                                                              running_mean, running_var, momentum);
+    }
     MATTEN_LAUNCH_CHECK();
     const int T = 256;
     bn_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(x, (int)dim, n_rows, col2chan,
@@ -856,13 +1015,24 @@ extern "C" int matten_instance_norm_bwd(const float* x, const float* dy, int64_t
 extern "C" int matten_bn_train_bwd(const float* x, const float* dy, int64_t dim, int64_t n_rows,
                                    const int32_t* col2chan, const int32_t* chan, int64_t n_chan, const float* mean,
                                    const float* nu, const float* weight, float eps, float* A, float* B, float* dx,
-                                   float* dweight, float* dbias, matten_stream_t stream_) {
+                                   float* dweight, float* dbias, float* scratch, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows <= 0 || dim <= 0 || n_chan <= 0) return MATTEN_EINVAL;
     if (!x || !dy || !col2chan || !chan || !mean || !nu || !weight || !A || !B || !dx) return MATTEN_EINVAL;
     if ((dweight == nullptr) != (dbias == nullptr)) return MATTEN_EINVAL;
-    bn_bwd_reduce_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, dy, (int)dim, n_rows, (const int4*)chan, mean, A, B, nullptr,
-                                                               nu, eps, dweight, dbias);
+    if (matten_bn_scratch_floats(n_rows, dim) > 0) {
+        if (!scratch) return MATTEN_EINVAL;
+        const int64_t n_blocks = matten_cdiv(n_rows, BN_RB);
+        if (n_blocks >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+        bn_bwd_cols_kernel<<<(unsigned)n_blocks, 256, 0, stream>>>(x, dy, (int)dim, n_rows, col2chan, mean,
+                                                                   (float2*)scratch);
+        MATTEN_LAUNCH_CHECK();
+        bn_bwd_finish_kernel<<<(unsigned)n_chan, 256, 0, stream>>>((const float2*)scratch, (int)dim, (int)n_blocks,
+                                                                   (const int4*)chan, A, B, nu, eps, dweight, dbias);
+    } else {
+        bn_bwd_reduce_kernel<<<(unsigned)n_chan, 256, 0, stream>>>(x, dy, (int)dim, n_rows, (const int4*)chan, mean, A, B,
+                                                                   nullptr, nu, eps, dweight, dbias);
+    }
     MATTEN_LAUNCH_CHECK();
     const int T = 256;
     bn_bwd_apply_kernel<<<(unsigned)matten_cdiv(n_rows * dim, T), T, 0, stream>>>(

@@ -790,6 +790,12 @@ def gate_bwd(x, meta, act_cst, dy) -> torch.Tensor:
     return dx
 
 
+def _bn_scratch(lib, x):
+    """partial records of the two-stage whole-batch reductions (large batches only)"""
+    n = lib.matten_bn_scratch_floats(x.shape[0], x.shape[1])
+    return torch.empty(n, dtype=torch.float32, device=x.device) if n > 0 else None
+
+
 def bn_train_fwd(x, col2chan, chan, weight, bias, eps: float, running_mean=None, running_var=None, momentum: float = 0.0):
     """batch statistics -> (y, mean, nu); running_mean / running_var (optional) are updated in place by the same launch"""
     lib = _lib.load()
@@ -801,9 +807,11 @@ def bn_train_fwd(x, col2chan, chan, weight, bias, eps: float, running_mean=None,
     if running_var is not None:
         running_mean = _need(running_mean, torch.float32, "running_mean")
         running_var = _need(running_var, torch.float32, "running_var")
+    scratch = _bn_scratch(lib, x)
     _lib.check(lib.matten_bn_train_fwd(_ptr(x), x.shape[1], x.shape[0], _ptr(col2chan), _ptr(chan), C, _ptr(weight),
                                        _ptr(bias), eps, _ptr(mean), _ptr(nu), _ptr(y), _ptr(running_mean),
-                                       _ptr(running_var), float(momentum), _stream()), "matten_bn_train_fwd")
+                                       _ptr(running_var), float(momentum), _ptr(scratch), _stream()),
+               "matten_bn_train_fwd")
     if running_var is not None:
         bump_weights_epoch()   # the running statistics were updated through raw pointers (caches of the folded BatchNorm)
     return y, mean, nu
@@ -869,9 +877,10 @@ def bn_train_bwd(x, dy, col2chan, chan, mean, nu, weight, eps: float, n_bias: in
     dweight = torch.empty(C, dtype=torch.float32, device=x.device)
     dbias = torch.empty(n_bias, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
+    scratch = _bn_scratch(lib, x)
     _lib.check(lib.matten_bn_train_bwd(_ptr(x), _ptr(dy), x.shape[1], x.shape[0], _ptr(col2chan), _ptr(chan), C,
                                        _ptr(mean), _ptr(nu), _ptr(weight), eps, _ptr(A), _ptr(B), _ptr(dx), _ptr(dweight),
-                                       _ptr(dbias), _stream()),
+                                       _ptr(dbias), _ptr(scratch), _stream()),
                "matten_bn_train_bwd")
     return dx, dweight, dbias
 

@@ -474,6 +474,7 @@ def test_flat_adam_state_dict_round_trip():
     ("70x0e+33x1o", "65x0e+17x1o", 2, 150),                   # more than 4 x 4 tiles per segment: two tile blocks
     ("32x0e+16x1e+16x1o+4x2e", "32x0e+16x1e+16x1o+4x2e", 2, 6000),   # large batch: row slices + ordered reduction
     ("8x0e+3x2e", "5x0e+2x2e", 1, 4000),                      # single species, sliced
+    ("16x0e+8x1o", "8x0e+8x1o", 70, 3000),                    # more species than one wave scans at once, skewed, two empty
 ])
 def test_species_linear_gradients_vs_oracle_autograd(irreps_in, irreps_out, S, N):
     """matten_species_linear_wgrad (fp32 MFMA over (row, component), fixed summation order, sliced rows for large
@@ -492,6 +493,10 @@ def test_species_linear_gradients_vs_oracle_autograd(irreps_in, irreps_out, S, N
     species = torch.randint(0, S, (N,), device=DEV, generator=gen)
     if N > 100:
         species[: N // 3] = 0                                    # ragged species groups
+    if S > 64:
+        species[species == 5] = 6                                # species without rows (they still own an item: zeros)
+        species[species == S - 1] = S - 2
+        species[N // 3: N // 3 + 128] = 66                       # >= one full slice in the second scan chunk
     order, seg, _ = ops.group_by_key(species, S)
     with torch.no_grad():
         mod.weight.copy_(w)
@@ -572,6 +577,66 @@ def test_instance_normalization_forward_and_gradients(golden_dir):
             _close(named[k].grad, p.grad, 3e-3, f"grad {k}")
             n += 1
     assert n > 25
+
+
+@pytest.mark.parametrize("N", [2047, 2048, 5003])
+def test_batchnorm_training_reductions_at_large_row_counts(N):
+    """matten_bn_train_fwd / _bwd on both sides of the row count where the reductions switch from one workgroup per
+    channel to the two-stage column form (16-row blocks, records merged per channel in a fixed order): statistics,
+    output, running averages and all three gradients against the e3nn BatchNorm arithmetic written out in fp64; the
+    0e columns sit on an offset 50x their spread (the pairwise mean / squared-deviation merge must not cancel)."""
+    from matten_amd.nn.utils import _IrrepBatchNorm
+    from matten_amd.o3 import Irreps
+
+    irreps = Irreps("8x0e+4x0o+5x1o+3x2e")
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    bn = _IrrepBatchNorm(irreps).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(bn.weight.shape, device=DEV, generator=gen) + 0.5)
+        bn.bias.copy_(torch.randn(bn.bias.shape, device=DEV, generator=gen))
+    x = torch.randn(N, irreps.dim, device=DEV, generator=gen)
+    x[:, :8] += 50.0
+    x.requires_grad_(True)
+    gy = torch.randn(N, irreps.dim, device=DEV, generator=gen)
+    outs = []
+    for _ in range(2):
+        bn.running_mean.zero_(), bn.running_var.fill_(1.0)
+        x.grad = bn.weight.grad = bn.bias.grad = None
+        y = bn.forward_train(x)
+        y.backward(gy)
+        outs.append([t.detach().clone() for t in (y, x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)   # fixed summation order
+    # e3nn BatchNorm (training mode, affine, "component" normalisation, mean reduce), fp64
+    xr = x.detach().cpu().double().requires_grad_(True)
+    w = bn.weight.detach().cpu().double().requires_grad_(True)
+    b = bn.bias.detach().cpu().double().requires_grad_(True)
+    cols, means, nus = [], [], []
+    off = ic = ib = 0
+    for mul, ir in irreps:
+        blk = xr[:, off:off + mul * ir.dim].reshape(N, mul, ir.dim)
+        if ir.is_scalar():
+            mu = blk.mean(dim=(0, 2))
+            blk = blk - mu[None, :, None]
+            means.append(mu)
+        nu = blk.pow(2).mean(dim=(0, 2))
+        nus.append(nu)
+        blk = blk * (w[ic:ic + mul] / (nu + bn.eps).sqrt())[None, :, None]
+        if ir.is_scalar():
+            blk = blk + b[ib:ib + mul][None, :, None]
+            ib += mul
+        cols.append(blk.reshape(N, -1))
+        off += mul * ir.dim
+        ic += mul
+    yr = torch.cat(cols, 1)
+    yr.backward(gy.cpu().double())
+    y, dx, dw, db, rm, rv = outs[0]
+    _close(y, yr, 2e-5, "y")   # (x - mean) of the offset columns carries the fp32 rounding of x itself: 50 * 2^-24 / 1
+    _close(dx, xr.grad, 2e-5, "dL/dx")
+    _close(dw, w.grad, 2e-5, "dL/dweight")
+    _close(db, b.grad, 2e-5, "dL/dbias")
+    _close(rm, 0.1 * torch.cat(means), 1e-6, "running_mean")
+    _close(rv, 0.9 + 0.1 * torch.cat(nus), 1e-5, "running_var")
 
 
 @pytest.mark.parametrize("normalization", ["batch", "instance", None])
