@@ -376,7 +376,13 @@ def extras(dev):
                   "contract": "ids 8 + vector 12 + w read 4 W + dw written 4 W + (x, dx rows: 2 d_in; grad rows: d_mid) / deg per "
                               "(edge, layer)"}
     kern_l = {k: v for k, v in ev_l.items() if k.startswith(("tp_backward", "tp_scatter", "radial_mlp", "species_linear_wgrad"))}
-    del m_l, opt_l, tbl
+    del m_l, opt_l
+    # the same large step replayed from a hipGraph with the flat-buffer Adam (no host time between its ~220 launches)
+    torch.manual_seed(3)
+    m_lg = ScalarTensorModel(backbone_hparams=dict(lmax2), dataset_hparams=ds4).to(dev).train()
+    gl = GraphedTrainStep(m_lg, FlatAdam(m_lg.parameters(), lr=1e-2, weight_decay=1e-5), loss_fn, tbl, target_l, warmup=3)
+    t_lg, _ = timed(lambda: gl.step(tbl, target_l), 3, 10)
+    del m_lg, gl, tbl
     Et, Nt = int(tb["edge_index"].shape[1]), int(tb["pos"].shape[0])
     rec = {
         "crystals": BS, "atoms": Nt, "edges": Et, "dtype": "f32 (the reference's dtype; bf16 storage: see 'bf16')",
@@ -388,8 +394,8 @@ def extras(dev):
         "bf16": {"ms_per_step_hipgraph": 1e3 * t_b,
                  "what": "opt-in bf16 STORAGE of the per-edge tensors (radial weights w[E,W] and dL/dw), fp32 arithmetic, "
                          "node features / BatchNorm statistics / parameters fp32 (MATTEN_EDGE_STORAGE=bf16)"},
-        "batch2048": {"crystals": BL, "atoms": Nl, "edges": El, "ms_per_step_eager": 1e3 * t_l, "crystals_per_sec": BL / t_l,
-                      "dtype": "f32", "data": "the n100 sample tiled to 2048 crystals", "roofline": roof_l,
+        "batch2048": {"crystals": BL, "atoms": Nl, "edges": El, "ms_per_step_eager": 1e3 * t_l, "ms_per_step_hipgraph_flat_adam": 1e3 * t_lg,
+                      "crystals_per_sec": BL / min(t_l, t_lg), "dtype": "f32", "data": "the n100 sample tiled to 2048 crystals", "roofline": roof_l,
                       "kernel_ms_per_launch": kern_l},
         "data": "synthetic-Zenodo-like (first 32 crystals of the reference's n100 example, random targets)",
         "note": "with l <= 2 features the 4e output has no path: 9 of the 21 components are identically 0 (SURVEY 8d)",

@@ -394,7 +394,7 @@ int matten_gather_scale(const float* src, const int64_t* idx, const float* scale
                         int scale_by_source, float* out, const int64_t* perm2, float* out2, matten_stream_t stream);
 /* perm2 [scale_period] / out2 (both or neither): a second output with the columns of every period permuted,
  * out2[r, q] = out[r, perm2[q]] -- the transposed packed weights of the species linear's adjoint in the same launch */
-int64_t matten_species_linear_wgrad_slices(int64_t n_rows, int64_t n_species);   /* rows of matten_species_linear_wgrad's partial */
+int64_t matten_species_linear_wgrad_scratch_floats(int64_t n_rows, int64_t n_species, int64_t w_stride);   /* matten_species_linear_wgrad's scratch */
 
 /* ------------------------------------------------------------------------------------------
  * CartesianTensor.to_cartesian (utils.py:123-124, predict.py:145): out[b,:] = x[b,:] @ Q
@@ -465,12 +465,12 @@ int matten_tp_backward_lit(const float* x, int64_t d_in, const void* w_edge, int
  * itself with the transposed segment table and transposed packed weights):
  *   dWp[s, w_off + u*mo + w] = sum_{rows n of species s} sum_k x[n, x_off+u*d+k] dy[n, o_off+w*d+k]
  * fp32 MFMA over (row, component); fixed summation order.  Every weight of the table's segments is written (dwp need
- * not be initialised).  partial: scratch [matten_species_linear_wgrad_slices(n_rows, n_species), w_stride], required
- * when that count is above 1 (large batches: the species' rows are cut into slices of 128 rows, one scratch row per
- * (species, slice) item), else may be NULL */
+ * not be initialised).  scratch [matten_species_linear_wgrad_scratch_floats(n_rows, n_species, w_stride)], required when
+ * that count is above 0 (large batches: a species' rows are cut into slices of 128 rows; a species of several slices
+ * writes one scratch row per slice and a second launch adds them in slice order), else may be NULL */
 int matten_species_linear_wgrad(const float* x, int64_t d_in, const float* dy, int64_t d_out, const int32_t* order,
                                 const int32_t* seg, int64_t n_species, int64_t n_rows, const int32_t* segs,
-                                int64_t n_segs, int64_t w_stride, float* dwp, float* partial, matten_stream_t stream);
+                                int64_t n_segs, int64_t w_stride, float* dwp, float* scratch, matten_stream_t stream);
 
 /* adjoint of the Gate part of matten_gate_bn (bn_weight == NULL forward); every column of dx is written (no atomics:
  * a gate's gradient is summed over its channel's components in order) */

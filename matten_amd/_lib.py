@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -70,7 +70,7 @@ SIGNATURES = {
     "matten_radial_h_scale": (c_int, [P, P, c_int, c_float, c_float, c_float, P, P]),
     "matten_split_a_tiles": (c_int, [P, c_int64, P, c_int64, P, P, P, P]),
     "matten_gather_scale": (c_int, [P, P, P, c_int64, c_int64, c_int, P, P, P, P]),
-    "matten_species_linear_wgrad_slices": (c_int64, [c_int64, c_int64]),
+    "matten_species_linear_wgrad_scratch_floats": (c_int64, [c_int64, c_int64, c_int64]),
     "matten_tp_backward": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, P, c_int64, P, P, P, c_int64, c_float, P, c_int64, P, P, c_int64,
                                    P, P, c_int64, c_int, P]),
     "matten_tp_backward_lit": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, P, c_int64, c_int64, P, c_int64, P, c_int64, c_float,

@@ -203,18 +203,6 @@ __device__ __forceinline__ int2 wgrad_find_item(const int32_t* __restrict__ seg,
     __syncthreads();
     return found;
 }
-// first item of species s (the sum of the item counts before it) -- wgrad_reduce_kernel
-__device__ __forceinline__ int wgrad_first_item(const int32_t* __restrict__ seg, int n_rows, int s) {
-    __shared__ int total;
-    if (threadIdx.x == 0) total = 0;
-    __syncthreads();
-    int v = 0;
-    for (int t = threadIdx.x; t < s; t += blockDim.x) v += wgrad_items_of(seg ? seg[t + 1] - seg[t] : n_rows);
-    if (v) atomicAdd(&total, v);   // integers: the order does not matter
-    __syncthreads();
-    return total;
-}
-
 // rows lo + 4 wave + g, + 16, ... of the slice: D = 2 l + 1 components per channel (0: run-time count)
 template <int D>
 __device__ __forceinline__ void wgrad_rows(const float* __restrict__ x, int d_in, const float* __restrict__ dy, int d_out,
@@ -282,10 +270,13 @@ __global__ __launch_bounds__(256) void species_linear_wgrad_kernel(const float* 
                                                                    const int32_t* __restrict__ order,
                                                                    const int32_t* __restrict__ seg, int n_rows,
                                                                    const LinSeg* __restrict__ segs, int w_stride,
-                                                                   float* __restrict__ out, int n_species, int sliced) {
+                                                                   float* __restrict__ dwp, float* __restrict__ partial,
+                                                                   int32_t* __restrict__ first, int n_species) {
     __shared__ __attribute__((aligned(16))) float red[4][256];
-    // sliced != 0: blockIdx.x is an item of the compact (species, slice) list and the workgroup writes partial row
-    // blockIdx.x; else blockIdx.x is the species and the workgroup writes dwp
+    // partial != nullptr (sliced): blockIdx.x is an item of the compact (species, slice) list; a species of several items
+    // writes partial row blockIdx.x and notes its first item for wgrad_reduce_kernel, a species of one item (most of
+    // them) and the unsliced form (blockIdx.x = species) write dwp
+    const bool sliced = partial != nullptr;
     int s = blockIdx.x, z = 0;
     if (sliced) {
         const int2 it = wgrad_find_item(seg, n_species, n_rows, (int)blockIdx.x);
@@ -294,14 +285,18 @@ __global__ __launch_bounds__(256) void species_linear_wgrad_kernel(const float* 
     }
     const LinSeg L = segs[blockIdx.y];
     int lo = seg ? seg[s] : 0, hi = seg ? seg[s + 1] : n_rows;
+    float* outp = dwp + (int64_t)s * w_stride + L.w_off;
     if (sliced) {
+        if (hi - lo > WG_SLICE_ROWS) {
+            outp = partial + (int64_t)blockIdx.x * w_stride + L.w_off;
+            if (z == 0 && blockIdx.y == 0 && threadIdx.x == 0) first[s] = (int)blockIdx.x;
+        }
         lo += z * WG_SLICE_ROWS;
         hi = min(hi, lo + WG_SLICE_ROWS);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int MT = (L.mul_in + 15) >> 4, NT = (L.mo + 15) >> 4;
-    float* outp = out + (int64_t)(sliced ? (int)blockIdx.x : s) * w_stride + L.w_off;
     for (int mt0 = 0; mt0 < MT; mt0 += WG_TB) {
         for (int nt0 = 0; nt0 < NT; nt0 += WG_TB) {
             wg_f32x4 acc[WG_TB][WG_TB];
@@ -337,16 +332,24 @@ __global__ __launch_bounds__(256) void species_linear_wgrad_kernel(const float* 
 }
 
 // dWp[s, q] = sum over the species' items (in slice order) of partial[item, q], for the weights of this call's segments
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const LinSeg* __restrict__ segs, int w_stride,
-                                    const int32_t* __restrict__ seg, int n_rows, float* __restrict__ dwp) {
+// and the species of several items (the others wrote dwp themselves)
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, const int32_t* __restrict__ first,
+                                    const LinSeg* __restrict__ segs, int w_stride, const int32_t* __restrict__ seg,
+                                    int n_rows, float* __restrict__ dwp) {
     const int s = blockIdx.x;
-    const LinSeg L = segs[blockIdx.y];
-    const int first = wgrad_first_item(seg, n_rows, s);
     const int nz = wgrad_items_of(seg ? seg[s + 1] - seg[s] : n_rows);
-    const float* p0 = partial + (int64_t)first * w_stride + L.w_off;
+    if (nz == 1) return;
+    const LinSeg L = segs[blockIdx.y];
+    const float* p0 = partial + (int64_t)first[s] * w_stride + L.w_off;
     for (int p = threadIdx.x; p < L.mul_in * L.mo; p += blockDim.x) {
         float v = 0.0f;
-        for (int z = 0; z < nz; ++z) v += p0[(int64_t)z * w_stride + p];
+        for (int z0 = 0; z0 < nz; z0 += 8) {   // eight loads in flight, added in slice order
+            float t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = z0 + i < nz ? p0[(int64_t)(z0 + i) * w_stride + p] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v += t[i];
+        }
         dwp[(int64_t)s * w_stride + L.w_off + p] = v;
     }
 }
@@ -850,39 +853,45 @@ extern "C" int matten_tp_backward(const float* x, int64_t d_in, const void* w_ed
     return MATTEN_OK;
 }
 
-// Number of partial-sum rows (of w_stride floats) a call needs.  ONE: none -- one workgroup per species writes dwp
-// directly; more: the bound of the compact (species, slice) item list (see WG_SLICE_ROWS), whose workgroups write
-// partial[item, w_stride] and a second launch adds a species' items in order.  Either way every packed weight of the
-// table's segments is written exactly once (dwp need not be initialised) and the summation order is fixed.
-extern "C" int64_t matten_species_linear_wgrad_slices(int64_t n_rows, int64_t n_species) {
+// Floats of scratch a call needs.  0: none -- one workgroup per species writes dwp directly; else the compact
+// (species, slice) item list (see WG_SLICE_ROWS) is in use: [items, w_stride] partial sums, written by the species of
+// several items and added in slice order by a second launch, + one int per species (its first item).  Either way
+// every packed weight of the table's segments is written exactly once (dwp need not be initialised) and the summation
+// order is fixed.
+static int64_t wgrad_items_bound(int64_t n_rows, int64_t n_species) {
 #ifdef MATTEN_WG_FORCE_SLICES
-    if (MATTEN_WG_FORCE_SLICES == 1) return 1;
+    if (MATTEN_WG_FORCE_SLICES == 1) return 0;
 #endif
-    if (n_rows < WG_SLICED_MIN_ROWS) return 1;
+    if (n_rows < WG_SLICED_MIN_ROWS) return 0;
     return std::max<int64_t>(1, n_species) + n_rows / WG_SLICE_ROWS;
+}
+extern "C" int64_t matten_species_linear_wgrad_scratch_floats(int64_t n_rows, int64_t n_species, int64_t w_stride) {
+    const int64_t items = wgrad_items_bound(n_rows, n_species);
+    return items ? items * w_stride + std::max<int64_t>(1, n_species) : 0;
 }
 
 extern "C" int matten_species_linear_wgrad(const float* x, int64_t d_in, const float* dy, int64_t d_out,
                                            const int32_t* order, const int32_t* seg, int64_t n_species, int64_t n_rows,
                                            const int32_t* segs, int64_t n_segs, int64_t w_stride, float* dwp,
-                                           float* partial, matten_stream_t stream_) {
+                                           float* scratch, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rows < 0 || d_in <= 0 || d_out <= 0 || n_species <= 0 || n_segs < 0 || w_stride < 0) return MATTEN_EINVAL;
     if (n_segs == 0 || w_stride == 0) return MATTEN_OK;
     if (!x || !dy || !segs || !dwp) return MATTEN_EINVAL;
     if ((order == nullptr) != (seg == nullptr)) return MATTEN_EINVAL;
     if (!order && n_species != 1) return MATTEN_EINVAL;
-    const int64_t items = matten_species_linear_wgrad_slices(n_rows, n_species);
-    if (items > 1 && !partial) return MATTEN_EINVAL;
+    const int64_t items = wgrad_items_bound(n_rows, n_species);
+    if (items && !scratch) return MATTEN_EINVAL;
     if (items >= ((int64_t)1 << 31) || n_species >= ((int64_t)1 << 31) || n_segs > 65535) return MATTEN_EINVAL;
-    dim3 grid((unsigned)(items > 1 ? items : n_species), (unsigned)n_segs);
+    int32_t* first = items ? reinterpret_cast<int32_t*>(scratch + items * w_stride) : nullptr;
+    dim3 grid((unsigned)(items ? items : n_species), (unsigned)n_segs);
     species_linear_wgrad_kernel<<<grid, 256, 0, stream>>>(x, (int)d_in, dy, (int)d_out, order, seg, (int)n_rows,
-                                                          (const LinSeg*)segs, (int)w_stride, items > 1 ? partial : dwp,
-                                                          (int)n_species, items > 1 ? 1 : 0);
+                                                          (const LinSeg*)segs, (int)w_stride, dwp,
+                                                          items ? scratch : nullptr, first, (int)n_species);
     MATTEN_LAUNCH_CHECK();
-    if (items > 1) {
-        wgrad_reduce_kernel<<<dim3((unsigned)n_species, (unsigned)n_segs), 256, 0, stream>>>(
-            partial, (const LinSeg*)segs, (int)w_stride, seg, (int)n_rows, dwp);
+    if (items) {
+        wgrad_reduce_kernel<<<dim3((unsigned)n_species, (unsigned)n_segs), 1024, 0, stream>>>(
+            scratch, first, (const LinSeg*)segs, (int)w_stride, seg, (int)n_rows, dwp);
         MATTEN_LAUNCH_CHECK();
     }
     return MATTEN_OK;

@@ -767,9 +767,9 @@ def species_linear_wgrad(x, dy, species_order, n_species: int, seg_tables, w_str
     order, seg = species_order if species_order is not None else (None, None)
     # every packed weight is written exactly once (nothing to pre-zero); large batches cut the species' rows into slices
     # (a compact list of (species, slice) items) whose partial sums the library adds in slice order
-    items = lib.matten_species_linear_wgrad_slices(x.shape[0], n_species)
+    n_scratch = lib.matten_species_linear_wgrad_scratch_floats(x.shape[0], n_species, w_stride)
     dwp = torch.empty(n_species, w_stride, dtype=torch.float32, device=x.device)
-    partial = torch.empty(items, w_stride, dtype=torch.float32, device=x.device) if items > 1 else None
+    partial = torch.empty(n_scratch, dtype=torch.float32, device=x.device) if n_scratch > 0 else None
     for segs in seg_tables:
         _lib.check(
             lib.matten_species_linear_wgrad(_ptr(x), x.shape[1], _ptr(dy), dy.shape[1], _ptr(order), _ptr(seg),

@@ -30,7 +30,7 @@ order = torch.argsort(sidx, stable=True).int()
 seg = torch.zeros(len(species) + 1, dtype=torch.int32, device=dev)
 seg[1:] = torch.cumsum(torch.bincount(sidx, minlength=len(species)), 0).int()
 print(f"{N} rows, {len(species)} species, largest species {int((seg[1:] - seg[:-1]).max())} rows, "
-      f"slices {ops._lib.load().matten_species_linear_wgrad_slices(N, len(species))}")
+      f"scratch floats per unit of w_stride {ops._lib.load().matten_species_linear_wgrad_scratch_floats(N, len(species), 1)}")
 total = 0.0
 for name, mod in m.named_modules():
     if not isinstance(mod, SpeciesLinear):
