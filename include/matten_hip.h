@@ -240,6 +240,8 @@ int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const flo
 int matten_tp_max_cols(void);   /* weight columns (mul * couplings) a group entry of matten_tp_fused / matten_conv_tile may have */
 int matten_tp_max_cols_l0(void);   /* the same for entries of scalar (l1 = 0) input blocks */
 int matten_tp_max_cols_l1(void);   /* ... and of vector (l1 = 1) input blocks */
+int matten_tp_compact(void);       /* weight block of an entry: 0 = [u][c] over all couplings of its group (absent ones: zero
+                                    * columns), 1 = [u][live c] (build switch -DTPF_COMPACT=1: measured 7-9 % slower) */
 
 /* ------------------------------------------------------------------------------------------
  * Conv layer on 16-node single-species tiles: tensor product + neighbour sum + lin2 + self-connection (+ Gate + eval
@@ -536,20 +538,28 @@ int matten_segment_reduce_bwd(const float* dy, int64_t dim, const int64_t* ptr, 
  *   edges = all (i, j, S): | pos[j] + S.cell - pos[i] | < r_cut (strict, fp64), (i==j, S==0) excluded,
  *   emitted in lexicographic order (i, j, Sx, Sy, Sz); i, j are GLOBAL node ids (ptr-offset applied).
  *   pos[N,3] fp64; cell[B,9] fp64 (rows = lattice vectors); ptr[B+1] int64;
- *   reach[B,3] int32 = number of periodic images to scan along each lattice direction.
  *   pair_ptr[B+1] int64 = running sum of n_b^2: ordered atom pairs are numbered crystal by crystal, i-major.
+ * matten_graph_prep (replaces the per-batch prologue of the reference's collate, data/dataset.py:150-152): per crystal
+ *   the inverse cell in closed form, frac[N,3] = pos @ inv, bound[B,3] = r_cut |inv[:, k]| (a neighbour's shift
+ *   along axis k lies within bound_k of -(frac_j - frac_i)_k), batch[N] int64, pos_f32[N,3], cell_f32[B,9].
  * Two passes: matten_neighbor_count -> counts[pair_ptr[B]] (edges of each ordered pair (i, j)); the caller scans
- * them into offsets (exclusive) and n_edges; matten_neighbor_fill writes edge_index[2,n_edges] (int64) and
- * edge_cell_shift[n_edges,3] (fp32).  num_neigh[i] = sum of the counts of atom i's n_b pairs.
- * max_atoms = largest n_b; at most 65535 crystals per call.
+ * them into offsets[pair_ptr[B] + 1] (exclusive, int64); matten_neighbor_summary -> {n_edges, smallest edge count
+ * of a crystal} (the builder's one read-back); matten_neighbor_fill writes edge_index[2,n_edges] (int64),
+ * edge_cell_shift[n_edges,3] (fp32) and num_neigh[N] (fp32, optional: edges per centre atom, the reference's
+ * bincount(i), data/data.py:401-411).  max_atoms = largest n_b; at most 65535 crystals per call.
  * ========================================================================================== */
-int matten_neighbor_count(const double* pos, const double* cell, const int64_t* ptr, const int32_t* reach,
-                          const int64_t* pair_ptr, double r_cut, int64_t n_crystals, int64_t max_atoms, int32_t* counts,
-                          matten_stream_t stream);
-int matten_neighbor_fill(const double* pos, const double* cell, const int64_t* ptr, const int32_t* reach,
-                         const int64_t* pair_ptr, double r_cut, int64_t n_crystals, int64_t max_atoms,
-                         const int64_t* offsets, int64_t n_edges, int64_t* edge_index, float* edge_cell_shift,
-                         matten_stream_t stream);
+int matten_graph_prep(const double* pos, const double* cell, const int64_t* ptr, int64_t n_crystals, double r_cut,
+                      double* frac, double* bound, int64_t* batch, float* pos_f32, float* cell_f32,
+                      matten_stream_t stream);
+int matten_neighbor_count(const double* pos, const double* cell, const int64_t* ptr, const double* frac,
+                          const double* bound, const int64_t* pair_ptr, double r_cut, int64_t n_crystals,
+                          int64_t max_atoms, int32_t* counts, matten_stream_t stream);
+int matten_neighbor_summary(const int64_t* offsets, const int64_t* pair_ptr, int64_t n_crystals, int64_t* out2,
+                            matten_stream_t stream);
+int matten_neighbor_fill(const double* pos, const double* cell, const int64_t* ptr, const double* frac,
+                         const double* bound, const int64_t* pair_ptr, double r_cut, int64_t n_crystals,
+                         int64_t max_atoms, const int64_t* offsets, int64_t n_edges, int64_t* edge_index,
+                         float* edge_cell_shift, float* num_neigh, matten_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,11 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_MAX_COLS_L1
 #define TPF_MAX_COLS_L1 TPF_MAX_COLS   // vector (l1 = 1) input blocks; 7 couplings with l2 <= 2 (112 columns for 16 channels:
 #endif                                 // measured, spills), 5 with l2 = 3, 4 (80 columns)
+// weight block of an entry: 1 = [u][live c] (only the couplings of the entry's mask), 0 = [u][c] over all couplings of the
+// group with zero columns for the absent ones (plan.py TP_COMPACT, checked at load through matten_tp_compact)
+#ifndef TPF_COMPACT
+#define TPF_COMPACT 0
+#endif
 __host__ __device__ constexpr int cap_channels(int l1, int nc) {
     int cap = 64;
     while (cap > 1 && cap * nc > (l1 == 0 ? TPF_MAX_COLS_L0 : l1 == 1 ? TPF_MAX_COLS_L1 : TPF_MAX_COLS)) cap /= 2;
@@ -162,6 +167,24 @@ __device__ __forceinline__ void mfma_tiles(const f16x8* __restrict__ ah, const f
     for (int mt = 0; mt < MTC; ++mt) dx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, dx[mt], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) *reinterpret_cast<f32x4*>(trow + mt * 16) = dh[mt] + SPLIT_LO_INV * dx[mt];
+}
+
+// w[c] of the lane's channel from its [live c] run in the weight tile: column rank(c) = live couplings below c (a dead
+// coupling reads its successor's column -- inside the row -- and is never used).  Full and compile-time masks keep
+// immediate offsets.
+template <int NC, unsigned CMASK>
+__device__ __forceinline__ void load_weights(const float* __restrict__ wp, unsigned mask, float (&w)[NC]) {
+    constexpr unsigned FULL = (1u << NC) - 1u;
+    if constexpr (CMASK != 0) {
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) w[cc] = wp[__builtin_popcount(CMASK & ((1u << cc) - 1u))];
+    } else if (mask == FULL) {
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+    } else {
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) w[cc] = wp[__popc(mask & ((1u << cc) - 1u))];
+    }
 }
 
 // loader role of a thread: (edge row of the chunk, 16-byte piece of the row) per MFMA tile; fixed for the whole walk
@@ -334,7 +357,15 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const int npw = 64 >> cu_log2;
     const int ch_log2 = npw >= 16 ? 0 : 4 - (6 - cu_log2);
     const int CH = 1 << ch_log2;
+    // the weight block holds the columns of the LIVE couplings only, [u][live c] (plan.py add_entry): a layer that lacks
+    // some couplings of the group (the dead-output view of the last layer keeps 1-5 of up to 9) runs the matrix phase
+    // on ceil(mul * live / 16) tiles
+#if TPF_COMPACT
+    const int ncl = CMASK ? __builtin_popcount(CMASK) : __popc(mask);
+    const int ncols = ge.mul * ncl;
+#else
     const int ncols = ge.mul * NC;
+#endif
     const int MT = (ncols + 15) >> 4;
 
     const int j = lane >> cu_log2;
@@ -456,7 +487,11 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_setprio(0);
         auto contract = [&](int so, const float* __restrict__ x) {
+#if TPF_COMPACT
+            const float* wp = tile + ((j << ch_log2) + so) * stride + u * ncl;
+#else
             const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
+#endif
             const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
             float y[G::NY], w[NC];
             {   // the harmonics of a staged row are 16-byte aligned: whole ds_read_b128 over [Y0, Y0 + NY)
@@ -471,8 +506,12 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 #pragma unroll
                 for (int jj = 0; jj < G::NY; ++jj) y[jj] = yq[G::Y0 - Q0 + jj];
             }
+#if TPF_COMPACT
+            load_weights<NC, CMASK>(wp, mask, w);
+#else
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+#endif
             G::apply(CMASK ? CMASK : mask, x, y, w, acc);
         };
         if constexpr (TPF_LAB_NO_VALU) {

@@ -171,46 +171,31 @@ def batch_graphs_gpu_soa(pos: np.ndarray, cell: np.ndarray, Z: np.ndarray, ptr: 
             out[k] = torch.as_tensor(v).to(out["pos"].device)
         out["ptr"] = torch.from_numpy(ptr).to(out["pos"].device)
         return out
-    # Only O(crystals) work stays on the host; everything per atom (crystal id, fractional extents for the image
-    # reach, pair numbering) is computed on the device from the four arrays that cross PCIe (the numpy form of this
-    # prologue was 2.5 of the builder's 4 ms per 1000 crystals).
+    # Four arrays cross PCIe (positions, cells, species, the two running sums of the crystals); one kernel derives what
+    # the search and the model need per crystal and per atom (ops.graph_prep), two passes find the edges, one 16-byte
+    # read-back sizes the outputs.  (The first device builder did this prologue with ~45 small library launches: 0.5 ms
+    # of host time per call, and bounded the image loops per crystal instead of per pair.)
     n_atoms = int(ptr[-1])
-    n_pairs = int((sizes * sizes).sum())
+    pair_ptr = np.zeros(n_crystals + 1, dtype=np.int64)
+    np.cumsum(sizes * sizes, out=pair_ptr[1:])
+    n_pairs = int(pair_ptr[-1])
     dev = torch.device(device)
     pos_d = torch.from_numpy(pos).to(dev)
     cell_d = torch.from_numpy(cell.reshape(-1, 9)).to(dev)
-    ptr_d = torch.from_numpy(ptr).to(dev)
-    sizes_d = ptr_d[1:] - ptr_d[:-1]
-    batch_d = torch.repeat_interleave(torch.arange(n_crystals, device=dev), sizes_d, output_size=n_atoms)
-    # inverse cells in closed form (rows a, b, c: inv = [b x c, c x a, a x b]^T / det), fp64
-    c3 = cell_d.view(-1, 3, 3)
-    a_, b_, c_ = c3[:, 0], c3[:, 1], c3[:, 2]
-    cof = torch.stack([torch.linalg.cross(b_, c_), torch.linalg.cross(c_, a_), torch.linalg.cross(a_, b_)], dim=2)
-    inv = cof / (a_ * cof[:, :, 0]).sum(1)[:, None, None]
-    frac = torch.einsum("ni,nij->nj", pos_d, inv[batch_d])
-    span = (torch.segment_reduce(frac, "max", offsets=ptr_d, axis=0, unsafe=True)
-            - torch.segment_reduce(frac, "min", offsets=ptr_d, axis=0, unsafe=True))
-    # the reach only bounds the image loops (the kernels apply the exact fp64 distance test): a hair of slack instead
-    # of bit-equality with the host formula ceil(r_cut / plane spacing + fractional extent)
-    reach_d = torch.ceil(float(r_cut) * torch.linalg.vector_norm(inv, dim=1) + span + 1e-9).to(torch.int32)
-    pair_ptr_d = torch.zeros(n_crystals + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(sizes_d * sizes_d, 0, out=pair_ptr_d[1:])
-    # first ordered pair of every atom (pairs of a crystal are numbered i-major): its edges are contiguous
-    atom_pair0 = (pair_ptr_d[:-1][batch_d]
-                  + (torch.arange(n_atoms, device=dev) - ptr_d[:-1][batch_d]) * sizes_d[batch_d])
-    edge_index, shifts, pair_off, min_edges = ops.neighbor_list(pos_d, cell_d, ptr_d, reach_d, pair_ptr_d, r_cut,
-                                                                int(sizes.max()), n_pairs)
-    first = pair_off[torch.cat([atom_pair0, pair_ptr_d[-1:]])]
-    counts = first[1:] - first[:-1]                       # edges per centre atom
+    ptrs_d = torch.from_numpy(np.stack([ptr, pair_ptr])).to(dev)
+    ptr_d, pair_ptr_d = ptrs_d[0], ptrs_d[1]
+    frac_d, bound_d, batch_d, pos32, cell32 = ops.graph_prep(pos_d, cell_d, ptr_d, r_cut)
+    edge_index, shifts, num_neigh, pair_off, min_edges = ops.neighbor_list(
+        pos_d, cell_d, ptr_d, frac_d, bound_d, pair_ptr_d, r_cut, int(sizes.max()), n_pairs)
     if min_edges == 0:   # (came back with the edge count: no second sync on the common path)
-        per_crystal = first[ptr_d[1:]] - first[ptr_d[:-1]]
+        per_crystal = pair_off[pair_ptr_d[1:]] - pair_off[pair_ptr_d[:-1]]
         raise EdgelessStructures(torch.nonzero(per_crystal == 0).flatten().tolist())
     out = {
-        "pos": pos_d.float(),
+        "pos": pos32,
         "edge_index": edge_index,
         "edge_cell_shift": shifts,
-        "cell": cell_d.float().reshape(-1, 3),
-        "num_neigh": counts.float(),
+        "cell": cell32,
+        "num_neigh": num_neigh,
         "atomic_numbers": torch.from_numpy(Z).to(dev),
     }
     for k, v in (y or {}).items():

@@ -453,6 +453,9 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
     if (lib.matten_tp_max_cols() != TP_MAX_COLS or lib.matten_tp_max_cols_l0() != TP_MAX_COLS_L0
             or lib.matten_tp_max_cols_l1() != TP_MAX_COLS_L1):
         raise _lib.MattenHipError("plan.TP_MAX_COLS does not match the library's entry width (-DTPF_MAX_COLS)")
+    from .plan import TP_COMPACT
+    if lib.matten_tp_compact() != TP_COMPACT:
+        raise _lib.MattenHipError("plan.TP_COMPACT does not match the library's weight-block layout (-DTPF_COMPACT)")
     x = _need_rows(x, torch.float32, "node_features")  # a column slice is fine: d_in below is the row stride
     h2p = _need(h2p, torch.float16, "h2s")
     if h2p.dim() != 3 or h2p.shape[1:] != (2, 32):
@@ -895,24 +898,44 @@ def segment_reduce_bwd(dy, ptr, n_rows: int, mean: bool) -> torch.Tensor:
     return dx
 
 
-def neighbor_list(pos64, cell64, ptr, reach, pair_ptr, r_cut: float, max_atoms: int, n_pairs: int):
-    """Periodic neighbour list of a batch of crystals, canonical (i, j, Sx, Sy, Sz) order.
-    pair_ptr[B+1] = running sum of n_b^2 (ordered pairs numbered crystal by crystal, i-major), n_pairs = pair_ptr[B].
-    -> (edge_index [2,E] i64 (global ids), edge_cell_shift [E,3] f32, pair_offsets [n_pairs+1] i64,
-        smallest edge count of a crystal: an int, read back together with the edge count)"""
+def graph_prep(pos64, cell64, ptr, r_cut: float):
+    """per-crystal prologue of the device graph builder (include/matten_hip.h matten_graph_prep)
+    -> (frac [N,3] f64, bound [B,3] f64, batch [N] i64, pos [N,3] f32, cell [3B,3] f32)"""
     lib = _lib.load()
     pos64 = _need(pos64, torch.float64, "pos")
     cell64 = _need(cell64, torch.float64, "cell")
     ptr = _need(ptr, torch.int64, "ptr")
-    reach = _need(reach, torch.int32, "reach")
+    N, B, dev = pos64.shape[0], ptr.shape[0] - 1, pos64.device
+    frac = torch.empty(N, 3, dtype=torch.float64, device=dev)
+    bound = torch.empty(B, 3, dtype=torch.float64, device=dev)
+    batch = torch.empty(N, dtype=torch.int64, device=dev)
+    pos32 = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    cell32 = torch.empty(3 * B, 3, dtype=torch.float32, device=dev)
+    _lib.check(lib.matten_graph_prep(_ptr(pos64), _ptr(cell64), _ptr(ptr), B, float(r_cut), _ptr(frac), _ptr(bound),
+                                     _ptr(batch), _ptr(pos32), _ptr(cell32), _stream()), "matten_graph_prep")
+    return frac, bound, batch, pos32, cell32
+
+
+def neighbor_list(pos64, cell64, ptr, frac, bound, pair_ptr, r_cut: float, max_atoms: int, n_pairs: int):
+    """Periodic neighbour list of a batch of crystals, canonical (i, j, Sx, Sy, Sz) order.
+    frac / bound: ops.graph_prep; pair_ptr[B+1] = running sum of n_b^2 (ordered pairs numbered crystal by crystal,
+    i-major), n_pairs = pair_ptr[B].
+    -> (edge_index [2,E] i64 (global ids), edge_cell_shift [E,3] f32, num_neigh [N] f32 (edges per centre atom),
+        pair_offsets [n_pairs+1] i64, smallest edge count of a crystal: an int, read back together with the edge count)"""
+    lib = _lib.load()
+    pos64 = _need(pos64, torch.float64, "pos")
+    cell64 = _need(cell64, torch.float64, "cell")
+    ptr = _need(ptr, torch.int64, "ptr")
+    frac = _need(frac, torch.float64, "frac")
+    bound = _need(bound, torch.float64, "bound")
     pair_ptr = _need(pair_ptr, torch.int64, "pair_ptr")
     B = ptr.shape[0] - 1
     dev = pos64.device
     counts = torch.empty(n_pairs, dtype=torch.int32, device=dev)
     with _timed("neighbor_count"):
         _lib.check(
-            lib.matten_neighbor_count(_ptr(pos64), _ptr(cell64), _ptr(ptr), _ptr(reach), _ptr(pair_ptr), float(r_cut), B,
-                                      int(max_atoms), _ptr(counts), _stream()),
+            lib.matten_neighbor_count(_ptr(pos64), _ptr(cell64), _ptr(ptr), _ptr(frac), _ptr(bound), _ptr(pair_ptr),
+                                      float(r_cut), B, int(max_atoms), _ptr(counts), _stream()),
             "matten_neighbor_count",
         )
     offsets = torch.zeros(n_pairs + 1, dtype=torch.int64, device=dev)
@@ -920,16 +943,20 @@ def neighbor_list(pos64, cell64, ptr, reach, pair_ptr, r_cut: float, max_atoms: 
     # the one host sync of graph construction: the edge count sizes the outputs; the smallest edge count of a crystal
     # (0: the caller has to find and report the edgeless ones) rides on the same read-back
     if n_pairs:
-        per_crystal = offsets[pair_ptr[1:]] - offsets[pair_ptr[:-1]]
-        E, min_edges = torch.stack([offsets[-1], per_crystal.min()]).tolist()
+        summary = torch.empty(2, dtype=torch.int64, device=dev)
+        _lib.check(lib.matten_neighbor_summary(_ptr(offsets), _ptr(pair_ptr), B, _ptr(summary), _stream()),
+                   "matten_neighbor_summary")
+        E, min_edges = summary.tolist()
     else:
         E, min_edges = 0, 0
     edge_index = torch.empty(2, E, dtype=torch.int64, device=dev)
     shifts = torch.empty(E, 3, dtype=torch.float32, device=dev)
+    num_neigh = torch.empty(pos64.shape[0], dtype=torch.float32, device=dev)
     with _timed("neighbor_fill"):
         _lib.check(
-            lib.matten_neighbor_fill(_ptr(pos64), _ptr(cell64), _ptr(ptr), _ptr(reach), _ptr(pair_ptr), float(r_cut), B,
-                                     int(max_atoms), _ptr(offsets), E, _ptr(edge_index), _ptr(shifts), _stream()),
+            lib.matten_neighbor_fill(_ptr(pos64), _ptr(cell64), _ptr(ptr), _ptr(frac), _ptr(bound), _ptr(pair_ptr),
+                                     float(r_cut), B, int(max_atoms), _ptr(offsets), E, _ptr(edge_index), _ptr(shifts),
+                                     _ptr(num_neigh), _stream()),
             "matten_neighbor_fill",
         )
-    return edge_index, shifts, offsets, int(min_edges)
+    return edge_index, shifts, num_neigh, offsets, int(min_edges)

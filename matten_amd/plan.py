@@ -35,6 +35,7 @@ TP_MAX_COMBOS = 12
 TP_MAX_COLS = int(os.environ.get("MATTEN_TP_MAX_COLS", "64"))  # == matten_tp_max_cols() of the library (-DTPF_MAX_COLS)
 TP_MAX_COLS_L0 = int(os.environ.get("MATTEN_TP_MAX_COLS_L0", "96"))  # scalar input blocks (see plan_uvu); -DTPF_MAX_COLS_L0
 TP_MAX_COLS_L1 = int(os.environ.get("MATTEN_TP_MAX_COLS_L1", str(TP_MAX_COLS)))  # vector input blocks; -DTPF_MAX_COLS_L1
+TP_COMPACT = int(os.environ.get("MATTEN_TP_COMPACT", "0"))   # == matten_tp_compact() (-DTPF_COMPACT): weight block [u][live c]
 TP_KIND_STRIDE = 8
 
 ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
@@ -356,8 +357,11 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         # wave tile: [16 * n_tiles16 edge rows][weight columns + 4 (+ 32: units off the shared path park the
         # edge's harmonics behind the weights; sized for them so that any unit order is valid)].  Without the 32
         # a block needs 35.8 instead of 52 KB of LDS, but four blocks per CU do not pay (docs/LAB_NOTES.md round 2).
-        lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(combos)) // 16)) + 32 + 4))
-        n_mt = -(-(mul_c * len(combos)) // 16)  # 16-column MFMA tiles of the entry's weight block
+        # weight block of the entry: [u][live c] -- only the couplings some half has (the dead-output view of the last layer
+        # keeps 1-5 of up to 9: 23 instead of 56 tiles of matrix work per edge)
+        live = [key for key in combos if any(key in present for _, present in halves)] if TP_COMPACT else list(combos)
+        lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(live)) // 16)) + 32 + 4))
+        n_mt = -(-(mul_c * len(live)) // 16)  # 16-column MFMA tiles of the entry's weight block
         merged = len(halves) == 2
         rows = []
         for h, (mul_h, present) in enumerate(halves):
@@ -377,13 +381,11 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
             rows[1][5] = head[4]                 # the first half's own mask travels in the continuation record
             head[4] |= rows[1][4]                # the walk contracts the union (absent couplings: zero weight columns)
         fused_a_tiles += n_mt
-        # fused weight layout of this entry: [u][c] -> column of the reference's weight row (-1: absent)
-        ubase = 0
+        # fused weight layout of this entry: [u][live c] -> column of the reference's weight row (-1: absent in this half)
         for (mul_h, present) in halves:
             for uu in range(mul_h):
-                for key in combos:
+                for key in live:
                     fused_cols.append(present[key].w_off + u0 + uu if key in present else -1)
-            ubase += mul_h
         for r_, (mul_h, present) in zip(rows, halves):
             gentries.append(r_)
             gentry_paths.append({c: paths.index(present[key]) for c, key in enumerate(combos) if key in present})

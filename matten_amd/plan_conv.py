@@ -38,7 +38,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from .o3 import Irrep, Irreps
-from .plan import TP_GROUPS, TP_KIND_STRIDE, TP_MAX_COLS, TP_MAX_COLS_L0, TP_MAX_COLS_L1, UVUPlan
+from .plan import TP_COMPACT, TP_GROUPS, TP_KIND_STRIDE, TP_MAX_COLS, TP_MAX_COLS_L0, TP_MAX_COLS_L1, UVUPlan
 
 TILE_NODES = 16          # == matten_conv_tile_nodes()
 DUMP_RS = 68             # floats between two registers of a wave's dump (64 lanes + 4: bank spread, 16-byte aligned)
@@ -140,11 +140,6 @@ def _build_entries(uvu: UVUPlan, cols0: int, merge: bool):
                 chunks = [(u0, min(cap, mul_blk - u0)) for u0 in range(0, mul_blk, cap)]
             for (u0, mul_c) in chunks:
                 cu_log2 = max(1, (mul_c - 1).bit_length())
-                n_mt = -(-(mul_c * len(combos)) // 16)
-                lds_need = max(lds_need, 16 * (16 * n_mt + 4))
-                row = [l1 * TP_KIND_STRIDE + gi, plists[0][0].x_off + u0 * d1, mul_c, cu_log2, 0, len(fused_cols), a_tiles,
-                       n_mt] + [0] * 24
-                a_tiles += n_mt
                 mask = 0
                 hv = []
                 if len(grp) == 2:
@@ -155,10 +150,15 @@ def _build_entries(uvu: UVUPlan, cols0: int, merge: bool):
                 for (_, _, cmap, _) in hv:
                     for c in cmap:
                         mask |= 1 << c
-                row[4] = mask
+                live = [c for c in range(len(combos)) if mask >> c & 1 or not TP_COMPACT]   # weight block [u][live c] (plan.py add_entry)
+                n_mt = -(-(mul_c * len(live)) // 16)
+                lds_need = max(lds_need, 16 * (16 * n_mt + 4))
+                row = [l1 * TP_KIND_STRIDE + gi, plists[0][0].x_off + u0 * d1, mul_c, cu_log2, mask, len(fused_cols), a_tiles,
+                       n_mt] + [0] * 24
+                a_tiles += n_mt
                 for uu in range(mul_c):
                     h = next(hh for hh in hv if hh[0] <= uu < hh[1])
-                    for c, key in enumerate(combos):
+                    for c in live:
                         if c in h[2]:
                             pth = uvu.paths[h[2][c]]
                             fused_cols.append(pth.w_off + h[3] + (uu - h[0]))

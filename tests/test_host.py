@@ -482,10 +482,15 @@ def test_conv_tile_plan_reproduces_lin2(case):
         nacc = sum(2 * l3 + 1 for _, l3 in combos)
         acc = np.zeros((pc.TILE_NODES, cu, nacc))
         off = 0
+        mask = int(rows[e][4])
+        n_live = bin(mask).count("1") if mplan.TP_COMPACT else len(combos)   # weight block [u][live c] or [u][c]
         for c, (l2, l3) in enumerate(combos):
             d3 = 2 * l3 + 1
             for uu in range(mul):
-                col = int(tp.fused_cols[w_base + uu * len(combos) + c])   # reference weight column of (channel, coupling)
+                if mplan.TP_COMPACT and not (mask >> c) & 1:
+                    continue
+                rank = bin(mask & ((1 << c) - 1)).count("1") if mplan.TP_COMPACT else c
+                col = int(tp.fused_cols[w_base + uu * n_live + rank])   # reference weight column of (channel, coupling)
                 if col >= 0:
                     pth = next(q for q in uvu.paths if q.w_off <= col < q.w_off + q.mul)
                     assert (pth.l1, pth.l2, pth.l3) == (l1, l2, l3) and (int(rows[e][4]) >> c) & 1
