@@ -98,12 +98,20 @@ def pack_structures(structures: Sequence):
     the reference dataset, dataset/structure_scalar_tensor.py:296-362): malformed arrays, no atoms, non-finite
     numbers, singular cell.  Everything after the attribute access is vectorised."""
     pos_l, cell_l, z_l, keep, failed = [], [], [], [], []
+    asarray, f64, i64 = np.asarray, np.float64, np.int64
     for i, s in enumerate(structures):
         try:
-            f = _fields(s)
-            p = np.asarray(f["cart_coords"], dtype=np.float64).reshape(-1, 3)
-            c = np.asarray(f["lattice"], dtype=np.float64).reshape(3, 3)
-            z = np.asarray(f["atomic_numbers"], dtype=np.int64).reshape(-1)
+            if isinstance(s, dict):
+                p, c, z = s["cart_coords"], s["lattice"], s["atomic_numbers"]
+            else:
+                p, c, z = s.cart_coords, s.lattice.matrix, s.atomic_numbers
+            p, c, z = asarray(p, dtype=f64), asarray(c, dtype=f64), asarray(z, dtype=i64)
+            if p.ndim != 2 or p.shape[1] != 3:
+                p = p.reshape(-1, 3)
+            if c.shape != (3, 3):
+                c = c.reshape(3, 3)
+            if z.ndim != 1:
+                z = z.reshape(-1)
             if len(p) == 0 or len(p) != len(z):
                 raise ValueError("malformed structure")
         except Exception as e:  # noqa: BLE001
@@ -111,28 +119,29 @@ def pack_structures(structures: Sequence):
             failed.append(i)
             continue
         pos_l.append(p); cell_l.append(c); z_l.append(z); keep.append(i)
-    if keep:
-        sizes = np.array([len(p) for p in pos_l], dtype=np.int64)
-        cell = np.stack(cell_l)
-        pos = np.concatenate(pos_l)
-        ptr = np.zeros(len(keep) + 1, dtype=np.int64)
-        np.cumsum(sizes, out=ptr[1:])
-        with np.errstate(all="ignore"):
-            ok = np.isfinite(cell).all(axis=(1, 2)) & (np.abs(np.linalg.det(cell)) > 1e-12)
-            ok &= np.logical_and.reduceat(np.isfinite(pos).all(axis=1), ptr[:-1])
-        if not ok.all():
-            for k in np.nonzero(~ok)[0]:
-                warnings.warn(f"Failed converting structure {keep[k]}, Skip it. singular cell or non-finite coordinates")
-                failed.append(keep[k])
-            sel = np.nonzero(ok)[0]
-            pos_l, cell_l, z_l = [pos_l[k] for k in sel], [cell_l[k] for k in sel], [z_l[k] for k in sel]
-            keep = [keep[k] for k in sel]
     if not keep:
         raise RuntimeError("Cannot successfully convert any structures.")
-    sizes = np.array([len(p) for p in pos_l], dtype=np.int64)
-    ptr = np.zeros(len(keep) + 1, dtype=np.int64)
-    np.cumsum(sizes, out=ptr[1:])
-    return np.concatenate(pos_l), np.stack(cell_l), np.concatenate(z_l), ptr, keep, sorted(failed)
+
+    def flat(pos_l, cell_l, z_l):
+        sizes = np.fromiter(map(len, z_l), dtype=np.int64, count=len(z_l))
+        ptr = np.zeros(len(z_l) + 1, dtype=np.int64)
+        np.cumsum(sizes, out=ptr[1:])
+        return np.concatenate(pos_l), np.stack(cell_l), np.concatenate(z_l), ptr
+
+    pos, cell, Z, ptr = flat(pos_l, cell_l, z_l)
+    with np.errstate(all="ignore"):
+        ok = np.isfinite(cell).all(axis=(1, 2)) & (np.abs(np.linalg.det(cell)) > 1e-12)
+        ok &= np.logical_and.reduceat(np.isfinite(pos).all(axis=1), ptr[:-1])
+    if not ok.all():
+        for k in np.nonzero(~ok)[0]:
+            warnings.warn(f"Failed converting structure {keep[k]}, Skip it. singular cell or non-finite coordinates")
+            failed.append(keep[k])
+        sel = np.nonzero(ok)[0]
+        if len(sel) == 0:
+            raise RuntimeError("Cannot successfully convert any structures.")
+        keep = [keep[k] for k in sel]
+        pos, cell, Z, ptr = flat([pos_l[k] for k in sel], [cell_l[k] for k in sel], [z_l[k] for k in sel])
+    return pos, cell, Z, ptr, keep, sorted(failed)
 
 
 _SIDE_STREAMS: Dict[Any, Any] = {}
@@ -170,6 +179,17 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+_CONVERTERS: Dict[str, CartesianTensorWrapper] = {}
+
+
+def _converter(formula: str) -> CartesianTensorWrapper:
+    """one converter per formula: its change-of-basis matrix stays on the device between calls (a fresh one uploads it
+    behind the forward: a blocking 7 KB copy the host sits in for the whole forward)"""
+    if formula not in _CONVERTERS:
+        _CONVERTERS[formula] = CartesianTensorWrapper(formula)
+    return _CONVERTERS[formula]
+
+
 def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
                  tensor_target_name: str = "elastic_tensor_full", tensor_target_formula: str = "ijkl=jikl=klij"):
     """Batched forward straight from the flat arrays of ``pack_structures``.  Graphs are built on the device batch
@@ -178,7 +198,7 @@ def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
     -> (Cartesian tensors [B, 3, ...] on the host as one array, indices of crystals without any edge)."""
     from .data.graph import batch_graphs_gpu_soa
 
-    converter = CartesianTensorWrapper(tensor_target_formula)
+    converter = _converter(tensor_target_formula)
     device = model.device
     rank_dims = (3,) * len(tensor_target_formula.split("=")[0].replace("-", ""))
     B = len(ptr) - 1
@@ -282,7 +302,7 @@ def evaluate(model, graphs: List, batch_size: int = 200,
     ``graphs`` holds either host graph dicts (``crystal_graph``) or raw (pos, cell, Z) triples; triples are
     turned into a batch on the device (``batch_graphs_gpu``, needs ``r_cut``).  A triple without any edge
     yields a NaN tensor."""
-    converter = CartesianTensorWrapper(tensor_target_formula)
+    converter = _converter(tensor_target_formula)
     device = model.device
     rank_dims = (3,) * len(tensor_target_formula.split("=")[0].replace("-", ""))
     # what the model emits per crystal: the irreps row ([21] for the elasticity tensor) or, for
@@ -329,7 +349,7 @@ def evaluate_atomic(model, graphs: List, batch_size: int = 200, tensor_target_na
                     tensor_target_formula: str = "ij=ji", r_cut: float = None) -> List[torch.Tensor]:
     """Per-atom tensors of all atoms of all structures, in input order, as ONE flat list -- what the reference's
     ``evaluate`` produces for an ``AtomicTensorModel`` (predict.py:117-148: ``predictions.extend(p)``)."""
-    converter = CartesianTensorWrapper(tensor_target_formula)
+    converter = _converter(tensor_target_formula)
     device = model.device
     outs = []
     model.eval()
