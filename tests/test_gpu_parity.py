@@ -807,6 +807,37 @@ def test_gpu_neighbor_list_is_identical_to_oracle_builder(golden_dir):
     assert ei.value.indices == [1]
 
 
+def test_gpu_neighbor_list_on_random_cells():
+    """The per-pair image bound of the device search (|S_k + df_k| <= r_cut |inv[:, k]|) only prunes: on 400 random cells
+    -- thin, skewed, nearly flat, atoms up to three cells outside the box, one to eight atoms, cutoffs 2.5 to 6.5 -- the
+    edge list, the shifts and num_neigh equal the oracle's brute-force builder bit for bit."""
+    from matten_amd.data.graph import batch_graphs_gpu
+    from oracle.matten_ref import data as rdata
+
+    rng = np.random.default_rng(77)
+    for r_cut in (2.5, 5.0, 6.5):
+        triples = []
+        while len(triples) < 134:
+            lengths = rng.choice([1.6, 2.5, 4.0, 7.0, 12.0], size=3)
+            cell = np.diag(lengths) + rng.normal(0.0, 0.35, (3, 3)) * lengths[:, None]
+            if rng.random() < 0.3:
+                cell[2] = 0.9 * cell[0] + 0.5 * cell[1] + rng.normal(0.0, 1.0, 3) * 0.5   # a nearly flat cell
+            vol = abs(np.linalg.det(cell))
+            if vol < 4.0:
+                continue
+            n = int(rng.integers(1, 9))
+            frac = rng.uniform(-3.0, 4.0, (n, 3)) if rng.random() < 0.5 else rng.random((n, 3))
+            try:
+                rdata.neighbor_list(frac @ cell, cell, r_cut)
+            except ValueError:
+                continue   # no edge at all: covered by the edgeless test
+            triples.append((frac @ cell, cell, rng.integers(1, 90, n)))
+        got = batch_graphs_gpu(triples, r_cut, DEV)
+        want = rdata.collate([rdata.crystal_graph(p, c, z, r_cut) for p, c, z in triples])
+        for k in ("edge_index", "edge_cell_shift", "num_neigh", "batch", "ptr", "pos", "cell"):
+            assert torch.equal(got[k].cpu(), want[k]), (r_cut, k)
+
+
 def _species_linear_case(irreps_in, irreps_out, S, N, with_add, gen):
     """The product's species-indexed linear (nn.utils.SpeciesLinear -> matten_species_linear[_rows]) against the
     ORACLE's FullyConnectedTensorProduct(x, one_hot(species)) (oracle/e3nn_lite/o3.py, e3nn semantics: instruction
