@@ -65,7 +65,14 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """the current HIP stream of the current device as a raw handle (the private getter skips the Stream object that
+    torch.cuda.current_stream() builds: ~4 us per launch, 40+ launches per forward)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

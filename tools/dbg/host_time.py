@@ -27,4 +27,4 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(20): step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(14); st.sort_stats("tottime").print_stats(30)
