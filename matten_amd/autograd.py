@@ -344,6 +344,17 @@ def needs_grad(*tensors: Optional[torch.Tensor]) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+def params_of(module) -> tuple:
+    """the module's parameters as a tuple, built once (module.parameters() walks the module tree: ~15 us per call for a
+    conv layer, called several times per forward).  The Parameter objects are stable -- FlatAdam re-homes their storage,
+    not the objects -- and their requires_grad flags are read live."""
+    cached = module.__dict__.get("_amd_params")
+    if cached is None:
+        cached = tuple(module.parameters())
+        module.__dict__["_amd_params"] = cached
+    return cached
+
+
 def needs_grad_lazy(tensors) -> bool:
     """needs_grad over the tuple ``tensors()`` returns, which is only built with autograd on (walking a module's
     parameters() a dozen times per forward is 0.1 ms of host time that an inference forward of a small batch feels)"""

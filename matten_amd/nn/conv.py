@@ -237,7 +237,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
     def forward(self, data: DataKey.Type) -> DataKey.Type:
         if self._view is not None and DEAD_PATH_ELIMINATION:
             # the consumer (model_factory.eliminate_dead_outputs paired it with this layer) takes the kept irreps only
-            data = self._view_forward(data, _ag.needs_grad_lazy(lambda: (data[DataKey.NODE_FEATURES], *self.parameters())))
+            data = self._view_forward(data, _ag.needs_grad_lazy(lambda: (data[DataKey.NODE_FEATURES], *_ag.params_of(self))))
             data[KEPT_ONLY] = True
             return data
         data.pop(KEPT_ONLY, None)   # (a re-used batch dict may carry the marker of an earlier forward)
@@ -256,7 +256,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         if (self.tile_plan is not None and CONV_TILE != "0" and x1.shape[0] >= CONV_TILE_MIN_ROWS
                 and self.tp.plan.d_mid >= CONV_TILE_MIN_DMID
                 and DataKey.AMD_SPECIES_I32 in data
-                and not _ag.needs_grad_lazy(lambda: (x1, self_connection, self.lin2.weight, *self.tp.weight_nn.parameters()))):
+                and not _ag.needs_grad_lazy(lambda: (x1, self_connection, self.lin2.weight, *_ag.params_of(self.tp.weight_nn)))):
             gate = self.__dict__.get("_gate_tile")   # set per call by PointConvWithActivation
             data[DataKey.NODE_FEATURES] = self._forward_tile(x1, self_connection, data, gate)
             if gate is not None:
@@ -266,7 +266,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         # and tables into LDS, species lookup -- is ~35 us of latency per launch that only a long stream pays back:
         # n100, 473 rows: 1.25 vs 1.08 ms per forward; 64 000 rows: -3 %)
         if (self.agg_plan is not None and x1.shape[0] >= AGG_KM_MIN_ROWS
-                and not _ag.needs_grad_lazy(lambda: (x1, self_connection, self.lin2.weight, *self.tp.weight_nn.parameters()))):
+                and not _ag.needs_grad_lazy(lambda: (x1, self_connection, self.lin2.weight, *_ag.params_of(self.tp.weight_nn)))):
             ap, t, dev = self.agg_plan, self._agg_tables, x1.device
             agg = self.tp(x1, data, self.avg_num_neighbors, out_layout=(t.get("entries", dev), ap.ld))
             gate = self.__dict__.get("_gate_fuse")   # set per call by PointConvWithActivation: (cmeta, act_cst, d_act, bn)
@@ -376,11 +376,11 @@ class PointConvWithActivation(ModuleIrreps, torch.nn.Module):
     def forward(self, data: DataKey.Type) -> DataKey.Type:
         x = data[DataKey.NODE_FEATURES]
         fuse = None
-        if not _ag.needs_grad_lazy(lambda: (x, *self.conv.parameters())) and x.shape[0] >= AGG_KM_MIN_ROWS:
+        if not _ag.needs_grad_lazy(lambda: (x, *_ag.params_of(self.conv))) and x.shape[0] >= AGG_KM_MIN_ROWS:
             fuse = self._gate_fuse_args(x.device)
         self.conv.__dict__["_gate_fuse"] = fuse
         self.conv.__dict__["_gate_tile"] = (self._gate_tile_args(x.device)
-                                            if not _ag.needs_grad_lazy(lambda: (x, *self.conv.parameters())) else None)
+                                            if not _ag.needs_grad_lazy(lambda: (x, *_ag.params_of(self.conv))) else None)
         try:
             data = self.conv(data)
         finally:

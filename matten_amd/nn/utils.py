@@ -322,7 +322,7 @@ class UVUTensorProduct(torch.nn.Module):
         dev = node_feats.device
         avg = avg_num_neighbors if avg_num_neighbors is not None else 0.0
         num_neigh = None if avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
-        if _ag.needs_grad_lazy(lambda: (node_feats, *self.weight_nn.parameters())):
+        if _ag.needs_grad_lazy(lambda: (node_feats, *_ag.params_of(self.weight_nn))):
             # training path: radial weights materialised in the reference layout by the MLP kernel, the tensor
             # product + neighbour sum and both adjoints are HIP kernels too
             from ._nequip import ensure_training_edge_tensors
