@@ -243,9 +243,22 @@ class RadialMLP(torch.nn.Module):
         return ops.radial_hidden(geom_sorted, n_basis, r_start, r_end, w0p, w1p, self.h_scale(r_start, r_end)), w2p
 
 
-# small batches: CSR segments longer than HUB_SPLIT_LEN edges are walked in pieces (ops.csr_split); 0 = off.  Large batches
+# small batches: CSR segments longer than the piece length are walked in pieces (ops.csr_split); 0 = off.  Large batches
 # (>= HUB_SPLIT_MAX_ROWS nodes) keep whole segments: regular degrees, and the pieces' rows would cost memory traffic.
-HUB_SPLIT_LEN = int(os.environ.get("MATTEN_HUB_SPLIT_LEN", "16"))   # n100 hipGraph forward: 827 us whole segments, 574 / 468 / 454 us at 32 / 16 / 8
+# The best length grows with the batch (hipGraph forward of the n100 sample tiled 1 / 3 / 10 / 17 times, ms;
+# tools/dbg/hub_len_sweep.py):   8: 0.457 0.645 1.358 2.086   16: 0.487 0.619 1.132 1.697   32: 0.580 0.669 1.112 1.599
+# whole segments: 0.877 0.985 1.378 1.844 -- few nodes need the parallelism, many pay for the pieces' rows.
+_HUB_SPLIT_LEN_ENV = os.environ.get("MATTEN_HUB_SPLIT_LEN")
+HUB_SPLIT_LEN = int(_HUB_SPLIT_LEN_ENV) if _HUB_SPLIT_LEN_ENV is not None else 16   # the training forward's length (autograd.py)
+
+
+def hub_split_len(n_rows: int) -> int:
+    """piece length of the inference forward for a batch of n_rows nodes (MATTEN_HUB_SPLIT_LEN overrides)"""
+    if _HUB_SPLIT_LEN_ENV is not None:
+        return HUB_SPLIT_LEN
+    return 8 if n_rows <= 768 else (16 if n_rows <= 3072 else 32)
+
+
 HUB_SPLIT_MAX_ROWS = int(os.environ.get("MATTEN_HUB_SPLIT_MAX_ROWS", "8192"))
 
 
@@ -339,12 +352,13 @@ class UVUTensorProduct(torch.nn.Module):
             h2p, w2p = self.weight_nn.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, data)
             rowptr = data[DataKey.AMD_ROWPTR]
             split = None
-            if out_layout is None and HUB_SPLIT_LEN > 0 and node_feats.shape[0] < HUB_SPLIT_MAX_ROWS:
+            piece = hub_split_len(node_feats.shape[0])
+            if out_layout is None and piece > 0 and node_feats.shape[0] < HUB_SPLIT_MAX_ROWS:
                 # small batch: the launch lasts as long as its longest CSR segment (one hub node walked serially by one
-                # wave): walk pieces of at most HUB_SPLIT_LEN edges as virtual nodes and sum them afterwards, in order
+                # wave): walk pieces of at most hub_split_len() edges as virtual nodes and sum them afterwards, in order
                 split = data.get("_amd_csr_split")
                 if split is None or split[3] is not rowptr:
-                    split = ops.csr_split(rowptr, data[DataKey.AMD_SRC].shape[0], HUB_SPLIT_LEN, num_neigh) + (rowptr,)
+                    split = ops.csr_split(rowptr, data[DataKey.AMD_SRC].shape[0], piece, num_neigh) + (rowptr,)
                     data["_amd_csr_split"] = split
             agg = ops.tp_fused(
                 node_feats, h2p, w2p, data[DataKey.AMD_SH], rowptr if split is None else split[0], data[DataKey.AMD_SRC],

@@ -1373,12 +1373,12 @@ def test_fuzzed_models_on_poisoned_buffers(mode):
 
 
 def test_hub_segments_are_walked_in_pieces(golden_dir, monkeypatch):
-    """Small batches cut every CSR segment into virtual nodes of at most HUB_SPLIT_LEN edges (matten_csr_split) so that
+    """Small batches cut every CSR segment into virtual nodes of at most hub_split_len(n_rows) edges (matten_csr_split) so that
     a hub -- the n100 sample has atoms with 80 neighbours, the average is 30 -- does not set the duration of every
     tensor-product launch; the real node's neighbour sum is the ordered sum of its pieces.  Checked: the split tables
     against a host evaluation (ragged degrees, empty segments, bound padding), the n100 forward with pieces of 32 / 5 /
     whole segments against each other and the oracle, per-node neighbour normalisation, and that a crystal's result does
-    not depend on its batch mates (bitwise)."""
+    not depend on its batch mates (bitwise at equal piece length; the default length grows with the batch: 8 / 16 / 32)."""
     from matten_amd import ops
     from matten_amd.data.graph import average_num_neighbors, collate, crystal_graph
     from matten_amd.nn import utils as nnu
@@ -1418,12 +1418,14 @@ def test_hub_segments_are_walked_in_pieces(golden_dir, monkeypatch):
         batch = collate(graphs, device=DEV)
         outs = {}
         with torch.no_grad():
+            outs["auto"] = model(dict(batch))[0]["elastic_tensor_full"].clone()   # the length hub_split_len() picks (8 here)
             for L in (32, 16, 5, 0):
-                monkeypatch.setattr(nnu, "HUB_SPLIT_LEN", L)
+                monkeypatch.setattr(nnu, "hub_split_len", lambda n_rows, L=L: L)
                 outs[L] = model(dict(batch))[0]["elastic_tensor_full"].clone()
             want = ref.decode(collate(graphs))
-            monkeypatch.setattr(nnu, "HUB_SPLIT_LEN", 32)
+            monkeypatch.setattr(nnu, "hub_split_len", lambda n_rows: 32)
             sub = model(dict(collate(graphs[40:57], device=DEV)))[0]["elastic_tensor_full"]
+        close_blocks(outs["auto"], outs[0].cpu(), rtol=5e-6, floor=2e-6, what="default piece length vs whole segments")
         close_blocks(outs[32], outs[0].cpu(), rtol=5e-6, floor=2e-6, what="pieces of 32 vs whole segments")
         close_blocks(outs[16], outs[0].cpu(), rtol=5e-6, floor=2e-6, what="pieces of 16 vs whole segments")
         close_blocks(outs[5], outs[0].cpu(), rtol=5e-6, floor=2e-6, what="pieces of 5 vs whole segments")

@@ -37,3 +37,10 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 nodes = sum(int(b["pos"].shape[0]) for b in batches) / len(batches); edges = sum(int(b["edge_index"].shape[1]) for b in batches) / len(batches)
 print(f"training step (batch {BS} crystals, {nodes:.0f} nodes, {edges:.0f} edges avg, Adam {'fused' if FUSED else 'per-tensor'}): "
       f"{dt*1e3:.2f} ms/step, {BS/dt:.0f} crystals/s, final loss {loss.item():.4f}")
+if os.environ.get("PROFILE"):   # host profile of the eager step (the step is launch-bound at this size)
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(5):
+        for b, t in zip(batches, targets): step(b, t)
+    pr.disable(); torch.cuda.synchronize()
+    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(35)
