@@ -170,11 +170,9 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
     const int fcol = lane & 31, frow = lane >> 5;   // flush role: column of the table row's slice, row parity
 
     // (io, k) unit state, wave-uniform
-    int K = 0, d3 = 0, n_mt = 0, cw = 0, a_off = 0, out_off = 0, mo = 0, T = 0, cur_ii = 0;
+    int K = 0, d3 = 0, n_mt = 0, cw = 0, a_off = 0, out_off = 0, mo = 0;
     auto load_io = [&](int ii) {
-        cur_ii = ii;
         const AggIo r = io_l[ii];
-        T = __builtin_amdgcn_readfirstlane(r.T);
         K = __builtin_amdgcn_readfirstlane(r.K);
         d3 = __builtin_amdgcn_readfirstlane(r.packed & 255);
         n_mt = __builtin_amdgcn_readfirstlane((r.packed >> 8) & 255);
