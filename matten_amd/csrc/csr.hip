@@ -239,7 +239,8 @@ inline int key_bits(int64_t N) {
 // launch lasts as long as the longest segment.  In a large regular batch that is the degree (18-30 everywhere); in a small
 // batch of real crystals it is the one hub (a one- or two-atom cell has 100-300 neighbours inside the cutoff while the
 // average is 30: the reference's n100 sample spends 65 % of its forward walking a handful of such segments on a few CUs).
-// Here every segment is cut into pieces of at most `max_len` edges; the pieces tile the sorted edge list in order, so
+// Here every segment is cut into the fewest pieces of at most `max_len` edges, of equal length up to one edge (the launch
+// lasts as long as the LONGEST piece); the pieces tile the sorted edge list in order, so
 // vrowptr[] is itself a CSR row pointer over virtual nodes, the kernels run on it unchanged, and the real node's sum is
 // the ordered sum of its pieces (matten_segment_reduce over vseg): fixed order, independent of the rest of the batch.
 // One workgroup (the batches this is for have a few thousand nodes): block scans of 1024 nodes with a running carry.
@@ -254,10 +255,11 @@ __global__ __launch_bounds__(1024) void csr_split_kernel(const int* __restrict__
     const int E = rowptr[N];
     for (int base = 0; base < N; base += 1024) {
         const int n = base + t;
-        int beg = 0, k = 0;
+        int beg = 0, k = 0, d = 0;
         if (n < N) {
             beg = rowptr[n];
-            k = max(1, (rowptr[n + 1] - beg + max_len - 1) / max_len);
+            d = rowptr[n + 1] - beg;
+            k = max(1, (d + max_len - 1) / max_len);
         }
         sh[t] = k;
         __syncthreads();
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(1024) void csr_split_kernel(const int* __restrict__
             for (int i = 0; i < k; ++i) {
                 const int v = first + i;
                 if (v < nv_bound) {
-                    vrowptr[v] = beg + i * max_len;
+                    vrowptr[v] = beg + (int)((int64_t)i * d / k);   // balanced pieces (18 edges at max_len 16: 9 + 9, not 16 + 2)
                     if (vnn) vnn[v] = num_neigh[n];
                 }
             }

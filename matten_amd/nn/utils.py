@@ -245,9 +245,11 @@ class RadialMLP(torch.nn.Module):
 
 # small batches: CSR segments longer than the piece length are walked in pieces (ops.csr_split); 0 = off.  Large batches
 # (>= HUB_SPLIT_MAX_ROWS nodes) keep whole segments: regular degrees, and the pieces' rows would cost memory traffic.
-# The best length grows with the batch (hipGraph forward of the n100 sample tiled 1 / 3 / 10 / 17 times, ms;
-# tools/dbg/hub_len_sweep.py):   8: 0.457 0.645 1.358 2.086   16: 0.487 0.619 1.132 1.697   32: 0.580 0.669 1.112 1.599
-# whole segments: 0.877 0.985 1.378 1.844 -- few nodes need the parallelism, many pay for the pieces' rows.
+# The best length grows with the batch (hipGraph forward in ms, tools/dbg/hub_len_sweep*.py; pieces are balanced: 18 edges
+# at length 16 are 9 + 9):  n100 tiled 1 / 3 / 10 / 17 times   8: 0.455 0.637 1.350 2.092   16: 0.480 0.611 1.114 1.677
+# 32: 0.575 0.660 1.079 1.549   whole segments: 0.877 0.985 1.378 1.844;   fcc-64, 4 / 11 / 30 / 60 / 120 crystals
+# 8: 0.365 0.433 0.584 0.850 1.473   16: 0.368 0.418 0.544 0.754 1.242   32 (= whole): 0.408 0.453 0.540 0.693 1.077
+# -- few nodes need the parallelism, many pay for the pieces' rows.
 _HUB_SPLIT_LEN_ENV = os.environ.get("MATTEN_HUB_SPLIT_LEN")
 HUB_SPLIT_LEN = int(_HUB_SPLIT_LEN_ENV) if _HUB_SPLIT_LEN_ENV is not None else 16   # the training forward's length (autograd.py)
 

@@ -1397,7 +1397,7 @@ def test_hub_segments_are_walked_in_pieces(golden_dir, monkeypatch):
     want_rows, want_seg = [], [0]
     for n, d in enumerate(deg.tolist()):
         k = max(1, -(-d // 32))
-        want_rows += [int(rowptr[n]) + 32 * i for i in range(k)]
+        want_rows += [int(rowptr[n]) + i * d // k for i in range(k)]   # balanced: 70 edges = 23 + 23 + 24, 33 = 16 + 17
         want_seg.append(want_seg[-1] + k)
     nv = want_seg[-1]
     assert vseg.tolist() == want_seg and vrow[:nv].tolist() == want_rows and (vrow[nv:] == E).all()
