@@ -441,6 +441,17 @@ def extras(dev):
         dt = (time.perf_counter() - t0) / 3
         pr[f"batch_size={bs}"] = {"ms_per_1000_structures": 1e3 * dt, "crystals_per_sec": len(structs) / dt}
     assert len(outp) == len(structs)
+    # a list longer than one slab (predict.PREDICT_SLAB structures): slab k + 1 is packed on the host while slab k runs
+    many = structs * 4
+    P.predict(many, model=model, config=cfg)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        outp = P.predict(many, model=model, config=cfg)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    pr["4000_structures"] = {"ms_per_1000_structures": 1e3 * dt / 4, "crystals_per_sec": len(many) / dt}
+    del many
     ex["predict_end_to_end_fcc64"] = dict(pr, note="host structure dicts -> device neighbour lists -> forward -> Cartesian "
                                                      "tensors on the host (PCIe and host packing inside the time)")
     # the reference's real use: small crystals (the n100 sample, 4.7 atoms each, tiled to 1000 structures) at its default

@@ -92,7 +92,7 @@ def check_species(model, structures: Sequence, Z=None, ptr=None, index=None):
             )
 
 
-def pack_structures(structures: Sequence):
+def pack_structures(structures: Sequence, first: int = 0):
     """One pass over the structures -> flat struct-of-arrays batch (pos [N,3] f64, cell [B,3,3] f64, Z [N] i64,
     ptr [B+1]) of the usable ones, plus the indices that cannot be used (same role as the per-structure try/except of
     the reference dataset, dataset/structure_scalar_tensor.py:296-362): malformed arrays, no atoms, non-finite
@@ -115,7 +115,7 @@ def pack_structures(structures: Sequence):
             if len(p) == 0 or len(p) != len(z):
                 raise ValueError("malformed structure")
         except Exception as e:  # noqa: BLE001
-            warnings.warn(f"Failed converting structure {i}, Skip it. {e}")
+            warnings.warn(f"Failed converting structure {first + i}, Skip it. {e}")
             failed.append(i)
             continue
         pos_l.append(p); cell_l.append(c); z_l.append(z); keep.append(i)
@@ -134,7 +134,7 @@ def pack_structures(structures: Sequence):
         ok &= np.logical_and.reduceat(np.isfinite(pos).all(axis=1), ptr[:-1])
     if not ok.all():
         for k in np.nonzero(~ok)[0]:
-            warnings.warn(f"Failed converting structure {keep[k]}, Skip it. singular cell or non-finite coordinates")
+            warnings.warn(f"Failed converting structure {first + keep[k]}, Skip it. singular cell or non-finite coordinates")
             failed.append(keep[k])
         sel = np.nonzero(ok)[0]
         if len(sel) == 0:
@@ -190,12 +190,41 @@ def _converter(formula: str) -> CartesianTensorWrapper:
     return _CONVERTERS[formula]
 
 
+class _deferred_input_checks:
+    """the per-forward range checks are read one batch late (and all of them before the results leave): the host keeps
+    building the next batch instead of waiting for the flags of the one it has just enqueued"""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        self.modes = [(m, m.check_species) for m in self.model.modules() if hasattr(m, "check_species")]
+        if hasattr(self.model, "set_input_checks"):
+            self.model.set_input_checks("deferred")
+        return self
+
+    def __exit__(self, *exc):
+        for m, mode in self.modes:
+            m._pending = None
+            m.check_species = mode
+        return False
+
+
 def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
                  tensor_target_name: str = "elastic_tensor_full", tensor_target_formula: str = "ijkl=jikl=klij"):
     """Batched forward straight from the flat arrays of ``pack_structures``.  Graphs are built on the device batch
     by batch on a SECOND stream: the neighbour search of batch k+1 (and its one host sync, the edge count) overlaps
     the forward of batch k, which runs on the caller's stream.
     -> (Cartesian tensors [B, 3, ...] on the host as one array, indices of crystals without any edge)."""
+    model.eval()
+    with _deferred_input_checks(model):
+        return _soa_end(model, _soa_begin(model, pos, cell, Z, ptr, r_cut, batch_size, tensor_target_name,
+                                          tensor_target_formula))
+
+
+def _soa_begin(model, pos, cell, Z, ptr, r_cut, batch_size, tensor_target_name, tensor_target_formula):
+    """enqueue every forward of the packed structures (inside _deferred_input_checks) -> (device tensors [B, 3, ...],
+    indices of crystals without any edge); nothing here waits for the forwards"""
     from .data.graph import batch_graphs_gpu_soa
 
     converter = _converter(tensor_target_formula)
@@ -228,18 +257,15 @@ def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
         return ids, None
 
     chunks = coalesce_batches(ptr, batch_size)
-    model.eval()
-    # the per-forward range checks are read one batch late (and all of them before the results leave): the host keeps
-    # building the next batch instead of waiting for the flags of the one it has just enqueued
-    modes = [(m, m.check_species) for m in model.modules() if hasattr(m, "check_species")]
-    if hasattr(model, "set_input_checks"):
-        model.set_input_checks("deferred")
-    try:
-        return _evaluate_soa_loop(model, chunks, build, main, side, out, edgeless, converter, tensor_target_name, device)
-    finally:
-        for m, mode in modes:
-            m._pending = None
-            m.check_species = mode
+    _evaluate_soa_loop(model, chunks, build, main, side, out, edgeless, converter, tensor_target_name, device)
+    return out, edgeless
+
+
+def _soa_end(model, handle):
+    out, edgeless = handle
+    if hasattr(model, "finish_input_checks"):
+        model.finish_input_checks()
+    return out.cpu().numpy(), sorted(edgeless)
 
 
 def _evaluate_soa_loop(model, chunks, build, main, side, out, edgeless, converter, tensor_target_name, device):
@@ -260,9 +286,6 @@ def _evaluate_soa_loop(model, chunks, build, main, side, out, edgeless, converte
                 else:                                            # queued behind the forward would stall the host here)
                     out[torch.as_tensor(ids, device=device)] = p
             nxt = build(chunks[k + 1]) if k + 1 < len(chunks) else None  # overlaps the forward just enqueued
-    if hasattr(model, "finish_input_checks"):
-        model.finish_input_checks()
-    return out.cpu().numpy(), sorted(edgeless)
 
 
 def build_graphs(structures: Sequence, r_cut: float, on_gpu: bool = False):
@@ -365,6 +388,52 @@ def evaluate_atomic(model, graphs: List, batch_size: int = 200, tensor_target_na
     return list(torch.cat(outs, dim=0).cpu())
 
 
+PREDICT_SLAB = int(__import__("os").environ.get("MATTEN_PREDICT_SLAB", "1024"))   # structures packed per slab
+
+
+def _predict_slabs(model, structures, r_cut, batch_size, tensor_target_name, tensor_target_formula):
+    """-> (predictions of the usable structures in input order, sorted indices of the failed ones)"""
+    n = len(structures)
+
+    def pack(lo, hi):
+        try:
+            pos, cell, Z, ptr, keep, failed = pack_structures(structures[lo:hi], first=lo)
+        except RuntimeError:                       # not one usable structure in this slab (each one was warned about)
+            return None, list(range(lo, hi))
+        keep = [lo + k for k in keep]
+        check_species(model, structures, Z, ptr, keep)   # (raises like the reference, naming the structure's own index)
+        return (pos, cell, Z, ptr, keep), [lo + k for k in failed]
+
+    failed, inflight = [], []
+    model.eval()
+    with _deferred_input_checks(model):
+        lo, size = 0, PREDICT_SLAB
+        nxt = pack(0, min(n, size)) if n else None
+        while nxt is not None:
+            cur, bad = nxt
+            failed += bad
+            lo = min(n, lo + size)
+            if cur is not None:
+                pos, cell, Z, ptr, keep = cur
+                inflight.append((keep, _soa_begin(model, pos, cell, Z, ptr, r_cut, batch_size, tensor_target_name,
+                                                  tensor_target_formula)))
+                # a slab should fill a forward: ~NODE_BUDGET atoms (1024 fcc-64 crystals, ~14 000 of the reference's
+                # 4.7-atom ones), between PREDICT_SLAB and 16 PREDICT_SLAB structures
+                per = max(1.0, len(pos) / max(1, len(keep)))
+                size = int(min(16 * PREDICT_SLAB, max(PREDICT_SLAB, NODE_BUDGET / per)))
+            nxt = pack(lo, min(n, lo + size)) if lo < n else None   # overlaps the forwards just enqueued
+        predictions = []
+        for keep, handle in inflight:
+            tensors, edgeless = _soa_end(model, handle)
+            for j in edgeless:
+                warnings.warn(f"Failed converting structure {keep[j]}, Skip it. After eliminating self edges, no edges "
+                              "remain in this system.")
+            dropped = set(edgeless)
+            failed += [keep[j] for j in edgeless]
+            predictions += [tensors[j] for j in range(len(keep)) if j not in dropped]
+    return predictions, sorted(set(failed))
+
+
 def predict(
     structure,
     model_identifier="20230627",
@@ -403,18 +472,11 @@ def predict(
                                 tensor_target_name=config["data"]["tensor_target_name"],
                                 tensor_target_formula=config["data"]["tensor_target_formula"], r_cut=r_cut)
         return [t.numpy() for t in preds]
-    # fast path: one pass over the structures, then flat arrays all the way to the device
-    pos, cell, Z, ptr, keep, failed = pack_structures(structures)
-    check_species(model, structures, Z, ptr, keep)
-    tensors, edgeless = evaluate_soa(model, pos, cell, Z, ptr, r_cut, batch_size=batch_size,
-                                     tensor_target_name=config["data"]["tensor_target_name"],
-                                     tensor_target_formula=config["data"]["tensor_target_formula"])
-    for k in edgeless:
-        warnings.warn(f"Failed converting structure {keep[k]}, Skip it. After eliminating self edges, no edges remain "
-                      "in this system.")
-    failed = sorted(set(failed) | {keep[k] for k in edgeless})
-    dropped = set(edgeless)
-    predictions = [tensors[k] for k in range(len(keep)) if k not in dropped]
+    # fast path: the structures are packed into flat arrays slab by slab (PREDICT_SLAB structures each); while the
+    # device runs the forwards of slab k the host packs slab k + 1 (a 1000-structure slab packs in 2-3 ms, its forwards
+    # take 4-5 ms: the host work of all slabs but the first disappears behind the device)
+    predictions, failed = _predict_slabs(model, structures, r_cut, batch_size, config["data"]["tensor_target_name"],
+                                         config["data"]["tensor_target_formula"])
     if not predictions:
         raise RuntimeError("Cannot successfully convert any structures.")
     if is_elasticity_tensor:

@@ -781,6 +781,49 @@ def test_predict_api_end_to_end(tmp_path):
                   model_identifier=str(tmp_path))
 
 
+def test_predict_packs_in_slabs_behind_the_device(monkeypatch):
+    """predict() packs PREDICT_SLAB structures at a time while the device runs the previous slab's forwards: the same list
+    in slabs of 3 and in one slab gives the same tensors, the None holes (malformed, edgeless, a slab without one usable
+    structure) sit at the structures' own indices, the warnings name those indices, an unsupported species in a later
+    slab raises like the reference."""
+    import warnings as W
+
+    from matten_amd import predict as P
+    from matten_amd.data import synthetic
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    model = ScalarTensorModel(backbone_hparams=dict(PAPER), dataset_hparams=ds).to(DEV).eval()
+    cfg = {"data": {"r_cut": 5.0, "tensor_target_name": "elastic_tensor_full", "tensor_target_formula": "ijkl=jikl=klij"}}
+    good = synthetic.fcc64_structures(8)
+    edgeless = {"lattice": 50.0 * np.eye(3), "cart_coords": np.zeros((1, 3)), "atomic_numbers": np.array([29])}
+    malformed = {"lattice": np.eye(3), "cart_coords": np.zeros((2, 3)), "atomic_numbers": np.array([29])}
+    structs = [good[0], edgeless, good[1], good[2], malformed, good[3], malformed, malformed, malformed, good[4],
+               good[5], good[6], edgeless, good[7]]          # slabs of 3: [0 1 2] [3 4 5] [6 7 8: none usable] [9 10 11] [12 13]
+    holes = [1, 4, 6, 7, 8, 12]
+    with W.catch_warnings(record=True) as w1:
+        W.simplefilter("always")
+        one = P.predict(structs, model=model, config=cfg, batch_size=2)
+    monkeypatch.setattr(P, "PREDICT_SLAB", 3)
+    with W.catch_warnings(record=True) as w3:
+        W.simplefilter("always")
+        three = P.predict(structs, model=model, config=cfg, batch_size=2)
+    for out in (one, three):
+        assert len(out) == len(structs) and [i for i, t in enumerate(out) if t is None] == holes
+    for i in range(len(structs)):
+        if i not in holes:
+            a, b = np.asarray(one[i]), np.asarray(three[i])
+            assert a.shape == (3, 3, 3, 3) and np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
+    for w in (w1, w3):
+        text = " ".join(str(m.message) for m in w)
+        for i in holes:
+            assert f"structure {i}," in text, (i, text)
+        assert f"{holes}" in text
+    bad_species = dict(good[0], atomic_numbers=np.full(64, 8))
+    with pytest.raises(RuntimeError, match="structure 4. It contains species 8 not supported"):
+        P.predict(structs[:4] + [bad_species], model=model, config=cfg)
+
+
 def test_gpu_neighbor_list_is_identical_to_oracle_builder(golden_dir):
     """the device neighbour search emits exactly the (i, j, S) list of the oracle's
     brute-force builder (oracle/matten_ref/data.py, ASE contract of data/data.py:285-413) in canonical order:
