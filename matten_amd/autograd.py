@@ -16,31 +16,6 @@ import torch
 from . import ops
 
 
-class PackWeightsFn(torch.autograd.Function):
-    """packed[s, j] = weight[gather[s, j]] * scale[j] with ``gather`` a bijection between the flat e3nn parameter and
-    the packed per-species table.  The generic index backward sorts the indices (nine small rocPRIM launches per
-    module and step); a bijection needs only the inverse permutation."""
-
-    @staticmethod
-    def forward(ctx, weight, gather, scale, inverse, perm_t=None):
-        """perm_t: also return the per-path transposed packing (what the species linear's adjoint multiplies by), from
-        the same launch; it is a by-product for SpeciesLinearFn.backward and carries no gradient"""
-        ctx.save_for_backward(scale, inverse)
-        ctx.set_materialize_grads(False)   # (no zero tensors for the by-product's never-defined gradient)
-        if perm_t is None:
-            return ops.gather_scale(weight, gather, scale)                   # one launch instead of index + multiply
-        wp, wpt = ops.gather_scale(weight, gather, scale, perm2=perm_t)
-        ctx.mark_non_differentiable(wpt)
-        return wp, wpt
-
-    @staticmethod
-    def backward(ctx, g, *_):
-        if g is None:
-            return None, None, None, None, None
-        scale, inverse = ctx.saved_tensors
-        return ops.gather_scale(g.contiguous(), inverse, scale, scale_by_source=True), None, None, None, None
-
-
 class SpeciesEmbedFn(torch.autograd.Function):
     """node features of the one-hot embedding, ``feats`` as the species_embed kernel computed them; the adjoint sums the
     incoming gradient per species with the weight-gradient kernel of the species linear (input = the constant 1:
@@ -62,14 +37,23 @@ class SpeciesEmbedFn(torch.autograd.Function):
 
 
 class SpeciesLinearFn(torch.autograd.Function):
-    """out = add + x W_species  (matten_species_linear); adjoints: same kernel with W^T, and the weight-gradient kernel."""
+    """out = add + x W_species  (matten_species_linear) from the flat e3nn ``weight``.
+    The per-species packing packed[s, j] = weight[gather[s, j]] * scale[j] is part of this node (one autograd node and
+    one Function.apply per linear instead of two: the eager step is bound by that host work at small batches): forward
+    packs (and, when x needs a gradient, emits the per-path transposed packing from the same launch), backward runs
+    the same kernel with W^T for dx, the weight-gradient kernel for the packed gradient, and maps that back through
+    the inverse permutation (``gather`` is a bijection: no index sort, no atomics)."""
 
     @staticmethod
-    def forward(ctx, x, wp, add, mod, species_order, wpt=None):
-        plan, dev = mod.plan, x.device
-        segs = [mod._tables.get(f"meta{i}", dev) for i in range(len(plan.passes))]
-        ctx.mod, ctx.species_order = mod, species_order
-        ctx.wpt = wpt   # the transposed packing, when PackWeightsFn produced it alongside
+    def forward(ctx, x, weight, add, mod, species_order):
+        plan, dev, t = mod.plan, x.device, mod._tables
+        gather, scale = t.get("gather", dev), t.get("scale", dev)
+        if ctx.needs_input_grad[0]:
+            wp, wpt = ops.gather_scale(weight, gather, scale, perm2=t.get("perm_t", dev))
+        else:
+            wp, wpt = ops.gather_scale(weight, gather, scale), None
+        segs = [t.get(f"meta{i}", dev) for i in range(len(plan.passes))]
+        ctx.mod, ctx.species_order, ctx.wpt = mod, species_order, wpt
         ctx.save_for_backward(x, wp)
         ctx.has_add = add is not None
         return ops.species_linear(x, species_order, wp, plan.w_stride, segs, plan.d_out, add, plan.fully_covered)
@@ -78,20 +62,19 @@ class SpeciesLinearFn(torch.autograd.Function):
     def backward(ctx, g):
         x, wp = ctx.saved_tensors
         mod, plan, dev = ctx.mod, ctx.mod.plan, g.device
+        t = mod._tables
         g = g.contiguous()
-        dx = dwp = None
+        dx = dweight = None
         if ctx.needs_input_grad[0]:
-            segs_t = [mod._tables.get(f"meta_t{i}", dev) for i in range(len(plan.passes_t))]
-            wpt = ctx.wpt
-            if wpt is None:
-                wpt = wp.reshape(-1, plan.w_stride)[:, mod._tables.get("perm_t", dev)].contiguous()
-            dx = ops.species_linear(g, ctx.species_order, wpt, plan.w_stride, segs_t, plan.d_in, None,
+            segs_t = [t.get(f"meta_t{i}", dev) for i in range(len(plan.passes_t))]
+            dx = ops.species_linear(g, ctx.species_order, ctx.wpt, plan.w_stride, segs_t, plan.d_in, None,
                                     plan.input_covered)
         if ctx.needs_input_grad[1]:
-            segs = [mod._tables.get(f"meta{i}", dev) for i in range(len(plan.passes))]
+            segs = [t.get(f"meta{i}", dev) for i in range(len(plan.passes))]
             n_species = wp.shape[0] if wp.dim() == 2 else 1
-            dwp = ops.species_linear_wgrad(x, g, ctx.species_order, n_species, segs, plan.w_stride).reshape(wp.shape)
-        return dx, dwp, (g if ctx.has_add else None), None, None, None
+            dwp = ops.species_linear_wgrad(x, g, ctx.species_order, n_species, segs, plan.w_stride)
+            dweight = ops.gather_scale(dwp.reshape(-1), t.get("gather_inv", dev), t.get("scale", dev), scale_by_source=True)
+        return dx, dweight, (g if ctx.has_add else None), None, None
 
 
 # Storage type of the two per-edge tensors of a training step, the radial weights w[E, W] and their gradient -- at

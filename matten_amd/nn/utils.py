@@ -72,17 +72,8 @@ class SpeciesLinear(torch.nn.Module):
             raise ValueError("species order required")
         order = species_order if self.n_species is not None else None
         if _ag.needs_grad(x, self.weight, add):
-            # training path: the re-packing (index + scale) is differentiable, the linear is the HIP Function
-            wpt = None
-            if x.requires_grad:   # the adjoint w.r.t. x multiplies by the per-path transposed packing: same launch
-                wp, wpt = _ag.PackWeightsFn.apply(self.weight, self._tables.get("gather", x.device),
-                                                  self._tables.get("scale", x.device),
-                                                  self._tables.get("gather_inv", x.device),
-                                                  self._tables.get("perm_t", x.device))
-            else:
-                wp = _ag.PackWeightsFn.apply(self.weight, self._tables.get("gather", x.device),
-                                             self._tables.get("scale", x.device), self._tables.get("gather_inv", x.device))
-            return _ag.SpeciesLinearFn.apply(x, wp, add, self, order, wpt)
+            # training path: packing, linear and both adjoints are ONE autograd node (autograd.SpeciesLinearFn)
+            return _ag.SpeciesLinearFn.apply(x, self.weight, add, self, order)
         wp = self._packed.get(self.weight)
         metas = [self._tables.get(f"meta{i}", x.device) for i in range(len(self.plan.passes))]
         return ops.species_linear(x, species_order if self.n_species is not None else None, wp, self.plan.w_stride,
