@@ -8,7 +8,8 @@
 //      dh2 = dw W2p^T          dW2p = h2^T dw
 //      dz2 = dh2 * silu'(z2)   dW1p = h1^T dz2     dh1 = dz2 W1p^T
 //      dz1 = dh1 * silu'(z1)   dW0p = b^T dz1
-// Two kernels, both on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), both reading dw once:
+// Layers of 128 to 512 weight columns run ONE kernel that reads dw once (radial_mlp_bwd_fused below); narrower / wider
+// ones two kernels, both on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), both reading dw once:
 //   radial_mlp_bwd_edges   a wave owns tiles of 16 edges (edges = the N dimension, like the forward kernel): recomputes
 //                          z1, h1, z2, h2 in registers, contracts dw with W2p over the weight columns (16 bytes per lane
 //                          and row: whole 64-byte pieces of 16 rows per load, the four floats being the B operands of
@@ -233,6 +234,245 @@ __global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_edges(
             for (int r = 0; r < 4; ++r) out1[(16 * tm + 4 * g + r) * HID + 16 * tn + c] = g_w1[tm][tn][r] * s1;
 }
 
+// ---- both halves in ONE kernel, dw read ONCE (w_pad <= 16 * 4 * FU_MAXCH) ---------------------------------------------
+// radial_mlp_bwd_edges + radial_mlp_bwd_w2 stream dw[E, w_pad] twice and pass h2[E, 32] through memory.  Here a workgroup
+// works in ROUNDS of four 16-edge tiles (tile t = wave t's tile of the round, the same edge assignment as above):
+//   phase 0  wave t recomputes z1, h1, z2, h2 of tile t and publishes h2 to LDS ([tile][edge][k]: the A operand of dW2p)
+//   phase A  the 16-column chunks of dw are dealt round-robin to the waves; for each of its chunks and each of the four
+//            tiles a wave loads the 16 x 16 piece of dw once (16 bytes per lane, whole 64-byte pieces of 16 rows) and uses
+//            it twice: as the B operand of dh2 += W2p dw^T (edges = N, as in radial_mlp_bwd_edges) and, transposed through
+//            a wave-private LDS tile, of dW2p += h2^T dw (edges = the contraction).  The wave's dW2p columns stay in
+//            registers for the whole walk (8 accumulator registers per chunk).
+//   phase B  the four waves' partial dh2 of tile t are added in wave order by wave t (LDS), which then runs the rest of
+//            the chain for its tile exactly as radial_mlp_bwd_edges does.
+// Partial sums: part_small per wave (as above), part_w2 per WORKGROUP; fixed order, no atomics.
+constexpr int FU_MAXCH = 8;                 // 16-column chunks per wave at most: w_pad <= 512
+constexpr int FU_HS = HID + 1;              // row stride of the published h2 tiles
+constexpr int FU_TT = 20;                   // row stride of the dw transpose tile (16-byte aligned rows)
+constexpr int FU_POOL = BW_WAVES * 64 * 8;  // floats per wave of the shared pool: partial dh2 [tile][lane][8] / the phase-B tiles
+static_assert((3 * HID + 16) * TS <= FU_POOL, "the phase-B transposes live in the wave's share of the pool");
+template <int KS0, bool BF16, int MAXCH>
+__global__ __launch_bounds__(BW_WAVES * 64, 2) void radial_mlp_bwd_fused(
+    const float4* __restrict__ geom, int64_t E, int n_basis, float r_start, float r_end, const float* __restrict__ w0p,
+    const float* __restrict__ w1p, const float* __restrict__ w2p, int w_pad, int w_cols, const void* __restrict__ dw,
+    int64_t dw_ld, float* __restrict__ part_small, float* __restrict__ part_w2, int tiles_per_wave, float s0, float s1,
+    float s2) {
+    // pool[wave]: the wave's partial dh2 [tile][lane][m, r] during phase A, its transposes in phase B (barrier between)
+    __shared__ __attribute__((aligned(16))) float pool[BW_WAVES][FU_POOL];
+    __shared__ float h2s[BW_WAVES][16 * FU_HS];                               // [tile][edge][k]
+    __shared__ __attribute__((aligned(16))) float tts[BW_WAVES][16 * FU_TT];   // dw piece [edge][column] (per wave)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t slice = (int64_t)blockIdx.x * BW_WAVES + wave;
+    float* t_h1 = pool[wave];
+    float* t_dz2 = t_h1 + HID * TS;
+    float* t_dz1 = t_dz2 + HID * TS;
+    float* t_b = t_dz1 + HID * TS;
+    float* tt = tts[wave];
+    // the small layers' weights as matrix operands: from LDS at every use (kept in registers they cost the kernel its
+    // second wave per SIMD)
+    __shared__ float w0s[16 * HID], w1s[HID * HID];
+    for (int i = threadIdx.x; i < 4 * KS0 * HID; i += BW_WAVES * 64) w0s[i] = w0p[i];
+    for (int i = threadIdx.x; i < HID * HID; i += BW_WAVES * 64) w1s[i] = w1p[i];
+    __syncthreads();
+    f32x4 g_w1[2][2], g_w0[2], g_w2[MAXCH][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        g_w0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) g_w1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) g_w2[j][0] = g_w2[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n_chunks = w_pad >> 4;
+    const int64_t wg_first = (int64_t)blockIdx.x * BW_WAVES * tiles_per_wave * 16;   // first edge of the workgroup
+    for (int round = 0; round < tiles_per_wave; ++round) {
+        if (wg_first + (int64_t)round * 16 >= E) break;   // uniform: not even wave 0 has a tile in this round
+        // ---- phase 0: forward of this wave's tile (z1, h1, z2 are recomputed in phase B: held across phase A they cost
+        // the registers that keep a second wave per SIMD) ----
+        const int64_t e0 = (slice * tiles_per_wave + round) * 16;
+        const int64_t e = e0 + c;
+        const bool e_ok = e < E;
+        const float len = geom[e_ok ? e : E - 1].w;
+        auto forward_tile = [&](float (&bes)[KS0], f32x4 (&z1)[2], f32x4 (&h1)[2], f32x4 (&z2)[2]) {
+            z1[0] = z1[1] = z2[0] = z2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS0; ++kk) {
+                const int k = 4 * kk + g;
+                bes[kk] = (k < n_basis && e_ok) ? matten::bessel_basis(len, k, n_basis, r_start, r_end) : 0.0f;
+                z1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0s[k * HID + c], bes[kk], z1[0], 0, 0, 0);
+                z1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0s[k * HID + 16 + c], bes[kk], z1[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[t][r] = silu(z1[t][r]);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float b = h1[kk >> 2][kk & 3];
+                const int kf = 16 * (kk >> 2) + 4 * g + (kk & 3);   // pi(kk, g): the feature the lane's D register (kk) holds
+                z2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1s[kf * HID + c], b, z2[0], 0, 0, 0);
+                z2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1s[kf * HID + 16 + c], b, z2[1], 0, 0, 0);
+            }
+        };
+        // wide layers (more than 4 chunks per wave) recompute z1, h1, z2 in phase B: held across phase A they would spill;
+        // narrow layers keep them (their phase A is short, the second evaluation would show: 0.20 vs 0.18 ms at 128 columns)
+        constexpr bool RECOMPUTE = MAXCH > 4;
+        float bes[KS0];
+        f32x4 z1[2], h1[2], z2[2];
+        {
+            float bes0[KS0];
+            f32x4 z1a[2], h1a[2], z2a[2];
+            if constexpr (RECOMPUTE) forward_tile(bes0, z1a, h1a, z2a);
+            else forward_tile(bes, z1, h1, z2);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)   // (0 for an edge past the end: its Bessel row is 0)
+                    h2s[wave][c * FU_HS + 16 * t + 4 * g + r] = silu(RECOMPUTE ? z2a[t][r] : z2[t][r]);
+        }
+        __syncthreads();
+        // ---- phase A: this wave's column chunks over the round's four tiles ----
+        f32x4 pdh[BW_WAVES][2];
+#pragma unroll
+        for (int t = 0; t < BW_WAVES; ++t) pdh[t][0] = pdh[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int64_t erow[BW_WAVES];
+        bool eok[BW_WAVES];
+#pragma unroll
+        for (int t = 0; t < BW_WAVES; ++t) {
+            const int64_t et = (((int64_t)blockIdx.x * BW_WAVES + t) * tiles_per_wave + round) * 16 + c;
+            eok[t] = et < E;
+            erow[t] = (eok[t] ? et : E - 1) * dw_ld;
+        }
+#pragma unroll
+        for (int jj = 0; jj < MAXCH; ++jj) {
+            const int j = jj * BW_WAVES + wave;
+            if (j < n_chunks) {   // uniform over the wave
+                const int q = 16 * j + 4 * g;
+                f32x4 b4[BW_WAVES];
+#pragma unroll
+                for (int t = 0; t < BW_WAVES; ++t) b4[t] = load4<BF16>(dw, erow[t] + q);
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(w2p + (int64_t)c * w_pad + q);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w2p + (int64_t)(16 + c) * w_pad + q);
+#pragma unroll
+                for (int t = 0; t < BW_WAVES; ++t) {
+                    f32x4 b = b4[t];
+#pragma unroll
+                    for (int sst = 0; sst < 4; ++sst) b[sst] = (q + sst < w_cols && eok[t]) ? b[sst] : 0.0f;   // pad columns of dw are never written: select
+#pragma unroll
+                    for (int sst = 0; sst < 4; ++sst) {
+                        pdh[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[sst], b[sst], pdh[t][0], 0, 0, 0);
+                        pdh[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[sst], b[sst], pdh[t][1], 0, 0, 0);
+                    }
+                    // the same piece with the edges as the contraction: [edge c][column 4 g + s] -> [edge 4 s + g][column c]
+                    *reinterpret_cast<f32x4*>(tt + c * FU_TT + 4 * g) = b;
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    float bt[4];
+#pragma unroll
+                    for (int sst = 0; sst < 4; ++sst) bt[sst] = tt[(4 * sst + g) * FU_TT + c];
+                    __builtin_amdgcn_wave_barrier();   // (the next piece's store follows these reads in the wave's LDS order)
+#pragma unroll
+                    for (int sst = 0; sst < 4; ++sst) {
+                        // A operand of dW2p: h2[tile][edge 4 s + g][k = c + 16 m]
+                        const float ha = h2s[t][(4 * sst + g) * FU_HS + c], hb = h2s[t][(4 * sst + g) * FU_HS + 16 + c];
+                        g_w2[jj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha, bt[sst], g_w2[jj][0], 0, 0, 0);
+                        g_w2[jj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb, bt[sst], g_w2[jj][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < BW_WAVES; ++t) {
+            *reinterpret_cast<f32x4*>(&pool[wave][(t * 64 + lane) * 8]) = pdh[t][0];
+            *reinterpret_cast<f32x4*>(&pool[wave][(t * 64 + lane) * 8 + 4]) = pdh[t][1];
+        }
+        __syncthreads();
+        // ---- phase B: dh2 of this wave's tile (waves added in order), then the chain of radial_mlp_bwd_edges ----
+        f32x4 dh2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int w = 0; w < BW_WAVES; ++w) {
+            dh2[0] += *reinterpret_cast<const f32x4*>(&pool[w][(wave * 64 + lane) * 8]);
+            dh2[1] += *reinterpret_cast<const f32x4*>(&pool[w][(wave * 64 + lane) * 8 + 4]);
+        }
+        __syncthreads();   // every wave has its sums: the pool now takes the transposes
+        if constexpr (RECOMPUTE) forward_tile(bes, z1, h1, z2);
+        f32x4 dz2[2], dh1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dz1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz2[t][r] = dh2[t][r] * dsilu(z2[t][r]);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float b = dz2[kk >> 2][kk & 3];
+            const int kf = 16 * (kk >> 2) + 4 * g + (kk & 3);
+            dh1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1s[c * HID + kf], b, dh1[0], 0, 0, 0);
+            dh1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1s[(16 + c) * HID + kf], b, dh1[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz1[t][r] = dh1[t][r] * dsilu(z1[t][r]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * t + 4 * g + r;
+                t_h1[k * TS + c] = h1[t][r];
+                t_dz2[k * TS + c] = dz2[t][r];
+                t_dz1[k * TS + c] = dz1[t][r];
+            }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) t_b[(4 * kk + g) * TS + c] = kk < KS0 ? bes[kk < KS0 ? kk : 0] : 0.0f;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int sst = 0; sst < 4; ++sst) {
+            const int ee = 4 * sst + g;
+            const float h1a = t_h1[c * TS + ee], h1b = t_h1[(16 + c) * TS + ee];
+            const float d2a = t_dz2[c * TS + ee], d2b = t_dz2[(16 + c) * TS + ee];
+            const float d1a = t_dz1[c * TS + ee], d1b = t_dz1[(16 + c) * TS + ee];
+            const float bb = t_b[c * TS + ee];
+            g_w1[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1a, d2a, g_w1[0][0], 0, 0, 0);
+            g_w1[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1a, d2b, g_w1[0][1], 0, 0, 0);
+            g_w1[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1b, d2a, g_w1[1][0], 0, 0, 0);
+            g_w1[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h1b, d2b, g_w1[1][1], 0, 0, 0);
+            g_w0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb, d1a, g_w0[0], 0, 0, 0);
+            g_w0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb, d1b, g_w0[1], 0, 0, 0);
+        }
+        __syncthreads();   // the next round overwrites h2s / dh2p
+    }
+    const int nb_pad = 4 * KS0;
+    float* out = part_small + slice * (int64_t)(nb_pad * HID + HID * HID);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k0 = 4 * g + r;
+            if (k0 < nb_pad) out[k0 * HID + 16 * tn + c] = g_w0[tn][r] * s0;
+        }
+    float* out1 = out + nb_pad * HID;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out1[(16 * tm + 4 * g + r) * HID + 16 * tn + c] = g_w1[tm][tn][r] * s1;
+    // dW2p[k = 16 m + 4 g + r][column 16 j + c] of this workgroup
+    float* out2 = part_w2 + (int64_t)blockIdx.x * HID * w_pad;
+#pragma unroll
+    for (int jj = 0; jj < MAXCH; ++jj) {
+        const int j = jj * BW_WAVES + wave;
+        if (j < n_chunks) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out2[(int64_t)(16 * m + 4 * g + r) * w_pad + 16 * j + c] = g_w2[jj][m][r] * s2;
+        }
+    }
+}
+
 // part_w2[range][32][w_pad]; grid = (ceil(w_pad / 64), n_ranges), wave w of a block owns columns [64 bx + 16 w, +16)
 template <bool BF16>
 __global__ __launch_bounds__(BW_WAVES * 64) void radial_mlp_bwd_w2(const float* __restrict__ h2, const void* __restrict__ dw,
@@ -305,7 +545,17 @@ __global__ __launch_bounds__(RED_COLS * RED_GROUPS) void radial_mlp_bwd_reduce(c
 extern "C" int64_t matten_radial_mlp_bwd_small_slices(int64_t n_edges) {
     return matten_cdiv(matten_cdiv(n_edges, bw_tiles(n_edges) * 16), BW_WAVES) * BW_WAVES;
 }
+// one kernel (dw read once) where the wave's share of dW2p fits its registers
+#ifndef BW_FUSED
+#define BW_FUSED 1
+#endif
+#ifndef BW_FUSED_MIN_W
+#define BW_FUSED_MIN_W 128   // narrower layers: too few column chunks for four waves (48 columns: 0.16 vs 0.13 ms at 293 k edges)
+#endif
+static inline bool bw_fused(int64_t w_pad) { return BW_FUSED && w_pad >= BW_FUSED_MIN_W && w_pad <= 16 * BW_WAVES * FU_MAXCH; }
+// partial rows of dW2p: one per workgroup of the fused kernel, else one per edge range of radial_mlp_bwd_w2
 extern "C" int64_t matten_radial_mlp_bwd_w2_ranges(int64_t n_edges, int64_t w_pad) {
+    if (bw_fused(w_pad)) return matten_radial_mlp_bwd_small_slices(n_edges) / BW_WAVES;
     return matten_cdiv(n_edges, w2_range(n_edges, w_pad));
 }
 
@@ -321,7 +571,19 @@ extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, 
     if (n_edges == 0) return MATTEN_OK;
     if (!geom_sorted || !w0p || !w1p || !w2p || !dw || !h2_scratch || !part_small || !part_w2) return MATTEN_EINVAL;
     const unsigned grid1 = (unsigned)(matten_radial_mlp_bwd_small_slices(n_edges) / BW_WAVES);
-#define LAUNCH(K, B)                                                                                                  \
+    const bool fused = bw_fused(w_pad);
+#define LAUNCH_FUSED_M(K, B, M)                                                                                       \
+    radial_mlp_bwd_fused<K, B, M><<<grid1, BW_WAVES * 64, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis,  \
+                                                                        r_start, r_end, w0p, w1p, w2p, w_pad, w_cols,  \
+                                                                        dw, dw_ld, part_small, part_w2,                \
+                                                                        bw_tiles(n_edges), scale0, scale1, scale2)
+#define LAUNCH_FUSED(K, B)                                                          \
+    do {                                                                            \
+        if (w_pad <= 16 * BW_WAVES * 4) LAUNCH_FUSED_M(K, B, 4);                    \
+        else if (w_pad <= 16 * BW_WAVES * 6) LAUNCH_FUSED_M(K, B, 6);               \
+        else LAUNCH_FUSED_M(K, B, FU_MAXCH);                                        \
+    } while (0)
+#define LAUNCH(K, B) if (fused) LAUNCH_FUSED(K, B); else                                                                                                  \
     radial_mlp_bwd_edges<K, B><<<grid1, BW_WAVES * 64, 0, stream>>>((const float4*)geom_sorted, n_edges, n_basis,     \
                                                                      r_start, r_end, w0p, w1p, w2p, w_pad, w_cols, dw, \
                                                                      dw_ld, h2_scratch, part_small, bw_tiles(n_edges), scale0, scale1)
@@ -335,9 +597,12 @@ extern "C" int matten_radial_mlp_bwd(const float* geom_sorted, int64_t n_edges, 
     if (dw_is_bf16) { LAUNCH_K(true) } else { LAUNCH_K(false) }
 #undef LAUNCH_K
 #undef LAUNCH
+#undef LAUNCH_FUSED
+#undef LAUNCH_FUSED_M
     MATTEN_LAUNCH_CHECK();
     dim3 grid2((unsigned)matten_cdiv(w_pad, 16 * BW_WAVES), (unsigned)matten_radial_mlp_bwd_w2_ranges(n_edges, w_pad));
-    if (dw_is_bf16)
+    if (fused) {
+    } else if (dw_is_bf16)
         radial_mlp_bwd_w2<true><<<grid2, BW_WAVES * 64, 0, stream>>>(h2_scratch, dw, dw_ld, n_edges, w_pad, part_w2,
                                                                      w2_range(n_edges, w_pad), scale2);
     else
