@@ -236,7 +236,9 @@ def test_training_script_loop_through_the_matten_alias(golden_dir):
     assert "metric_test/MeanAbsoluteError/elastic_tensor_full" in out[0]
 
 
-@pytest.mark.parametrize("n_edges,W", [(1, 48), (37, 216), (5000, 432), (4096 + 17, 842)])
+# (48 and 842 columns: two kernels; 128-512: the one-kernel adjoint at 4 / 6 / 8 chunks per wave; 70 001 edges: two rounds
+# per workgroup with a ragged last one)
+@pytest.mark.parametrize("n_edges,W", [(1, 48), (37, 216), (200, 128), (5000, 432), (70001, 330), (4096 + 17, 842)])
 def test_radial_mlp_kernels_forward_and_adjoint(n_edges, W):
     """matten_radial_mlp / matten_radial_mlp_bwd (fp32 MFMA, partial sums in a fixed order) against the plain formula of
     e3nn FullyConnectedNet([8, 32, 32, W], silu) differentiated by torch autograd in fp64: w, dW0, dW1, dW2; edges at and
