@@ -450,7 +450,8 @@ int matten_calib_copy(const float* src, float* dst, int64_t n_floats, matten_str
 /* the same adjoint with the literal-coefficient coupling code of the forward kernels (cg_gen.h): a thread owns (edge,
  * channel of one input block) and walks the block's paths; one atomic per (edge, channel, component) into dx.
  *   blocks[n_blocks,4] int32 {x_off, mul, l1, first path | n_paths << 16}; paths[n_paths,4] {l1*25+l2*5+l3, w_off, out_off, 0};
- *   max_mul = the largest mul of a block (sizes the launch); w_edge / dw fp32, or both bf16 when edge_is_bf16
+ *   sum_lanes = sum over the blocks of mul rounded up to a power of two (sizes the launch: the blocks' workgroup ranges
+ *   are laid end to end); w_edge / dw fp32, or both bf16 when edge_is_bf16
  * dx: two modes.  dx_edges == NULL: dx [N, d_in] zero-initialised, contributions meet through fp32 atomics (order not
  * fixed).  dx_edges != NULL (scratch [E, d_in]; every input block's columns are written, columns of input irreps without
  * a path must be zero on entry): each edge's contribution is stored and dx[n] = the sum over the edges leaving n in the

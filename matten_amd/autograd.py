@@ -157,7 +157,7 @@ class TensorProductScatterFn(torch.autograd.Function):
             # dx summed per source node in a fixed order (MATTEN_TP_BWD_DX=atomic: fp32 atomics, order not fixed)
             out_csr = ctx.out_csr if os.environ.get("MATTEN_TP_BWD_DX", "ordered") != "atomic" else None
             dx, dw = ops.tp_backward_lit(x, w_edge, sh, src, dst, mod._tables.get("bw_blocks", dev),
-                                         mod._tables.get("bw_paths", dev), mod.plan.bw_max_mul, g.contiguous(), ctx.avg,
+                                         mod._tables.get("bw_paths", dev), mod.plan.bw_sum_lanes, g.contiguous(), ctx.avg,
                                          ctx.num_neigh, out_csr=out_csr,
                                          blocks_cover_input=int(mod.plan.bw_blocks[:, 1].dot(2 * mod.plan.bw_blocks[:, 2] + 1))
                                          == mod.plan.d_in)
@@ -213,7 +213,7 @@ class FusedTensorProductFn(torch.autograd.Function):
         w_edge = ops.radial_mlp(geom, *ctx.rbf, w0p, w1p, w2p, out_dtype=EDGE_STORAGE_DTYPE)   # transient
         out_csr = ctx.out_csr if os.environ.get("MATTEN_TP_BWD_DX", "ordered") != "atomic" else None
         dx, dw = ops.tp_backward_lit(x, w_edge, sh, src, dst, mod._tables.get("bw_blocks", dev),
-                                     mod._tables.get("bw_paths", dev), mod.plan.bw_max_mul, g.contiguous(), ctx.avg,
+                                     mod._tables.get("bw_paths", dev), mod.plan.bw_sum_lanes, g.contiguous(), ctx.avg,
                                      ctx.num_neigh, out_csr=out_csr,
                                      blocks_cover_input=int(mod.plan.bw_blocks[:, 1].dot(2 * mod.plan.bw_blocks[:, 2] + 1))
                                      == mod.plan.d_in)

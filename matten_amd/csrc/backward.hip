@@ -1294,12 +1294,22 @@ __global__ void rows_segment_sum_kernel(const float* __restrict__ rows, int d, c
     out[idx] = acc;
 }
 
-__global__ __launch_bounds__(256) void tp_backward_lit_kernel(LitArgs a, const int4* __restrict__ blocks,
+// The grid is the input blocks' own workgroup ranges (cdiv(E * lanes per edge, 256) each) laid end to end: a 2-D grid sized
+// for the widest block left half of its workgroups without an edge (blocks of 4 channels beside blocks of 32: 100 k
+// empty workgroups per launch at 293 k edges).
+__global__ __launch_bounds__(256) void tp_backward_lit_kernel(LitArgs a, const int4* __restrict__ blocks, int n_blocks,
                                                               const int4* __restrict__ paths) {
-    const int4 blk = blocks[blockIdx.y];
-    int cu = 1;
-    while (cu < blk.y) cu <<= 1;                       // lanes per edge: the block's channels rounded up to a power of two
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int b = 0, cu = 1;
+    int64_t first = 0;   // first workgroup of block b
+    for (;; ++b) {
+        cu = 1;
+        while (cu < blocks[b].y) cu <<= 1;             // lanes per edge: the block's channels rounded up to a power of two
+        const int64_t n = (a.E * cu + 255) / 256;
+        if (b + 1 >= n_blocks || (int64_t)blockIdx.x < first + n) break;
+        first += n;
+    }
+    const int4 blk = blocks[b];
+    const int64_t idx = ((int64_t)blockIdx.x - first) * blockDim.x + threadIdx.x;
     const int64_t e = idx / cu;
     const int u = (int)(idx - e * cu);
     if (e >= a.E || u >= blk.y) return;
@@ -1316,14 +1326,14 @@ __global__ __launch_bounds__(256) void tp_backward_lit_kernel(LitArgs a, const i
 
 extern "C" int matten_tp_backward_lit(const float* x, int64_t d_in, const void* w_edge, int64_t w_ld, const float* sh_sorted,
                                       int64_t sh_stride, const int32_t* src_sorted, const int32_t* dst_sorted,
-                                      const int32_t* blocks, int64_t n_blocks, int64_t max_mul, const int32_t* paths,
+                                      const int32_t* blocks, int64_t n_blocks, int64_t sum_lanes, const int32_t* paths,
                                       int64_t n_paths, const float* g_agg, int64_t d_mid, float avg_num_neighbors,
                                       const float* num_neigh, int64_t n_edges, float* dx, void* dw, int64_t dw_ld,
                                       int edge_is_bf16, int64_t n_nodes, const int32_t* out_ptr, const int32_t* out_perm,
                                       float* dx_edges, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (n_edges < 0 || d_in <= 0 || n_blocks <= 0 || n_blocks > 65535 || n_paths <= 0 || d_mid <= 0 || max_mul <= 0 ||
-        max_mul > 4096 || w_ld <= 0 || dw_ld <= 0)
+    if (n_edges < 0 || d_in <= 0 || n_blocks <= 0 || n_blocks > 65535 || n_paths <= 0 || d_mid <= 0 || sum_lanes <= 0 ||
+        sum_lanes > 4096 * n_blocks || w_ld <= 0 || dw_ld <= 0)
         return MATTEN_EINVAL;
     if (dx_edges && (!out_ptr || !out_perm || n_nodes < 0)) return MATTEN_EINVAL;
     if (n_edges == 0) {
@@ -1336,14 +1346,13 @@ extern "C" int matten_tp_backward_lit(const float* x, int64_t d_in, const void* 
     if (!x || !w_edge || !sh_sorted || !src_sorted || !dst_sorted || !blocks || !paths || !g_agg || !dx || !dw)
         return MATTEN_EINVAL;
     if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
-    int64_t cu = 1;
-    while (cu < max_mul) cu <<= 1;
-    const int64_t gx = matten_cdiv(n_edges * cu, 256);
+    // sum_lanes = sum over the blocks of their lanes per edge (channels rounded up to a power of two): the blocks'
+    // workgroup ranges laid end to end need at most this many workgroups (the excess ones find no edge and leave)
+    const int64_t gx = matten_cdiv(n_edges * sum_lanes, 256) + n_blocks;
     if (gx >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
     LitArgs a{x, w_edge, sh_sorted, src_sorted, dst_sorted, g_agg, num_neigh, dx_edges ? dx_edges : dx, dw, n_edges, (int)d_in,
               (int)w_ld, (int)sh_stride, (int)d_mid, (int)dw_ld, edge_is_bf16, avg_num_neighbors, dx_edges ? 1 : 0};
-    tp_backward_lit_kernel<<<dim3((unsigned)gx, (unsigned)n_blocks), 256, 0, stream>>>(a, (const int4*)blocks,
-                                                                                      (const int4*)paths);
+    tp_backward_lit_kernel<<<(unsigned)gx, 256, 0, stream>>>(a, (const int4*)blocks, (int)n_blocks, (const int4*)paths);
     MATTEN_LAUNCH_CHECK();
     if (dx_edges && n_nodes > 0) {
         if (matten_cdiv(n_nodes * d_in, 256) >= ((int64_t)1 << 31)) return MATTEN_EINVAL;

@@ -735,7 +735,7 @@ def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk,
     return dx, dw
 
 
-def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths, max_mul: int, g_agg,
+def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths, sum_lanes: int, g_agg,
                     avg_num_neighbors: float, num_neigh=None, out_csr=None, blocks_cover_input: bool = True):
     """the adjoint of tp_backward with literal-coefficient coupling code (include/matten_hip.h matten_tp_backward_lit;
     tables plan.bw_blocks / bw_paths) -> (dx [N,d_in], dw [E, ld of w_edge]).
@@ -761,7 +761,7 @@ def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths,
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
     with _timed(f"tp_backward/d_mid={g_agg.shape[1]}/d_in={d_in}"):
         rc = lib.matten_tp_backward_lit(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
-                                        _ptr(src_sorted), _ptr(dst_sorted), _ptr(blocks), blocks.shape[0], int(max_mul),
+                                        _ptr(src_sorted), _ptr(dst_sorted), _ptr(blocks), blocks.shape[0], int(sum_lanes),
                                         _ptr(paths), paths.shape[0], _ptr(g_agg), g_agg.shape[1],
                                         float(avg_num_neighbors or 0.0), _ptr(num_neigh), E, _ptr(dx), _ptr(dw),
                                         dw.shape[1], int(w_edge.dtype == torch.bfloat16), N, _ptr(out_ptr), _ptr(out_perm),

@@ -190,6 +190,7 @@ class UVUPlan:
     bw_in_cols: np.ndarray = None
     # literal-coefficient adjoint (matten_tp_backward_lit): input blocks and their path lists
     bw_blocks: np.ndarray = None      # int32 [n_blocks, 4] {x_off, mul, l1, first path | n_paths << 16}
+    bw_sum_lanes: int = 0             # sum of the blocks' mul rounded up to a power of two (matten_tp_backward_lit's launch)
     bw_paths: np.ndarray = None       # int32 [n_paths, 4] {l1*25 + l2*5 + l3, w_off, out_off, 0}
     bw_max_mul: int = 0
 
@@ -456,6 +457,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
     return UVUPlan(
         bw_blocks=np.array(bw_blocks, dtype=np.int32).reshape(-1, 4), bw_paths=np.array(bw_paths, dtype=np.int32).reshape(-1, 4),
         bw_max_mul=max(b[1] for b in bw_blocks),
+        bw_sum_lanes=sum(1 << max(0, (int(b[1]) - 1).bit_length()) for b in bw_blocks),
         bw_in_ptr=bw_in_ptr, bw_in_cols=in_order.astype(np.int32),
         bw_col_meta=col_meta.astype(np.int32), bw_nnz_ijk=np.array(nnz_ijk, dtype=np.uint8).reshape(-1, 4),
         bw_nnz_c=np.array(nnz_c, dtype=np.float32),
