@@ -158,8 +158,9 @@ constexpr int WG_TB = MATTEN_WG_TB;   // tile block: WG_TB x WG_TB tiles of 16 x
 #define WG_LD(p) (p)
 #endif
 // Row slices.  Real data sets are far from uniform over species (the commonest of the 73 elements of the reference's
-// sample owns 7 % of the rows, the rarest 0.2 %), and a workgroup costs ~12 ns of dispatch even when it leaves at once
-// (measured: 16 slices for every species = 7008 workgroups per call, 84 us of pure dispatch), so a species' rows are cut
+// sample owns 7 % of the rows, the rarest 0.2 %), and a workgroup that leaves at once still costs ~12 ns of chip time here
+// (it reads its segment table and row range first; 16 slices for every species = 7008 workgroups per call: +84 us), so a
+// species' rows are cut
 // into slices of WG_SLICE_ROWS rows and the grid is the COMPACT list of (species, slice) items: item i belongs to the
 // species whose running slice count covers i (every species owns at least one item and writes zeros when it has no
 // rows).  n_items <= n_species + n_rows / WG_SLICE_ROWS, the grid size; the excess items leave.
