@@ -478,6 +478,19 @@ def extras(dev):
 
 
 
+def _dce_clause(model) -> str:
+    """what the last conv layer really runs, for config.workload (dead-output elimination)"""
+    from matten_amd.nn import conv as pconv
+
+    full = [m for m in model.backbone.modules() if type(m).__name__ == "PointConv"]
+    last = full[-1]
+    if last._view is None or not pconv.DEAD_PATH_ELIMINATION:
+        return "; every conv layer run in full"
+    return (f"; last conv layer run for its live outputs only ({last._view.tp.plan.weight_numel}/{last.tp.plan.weight_numel} "
+            f"radial-weight columns: the irreps its only reader takes) -- `value` counts 4 edge-TP per edge all the same, "
+            f"`value_full_layers` is the rate with the full last layer")
+
+
 def algorithmic_bytes_tp_kernel(plan, deg: float) -> float:
     """Per-edge algorithmic bytes of ONE TP+scatter launch (DESIGN.md 'kernels'): edge ids (8) + edge
     vector (12) + the per-edge weights read once (4 W) + node rows amortised over the degree."""
@@ -541,14 +554,19 @@ def run_rank(args):
     n_nodes = int(batch["pos"].shape[0])
     gathered = torch.empty(world * B, 21, dtype=torch.float32, device="cpu" if via_host else dev) if distributed else None
 
-    def step():
+    def forward_only():
+        """this rank's forward WITHOUT the gather: what rank-local side work (calibration re-warm, clock probe load) runs --
+        a collective there would have no peer on the other ranks"""
         with torch.no_grad():
             preds, _ = model(dict(batch))
-            out = preds["elastic_tensor_full"]
-            if distributed:
-                dist.all_gather_into_tensor(gathered, out.cpu() if via_host else out)
-                return gathered
-            return out
+            return preds["elastic_tensor_full"]
+
+    def step():
+        out = forward_only()
+        if distributed:
+            dist.all_gather_into_tensor(gathered, out.cpu() if via_host else out)
+            return gathered
+        return out
 
     def barrier():
         if distributed:
@@ -562,10 +580,10 @@ def run_rank(args):
         step()
     barrier()
     calibration = None
-    if rank == 0 and not args.no_calibration and not args.share_gpu:
+    if rank == 0 and not args.no_calibration:   # (also in the --share-gpu rehearsal: the branch must not hide a collective)
         calibration = {"before": calibrate(dev)}
         for _ in range(2):          # the calibration kernels evicted the caches the warm-up filled
-            step()
+            forward_only()          # (rank-local: no collective, the other ranks are waiting in the barrier below)
     barrier()
     # HIP events around the dominant kernel (roofline) and the radial-MLP kernel (mfma) only: an event pair costs a few
     # microseconds of queue time, the timed region should not pay it for every launch
@@ -590,17 +608,17 @@ def run_rank(args):
         probe_clocks = torch.zeros(2, dtype=torch.int64, device=dev)
         side = torch.cuda.Stream(dev)
         n_probe = 6
-        window_ticks = int(1e8 * (n_probe - 1) * elapsed / args.steps)          # 100 MHz ticks of n_probe - 1 forwards
+        # 100 MHz ticks of n_probe - 1 forwards; the probe kernel accepts at most 1 s (steps above 200 ms: a shorter window)
+        window_ticks = min(100_000_000, max(1, int(1e8 * (n_probe - 1) * elapsed / args.steps)))
         side.wait_stream(torch.cuda.current_stream(dev))
-        step()                                                                   # the load is up before the probe starts
+        forward_only()                                                           # the load is up before the probe starts
         with torch.cuda.stream(side):
-            _mlib.check(lib_.matten_calib_clock_probe(max(1, window_ticks), probe_clocks.data_ptr(), side.cuda_stream),
-                        "matten_calib_clock_probe")
+            probe_rc = lib_.matten_calib_clock_probe(window_ticks, probe_clocks.data_ptr(), side.cuda_stream)
         for _ in range(n_probe):
-            step()
+            forward_only()                                                       # rank-local load: no collective
         model.finish_input_checks()
         torch.cuda.synchronize()
-        tk, rf = (int(v) for v in probe_clocks.tolist())
+        tk, rf = (int(v) for v in probe_clocks.tolist()) if probe_rc == 0 else (0, 0)   # a failed probe never kills the line
         calibration["sclk_mhz_during_forward"] = 100.0 * tk / rf if rf else None
         calibration["after"] = calibrate(dev)
     if distributed:
@@ -628,11 +646,14 @@ def run_rank(args):
         "data": "synthetic",
         "crystals_per_sec": crystals_per_s,
         "rccl_ranks": dist.get_world_size() if (distributed and not via_host) else 0,   # 0: no RCCL process group
+        # what a step returned on this rank: [B, 21] alone, [world * B, 21] after the all_gather (finite: asserted above)
+        "output_shape": list(out.shape),
         "backend": ("gloo (REHEARSAL: host-side gather" + (", all ranks on cuda:0" if args.share_gpu else "") + "; not a "
                     "measurement)") if via_host else ("nccl (RCCL)" if distributed else None),
         "config": {
             "workload": "configs[2]: synthetic fcc-64 crystals (64 atoms, cutoff 5 A, 1152 edges each), "
-                        "paper hparams lmax=4, eval forward backbone+out_layer, one batch per step per GPU",
+                        "paper hparams lmax=4, eval forward backbone+out_layer, one batch per step per GPU"
+                        + _dce_clause(model),
             "crystals_per_gpu_per_step": B,
             "nodes_per_gpu": n_nodes,
             "edges_per_gpu": n_edges,
@@ -674,6 +695,12 @@ def run_rank(args):
             rec = {"kernel": kern, "d_mid": p.d_mid, "weight_numel": p.weight_numel, "ms": per_kernel.get(k),
                    "algorithmic_bytes": contract_bytes(p, p.weight_numel, p.d_in, p.d_mid)}
             rec["achieved_GBps"] = rec["algorithmic_bytes"] / (rec["ms"] * 1e-3) / 1e9 if rec["ms"] else None
+            # what THIS design has to move per launch (w[E, W] never exists): split hidden features 128 B + harmonics row
+            # 128 B + source index 4 B per edge; row pointer 4 B, the input row once and the neighbour-sum row as laid
+            # out (component-major, padded) per node; the layer's pre-split A fragments
+            ld_out = m.agg_plan.ld if getattr(m, "agg_plan", None) is not None else p.d_mid
+            rec["compulsory_bytes_fused_design"] = ((128.0 + 128.0 + 4.0) * n_edges + (4.0 + 4.0 * p.d_in + 4.0 * ld_out) * n_nodes
+                                                    + 2.0 * 2 * 32 * 16 * p.fused_a_tiles)
             layers.append(rec)
         avg_ms = None
         # dominant kernel = the one with the most time per forward, averaged over ITS launches of the timed region like
@@ -682,12 +709,13 @@ def run_rank(args):
         by_kernel = {}
         for r in layers:
             if r["ms"]:
-                by_kernel.setdefault(r["kernel"], []).append((r["ms"], r["algorithmic_bytes"]))
-        dom_name = max(by_kernel, key=lambda kn: sum(m for m, _ in by_kernel[kn])) if by_kernel else None
+                by_kernel.setdefault(r["kernel"], []).append((r["ms"], r["algorithmic_bytes"], r["compulsory_bytes_fused_design"]))
+        dom_name = max(by_kernel, key=lambda kn: sum(m for m, _, _ in by_kernel[kn])) if by_kernel else None
         dom = by_kernel.get(dom_name, [])
         if dom:
-            bytes_per_launch = sum(b for _, b in dom) / len(dom)
-            avg_ms = sum(m for m, _ in dom) / len(dom)
+            bytes_per_launch = sum(b for _, b, _ in dom) / len(dom)
+            compulsory = sum(c for _, _, c in dom) / len(dom)
+            avg_ms = sum(m for m, _, _ in dom) / len(dom)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             traffic, traffic_source = _pmc_traffic(dom_name)
             result["roofline"] = {
@@ -711,6 +739,10 @@ def run_rank(args):
                 "physical_bound": "fp32 VALU issue at 3 waves/SIMD (DESIGN.md section 4; `valu` below); HBM is the bound "
                                   "of the contract figure only",
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                # bytes the fused design cannot avoid (per_layer[].compulsory_bytes_fused_design) and how much more the
+                # memory system moved: re-reads / partial-line writes show up here
+                "compulsory_bytes_per_launch": compulsory,
+                "traffic_over_compulsory": None if traffic is None else traffic / compulsory,
                 "avg_launch_ms": avg_ms,
                 "per_layer": layers,
             }
@@ -795,7 +827,6 @@ def run_rank(args):
                           "conv layer without its dead output irreps) over those of the full layers",
             "executed_share": executed_share,
             "frac": value / world * B_ALG_PER_EDGE_TP * executed_share / HBM_PEAK,
-            "frac_at_full_model_bytes": value / world * B_ALG_PER_EDGE_TP / HBM_PEAK,
         }
         lastf, laste = full_convs[-1], convs[-1]
         result["dead_output_elimination"] = {
@@ -833,23 +864,27 @@ def run_rank(args):
 
             gc.collect()               # the captured graph and its private memory pool go NOW, not at some collection
             torch.cuda.empty_cache()   # inside a later timed loop (a one-off ~100 ms stall in the extras otherwise)
-        if laste is not lastf and world == 1 and not distributed and not args.no_extras:
-            # the same workload with the full last layer, timed by the same loop (shorter: 3 + 10 forwards)
+        if laste is not lastf and world == 1 and not distributed:
+            # the same workload with the FULL last layer, timed by the same loop at the same steps / warm-up (like for like
+            # with SURVEY's 4816 B per edge-TP: path_roofline.frac_full_layers)
             pconv.DEAD_PATH_ELIMINATION = False
             try:
-                for _ in range(3):
+                for _ in range(args.warmup):
                     step()
                 barrier()
                 t1 = time.perf_counter()
-                for _ in range(10):
+                for _ in range(args.steps):
                     step()
                 model.finish_input_checks()
                 barrier()
-                ms_full = 1e3 * (time.perf_counter() - t1) / 10
+                ms_full = 1e3 * (time.perf_counter() - t1) / args.steps
             finally:
                 pconv.DEAD_PATH_ELIMINATION = True
+            result["ms_per_step_full_layers"] = ms_full
+            result["value_full_layers"] = n_edges * n_layers / (ms_full * 1e-3)
+            result["path_roofline"]["frac_full_layers"] = result["value_full_layers"] * B_ALG_PER_EDGE_TP / HBM_PEAK
             result["dead_output_elimination"]["without_it"] = {
-                "ms_per_step": ms_full, "value": n_edges * n_layers / (ms_full * 1e-3), "steps": 10, "warmup": 3}
+                "ms_per_step": ms_full, "value": result["value_full_layers"], "steps": args.steps, "warmup": args.warmup}
 
         # ---- CPU baseline: the oracle on a bounded sample of the same workload ----
         if world == 1 and not args.no_cpu_baseline:

@@ -570,6 +570,17 @@ extern "C" int matten_radial_hidden(const float* geom_sorted, int64_t n_edges, i
     return MATTEN_OK;
 }
 
+#if TPF_TRACING
+static unsigned* g_tp_trace = nullptr;
+static int64_t g_tp_trace_waves = 0, g_tp_trace_skip = 0;
+// lab builds only (tools/tp_trace.py): the waves of ONE matten_tp_fused launch -- the one after `skip` further launches --
+// write 16 words each into buf (skip < 0: every launch until disarmed with buf = NULL)
+extern "C" int matten_lab_tp_trace(unsigned* buf, int64_t n_waves, int64_t skip) {
+    g_tp_trace = buf, g_tp_trace_waves = n_waves, g_tp_trace_skip = skip;
+    return 0;
+}
+#endif
+
 extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
                                const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr,
                                const int32_t* src_sorted, int64_t n_nodes, const int32_t* group_entries,
@@ -594,6 +605,14 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
     const int blocks_per_tile = (int)matten_cdiv(units_per_tile, WAVES_PER_BLOCK);
     const int64_t grid = matten_cdiv(n_tiles, N_XCD) * N_XCD * (int64_t)blocks_per_tile;
     if (grid >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+#if TPF_TRACING
+    a.trace = nullptr;
+    if (g_tp_trace && grid * WAVES_PER_BLOCK <= g_tp_trace_waves) {
+        if (g_tp_trace_skip <= 0) a.trace = g_tp_trace;
+        if (g_tp_trace_skip == 0) g_tp_trace = nullptr;
+        if (g_tp_trace_skip > 0) --g_tp_trace_skip;
+    }
+#endif
     tp_fused_kernel<<<(unsigned)grid, WAVES_PER_BLOCK * 64, lds, stream>>>(
         a, (const GroupEntry*)group_entries, unit_map, (int)n_entries, (int)units_per_tile, blocks_per_tile, n_tiles);
     MATTEN_LAUNCH_CHECK();

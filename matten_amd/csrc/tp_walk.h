@@ -61,7 +61,30 @@ constexpr bool TPF_LAB_NO_LOOP = true;
 constexpr bool TPF_LAB_NO_LOOP = false;
 #endif
 
+// -DMATTEN_LAB -DTPF_TRACE: every contracting wave of a shared workgroup records where its cycles go (s_memtime at the
+// phase boundaries of the chunk loop, summed per wave) into a buffer set through matten_lab_tp_trace (tp_fused.hip)
+#if defined(MATTEN_LAB) && defined(TPF_TRACE)
+#define TPF_TRACING 1
+#else
+#define TPF_TRACING 0
+#endif
+
 namespace matten_walk {
+
+#if TPF_TRACING
+__device__ __forceinline__ unsigned long long tpf_stamp() {
+    unsigned long long t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+template <int N>
+__device__ __forceinline__ unsigned long long tpf_stamp_after(float (&acc)[N]) {   // ... once the accumulators exist
+    unsigned long long t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(t), "+v"(acc[0]), "+v"(acc[N / 2]), "+v"(acc[N - 1]) : : "memory");
+    return t;
+}
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -137,6 +160,9 @@ struct Args {
     float* agg;
     int d_in, w_pad, sh_stride, d_mid, n_nodes, lds_per_wave;
     float avg_nn;
+#if TPF_TRACING
+    unsigned* trace;   // [waves of the launch][16]
+#endif
 };
 
 // ---- workgroup-shared staging (units flagged by the host, plan.fused_unit_map) --------------------------------------
@@ -342,6 +368,10 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                                                  float* __restrict__ stage, int entry, int node, int lane, bool valid,
                                                  int beg, int deg_node, int maxdeg, const Epilogue& epi) {
     static_assert(!PAIRED || TT == 1, "paired workgroups stage 2 x 16 rows");
+#if TPF_TRACING
+    const unsigned long long tr_in = tpf_stamp();
+    unsigned tr_mfma = 0, tr_con = 0, tr_pub = 0, tr_bar = 0, tr_chunks = 0;
+#endif
     const int row0 = PAIRED ? 16 * (int)(threadIdx.x >> 7) : 0;       // this wave's half of a paired stage
     constexpr int STAGE_BUF = (PAIRED ? 32 : 16 * TT) * STAGE_ROW;    // floats per stage buffer
     const int deg = valid ? deg_node : 0;
@@ -456,6 +486,10 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     }
     ld.publish(0);
     __syncthreads();
+#if TPF_TRACING
+    const unsigned long long tr_loop = tpf_stamp();
+    unsigned long long tr_a = tr_loop;
+#endif
     int buf = 0;
     for (int s0 = 0; s0 < maxdeg; s0 += CH, buf ^= 1) {
         // the short serial head of a chunk (issue the stage loads, LDS -> MFMA -> LDS) runs at raised priority: it is a
@@ -486,6 +520,9 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the weight tile is written
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_setprio(0);
+#if TPF_TRACING
+        const unsigned long long tr_b = tpf_stamp();
+#endif
         auto contract = [&](int so, const float* __restrict__ x) {
 #if TPF_COMPACT
             const float* wp = tile + ((j << ch_log2) + so) * stride + u * ncl;
@@ -549,15 +586,41 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                 if (s < deg) contract(so, x);
             }
         }
+#if TPF_TRACING
+        const unsigned long long tr_c = tpf_stamp_after(acc);
+#endif
         ld.publish(buf ^ 1);
+#if TPF_TRACING
+        const unsigned long long tr_d = tpf_stamp();
+#endif
         if constexpr (TPF_LAB_NO_BARRIER) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
         } else {
             __syncthreads();  // the next stage is published; every wave is done with this chunk's rows
         }
+#if TPF_TRACING
+        const unsigned long long tr_e = tpf_stamp();
+        tr_mfma += (unsigned)(tr_b - tr_a), tr_con += (unsigned)(tr_c - tr_b), tr_pub += (unsigned)(tr_d - tr_c);
+        tr_bar += (unsigned)(tr_e - tr_d), tr_chunks += 1;
+        tr_a = tr_e;
+#endif
     }
+#if TPF_TRACING
+    const unsigned long long tr_end = tpf_stamp();
+#endif
     epi.template store<G>(a, ge, acc, a_scale_inv, node, j, u, valid);
+#if TPF_TRACING
+    if (a.trace && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tr_out = tpf_stamp();
+        unsigned* tr = a.trace + ((size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 16;
+        tr[0] = 1u, tr[1] = (unsigned)ge.kind, tr[2] = (unsigned)cu_log2 | (PAIRED ? 256u : 0u) | ((unsigned)TT << 12) | ((unsigned)MT << 16);
+        tr[3] = tr_chunks, tr[4] = (unsigned)(tr_loop - tr_in), tr[5] = tr_mfma, tr[6] = tr_con, tr[7] = tr_pub, tr[8] = tr_bar;
+        tr[9] = (unsigned)(tr_out - tr_end), tr[10] = (unsigned)(tr_out - tr_in), tr[11] = (unsigned)ge.mask;
+        tr[12] = (unsigned)(tr_in & 0xffffffffu), tr[13] = (unsigned)(tr_in >> 32);
+    }
+#endif
 }
 
 // Coupling masks worth a specialisation: only the scalar-block kind (all five couplings, or l2 <= 3 when the target has

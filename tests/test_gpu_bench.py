@@ -1,0 +1,80 @@
+"""bench.py's distributed branch under the driver's eyes (pytest -m gpu on the 1-GPU box): the RCCL code path with one
+rank, and the N > 1 branch rehearsed with two gloo ranks on one device INCLUDING rank 0's calibration side work (a
+collective inside it would have no peer: advisor finding of round 4).  No scaling number comes out of either."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench_line(args, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MATTEN_FORCE_DIST"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # a CHILD process: this pytest process has initialised the GPU and must never exec
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """`bench.py --gpus 1 --force-dist`: init_process_group("nccl") = RCCL, barrier, all_gather_into_tensor of the [B, 21]
+    predictions, max-over-ranks all_reduce -- everything `--gpus 8` runs, with one rank.  Rank 0's calibration (fixed
+    kernels + clock probe beside untimed forwards) stays on: it must not issue a collective."""
+    d = _bench_line(["--gpus", "1", "--force-dist", "--no-extras", "--no-cpu-baseline", "--steps", "3", "--warmup", "2"])
+    assert d["rccl_ranks"] == 1 and d["n_gpus"] == 1 and d["backend"] == "nccl (RCCL)"
+    assert d["output_shape"] == [1000, 21] and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["config"]["sharding"].startswith("batch-index x1")
+    assert d["calibration"]["sclk_mhz_during_forward"] and "roofline" in d
+
+
+def test_bench_two_rank_rehearsal_keeps_calibration():
+    """`--gpus 2 --backend gloo --share-gpu`: two ranks on cuda:0, predictions gathered through host tensors.  Measures
+    nothing; what it proves is that the N > 1 branch terminates with calibration ON (rank 0 alone runs side work between
+    the barriers) and gathers [2 B, 21]."""
+    d = _bench_line(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--no-extras", "--no-cpu-baseline", "--steps", "3",
+                     "--warmup", "1", "--crystals", "100"])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 0 and "REHEARSAL" in d["backend"]
+    assert d["output_shape"] == [200, 21]
+    assert d["calibration"]["before"]["valu"]["ms"] > 0 and d["calibration"]["after"]["copy"]["GBps"] > 0
+
+
+def test_eight_rank_shards_tile_one_set():
+    """configs[4]: rank r of 8 owns crystals [r B, (r + 1) B) of ONE set of 8 B crystals (synthetic.fcc64_shard): the shards
+    laid end to end ARE that set -- positions, species, edge lists -- and the device forward of shard r equals rows
+    [r B, (r + 1) B) of the forward of the whole set (a crystal's prediction does not depend on its batch mates: bitwise
+    within one kernel path, to 2e-6 of the block's scale across the batch-size dependent piece lengths of small batches),
+    which is what the single all_gather over xGMI relies on."""
+    from __graft_entry__ import PAPER_HPARAMS
+    from matten_amd.data import synthetic as S
+    from matten_amd.data.graph import collate
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+
+    B, W = 3, 8
+    whole = S.fcc64_graphs(W * B, S.FCC_SEED + 1)
+    shards = [S.fcc64_shard(r, W, B) for r in range(W)]
+    flat = [g for sh in shards for g in sh]
+    assert len(flat) == len(whole)
+    for a, b in zip(whole, flat):
+        assert all(torch.equal(a[k], b[k]) for k in ("pos", "edge_index", "atomic_numbers", "cell", "edge_cell_shift"))
+    torch.manual_seed(35)
+    ds = {"allowed_species": list(S.FCC_METALS), "average_num_neighbors": 18.0}
+    model = ScalarTensorModel(backbone_hparams=dict(PAPER_HPARAMS), dataset_hparams=ds).to("cuda:0").eval()
+    with torch.no_grad():
+        full = model(collate(whole, device="cuda:0"))[0]["elastic_tensor_full"]
+        for r in (0, 3, 7):
+            part = model(collate(shards[r], device="cuda:0"))[0]["elastic_tensor_full"]
+            want = full[r * B:(r + 1) * B]
+            for lo, hi in ((0, 2), (2, 12), (12, 21)):     # per irrep block of the 21 components, against the block's scale
+                err = (part[:, lo:hi] - want[:, lo:hi]).abs().max().item()
+                assert err <= 2e-6 * full[:, lo:hi].abs().max().item() + 1e-12, (r, lo, err)

@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${TAG}_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-calibration > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
 done
 python3 - <<PY
-import csv, json, collections, re
+import csv, json, collections, re, os
 R="$R"; TAG="$TAG"
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -36,7 +36,9 @@ doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
        "tag": TAG, "kernels": out}
 try:
     import subprocess
-    doc["commit"] = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    # the GPU box has no .git: tools/gpu.sh writes the commit (+ "-dirty") into .head_commit before every gpurun call
+    doc["commit"] = (subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+                     or (open(os.path.join(R, ".head_commit")).read().strip() if os.path.exists(os.path.join(R, ".head_commit")) else None))
 except Exception:
     pass
 json.dump(doc, open(f"{R}/gpurun_out/traffic_{TAG}.json", "w"), indent=1)

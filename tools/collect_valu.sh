@@ -13,7 +13,7 @@ for P in "$P1" "$P2"; do i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/valu_${TAG}_$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-calibration > $R/gpurun_out/valu_${TAG}_$i.log 2>&1
 done
 python3 - <<PY
-import csv, json, collections, re, subprocess
+import csv, json, collections, re, subprocess, os
 R="$R"; TAG="$TAG"
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for i in (1, 2):
@@ -37,7 +37,9 @@ doc = {"source": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes, to
                  "quad-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES cycles (MI355X_MICROARCH.md)",
        "tag": TAG, "kernels": out}
 try:
-    doc["commit"] = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    # the GPU box has no .git: tools/gpu.sh writes the commit (+ "-dirty") into .head_commit before every gpurun call
+    doc["commit"] = (subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+                     or (open(os.path.join(R, ".head_commit")).read().strip() if os.path.exists(os.path.join(R, ".head_commit")) else None))
 except Exception:
     pass
 json.dump(doc, open(f"{R}/gpurun_out/valu_{TAG}.json", "w"), indent=1)

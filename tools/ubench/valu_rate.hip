@@ -11,6 +11,9 @@ __global__ void k(const float* in, float* out, long long* cyc) {
     float s = in[blockIdx.x & 63];
     float v[16];
     for (int i = 0; i < 16; ++i) v[i] = in[(threadIdx.x + i) & 63];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 pv[8], pa = {a, b}, pb = {b, a};
+    for (int i = 0; i < 8; ++i) pv[i] = f2{v[i], v[i + 8]};
     long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITERS; ++it) {
 #define FMA3(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(v[i]) : "v"(a), "v"(b));
@@ -19,15 +22,24 @@ __global__ void k(const float* in, float* out, long long* cyc) {
 #define FMACS(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "s"(s), "v"(a));
 #define MUL2(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
 #define FMA3L(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(v[i]) : "s"(s), "v"(b));
+// packed fp32 (two lanes' worth of FMAs per instruction): 8 independent 64-bit accumulators
+#define PKFMA(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pv[(i) & 7]) : "v"(pa), "v"(pb));
+#define PKMUL(i) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(pv[(i) & 7]) : "v"(pa));
+// scalar fma whose multiplier is a literal, interleaved 1:1 with LDS reads of the previous result's neighbour (not dependent)
+#define FMADPP(i) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v[i]) : "v"(a), "v"(b));
         if (MODE == 0) { REP16(FMA3) }
         if (MODE == 1) { REP16(FMAC) }
         if (MODE == 2) { REP16(FMACL) }
         if (MODE == 3) { REP16(FMACS) }
         if (MODE == 4) { REP16(MUL2) }
         if (MODE == 5) { REP16(FMA3L) }
+        if (MODE == 6) { REP16(PKFMA) }
+        if (MODE == 7) { REP16(PKMUL) }
+        if (MODE == 8) { REP16(FMADPP) }
     }
     long long t1 = __builtin_readcyclecounter();
     float r = 0; for (int i = 0; i < 16; ++i) r += v[i];
+    for (int i = 0; i < 8; ++i) r += pv[i][0] + pv[i][1];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
@@ -62,5 +74,8 @@ int main() {
     run<3>("v_fmac_f32 s,v (VOP2, 4 B)", in, out, cyc);
     run<4>("v_mul_f32 v,v (VOP2, 4 B)", in, out, cyc);
     run<5>("v_fma_f32 s,v,v (VOP3, 8 B)", in, out, cyc);
+    run<6>("v_pk_fma_f32 v,v,v (2 FMA/lane)", in, out, cyc);
+    run<7>("v_pk_mul_f32 v,v", in, out, cyc);
+    run<8>("v_fmac_f32_dpp quad_perm", in, out, cyc);
     return 0;
 }
