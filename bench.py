@@ -108,9 +108,9 @@ def calibrate(dev, copy_floats: int = 1 << 28, valu_iters: int = 4096, reps: int
       copy: 1 GiB read + 1 GiB written, 16 bytes per lane -> GB/s"""
     import ctypes
 
-    from matten_amd import _lib, ops
+    from matten_amd import _lib, lab, ops
 
-    lib = _lib.load()
+    lib = lab.load()    # libmatten_lab.so (make lab): measurement helpers, not part of the product library
     stream = ops._stream()
     src = torch.empty(copy_floats, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
@@ -580,14 +580,16 @@ def run_rank(args):
         step()
     barrier()
     calibration = None
-    if rank == 0 and not args.no_calibration:   # (also in the --share-gpu rehearsal: the branch must not hide a collective)
+    from matten_amd import lab as _lab_probe
+
+    if rank == 0 and not args.no_calibration and _lab_probe.load() is not None:   # (also in the --share-gpu rehearsal)
         calibration = {"before": calibrate(dev)}
         for _ in range(2):          # the calibration kernels evicted the caches the warm-up filled
             forward_only()          # (rank-local: no collective, the other ranks are waiting in the barrier below)
     barrier()
     # HIP events around the dominant kernel (roofline) and the radial-MLP kernel (mfma) only: an event pair costs a few
     # microseconds of queue time, the timed region should not pay it for every launch
-    ops.enable_event_timing(True, only=("tp_scatter", "conv_tile", "agg_linear", "radial_hidden"))
+    ops.enable_event_timing(True, only=("tp_scatter", "agg_linear", "radial_hidden"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -602,9 +604,9 @@ def run_rank(args):
         # the shader clock the chip sustains UNDER THE FORWARD's load: a one-wave probe on a side stream watches the clocks
         # while a few more (untimed) forwards run.  The fixed kernels of calibrate() run at full clock on boxes whose
         # power-hungry tensor-product kernels clock 7 % lower: this is the number two BENCH lines are normalised by.
-        from matten_amd import _lib as _mlib
+        from matten_amd import lab as _mlab
 
-        lib_ = _mlib.load()
+        lib_ = _mlab.load()
         probe_clocks = torch.zeros(2, dtype=torch.int64, device=dev)
         side = torch.cuda.Stream(dev)
         n_probe = 6
@@ -684,14 +686,9 @@ def run_rank(args):
         layers = []
         for m in convs:
             p = m.tp.plan
-            tiled = (m.tile_plan is not None and pconv.CONV_TILE != "0" and n_nodes >= pconv.CONV_TILE_MIN_ROWS
-                     and p.d_mid >= pconv.CONV_TILE_MIN_DMID)
-            if tiled:
-                k, kern = f"conv_tile/d_out={m.tile_plan.d_out}/d_in={p.d_in}", "conv_tile_kernel"
-            else:
-                # the row stride of the neighbour sums names the launch: component-major rows are padded (plan_agg_linear)
-                k = f"tp_scatter/d_mid={m.agg_plan.ld if getattr(m, 'agg_plan', None) is not None else p.d_mid}/d_in={p.d_in}"
-                kern = "tp_fused_kernel"
+            # the row stride of the neighbour sums names the launch: component-major rows are padded (plan_agg_linear)
+            k = f"tp_scatter/d_mid={m.agg_plan.ld if getattr(m, 'agg_plan', None) is not None else p.d_mid}/d_in={p.d_in}"
+            kern = "tp_fused_kernel"
             rec = {"kernel": kern, "d_mid": p.d_mid, "weight_numel": p.weight_numel, "ms": per_kernel.get(k),
                    "algorithmic_bytes": contract_bytes(p, p.weight_numel, p.d_in, p.d_mid)}
             rec["achieved_GBps"] = rec["algorithmic_bytes"] / (rec["ms"] * 1e-3) / 1e9 if rec["ms"] else None
@@ -704,8 +701,7 @@ def run_rank(args):
             layers.append(rec)
         avg_ms = None
         # dominant kernel = the one with the most time per forward, averaged over ITS launches of the timed region like
-        # rocprofv3 --stats does: conv_tile_kernel (tensor product + neighbour sum + lin2 + Gate on 16-node tiles) for the
-        # layers that run it, tp_fused_kernel (tensor product + neighbour sum, agg to HBM) for the others
+        # rocprofv3 --stats does: tp_fused_kernel (tensor product + neighbour sum, agg to HBM)
         by_kernel = {}
         for r in layers:
             if r["ms"]:
@@ -719,8 +715,7 @@ def run_rank(args):
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             traffic, traffic_source = _pmc_traffic(dom_name)
             result["roofline"] = {
-                "kernel": f"{dom_name} (last radial-MLP layer on MFMA + CG paths + neighbour sum"
-                          f"{' + lin2 + Gate per 16-node tile, agg never written' if dom_name == 'conv_tile_kernel' else ''}; "
+                "kernel": f"{dom_name} (last radial-MLP layer on MFMA + CG paths + neighbour sum; "
                           f"mean over its {len(dom)} launches per forward)",
                 "bound": "hbm",
                 "achieved": achieved,
@@ -733,7 +728,7 @@ def run_rank(args):
                 "traffic_source": traffic_source,
                 # `achieved` / `frac` price the CONTRACT bytes of the tensor-product share of the launch (SURVEY 8d
                 # two-kernel architecture: ids, edge vector, radial weights w[E, W] read once, node rows over the degree --
-                # w and, in conv_tile_kernel, agg never exist here).  What the memory system really moves:
+                # w never exists here).  What the memory system really moves:
                 "measured_GBps": None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9,
                 "measured_frac": None if traffic is None else traffic / (avg_ms * 1e-3) / HBM_PEAK,
                 "physical_bound": "fp32 VALU issue at 3 waves/SIMD (DESIGN.md section 4; `valu` below); HBM is the bound "
@@ -812,7 +807,7 @@ def run_rank(args):
                 "last_layer_in_tp_kernels": {
                     "algorithmic_flops_per_layer": sum(last_flops) / len(last_flops),
                     "issued_f16_flops_per_layer": 3.0 * sum(last_flops) / len(last_flops),
-                    "note": "evaluated as hi.hi + 2^-11 (hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16 inside conv_tile_kernel / "
+                    "note": "evaluated as hi.hi + 2^-11 (hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16 inside "
                             "tp_fused_kernel; matrix-pipe busy fraction from PMC in DESIGN.md section 4",
                     "f16_TFLOPs_over_kernel_time": 3.0 * sum(last_flops) / len(last_flops) / (tp_ms * 1e-3) / 1e12,
                     "peak_f16_TFLOPs": MFMA_F16_PEAK / 1e12,

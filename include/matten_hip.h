@@ -237,64 +237,9 @@ int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const flo
                     const float* num_neigh, const uint16_t* a_split, const float* a_scale_inv,
                     float* agg /*[N,d_mid]*/, matten_stream_t stream);
 
-int matten_tp_max_cols(void);   /* weight columns (mul * couplings) a group entry of matten_tp_fused / matten_conv_tile may have */
+int matten_tp_max_cols(void);   /* weight columns (mul * couplings) a group entry of matten_tp_fused may have */
 int matten_tp_max_cols_l0(void);   /* the same for entries of scalar (l1 = 0) input blocks */
 int matten_tp_max_cols_l1(void);   /* ... and of vector (l1 = 1) input blocks */
-int matten_tp_compact(void);       /* weight block of an entry: 0 = [u][c] over all couplings of its group (absent ones: zero
-                                    * columns), 1 = [u][live c] (build switch -DTPF_COMPACT=1: measured 7-9 % slower) */
-
-/* ------------------------------------------------------------------------------------------
- * Conv layer on 16-node single-species tiles: tensor product + neighbour sum + lin2 + self-connection (+ Gate + eval
- * BatchNorm) in ONE launch; the neighbour sums agg[N, d_mid] never reach memory
- * (reference nn/conv.py:113-123:  scatter(tp(x[src], Y, w)) / sqrt(avg)  ->  lin2(., species) + sc;  :209-213 Gate, norm).
- *
- * matten_species_tiles: cuts the batch into blocks of `block_nodes` consecutive nodes (a multiple of 16; whole crystals
- *   are not required), groups every block's nodes by species and emits 16-node tiles of ONE species each:
- *   tile_nodes[n_slots, 16] (node ids, -1 = padding), tile_species[n_slots] (-1 = unused slot), block b owning the
- *   slots [b spb, (b + 1) spb), spb = matten_species_tiles_slots_per_block(block_nodes, n_species) = block_nodes/16 +
- *   n_species, n_slots = ceil(N / block_nodes) spb.  species[N] int32 species indices (clamped to [0, n_species)).
- *   The order of the nodes inside a species run is unspecified (a node's result does not depend on its tile mates).
- * matten_conv_tile: one workgroup per tile walks `entries` (group entries as matten_tp_fused: words 0..7 used) in
- *   rounds of four and applies lin2 on the matrix cores after each round (csrc/conv_tile.hip; host tables
- *   matten_amd/plan_conv.py plan_conv_tile):
- *   quads[n_quads, 8]     : {e0, e1, e2, e3 (entry per wave, -1 = the wave only feeds the shared stage), class lanes
- *                            per node (log2), passes, node groups of the tile, base index into wave_units}
- *   rounds[n_rounds, 2]   : {quad, node group} in walking order (rounds that stage the same edge rows adjacent)
- *   the lin2 work lists, packed (the kernel keeps a copy in LDS), in the order a wave meets them:
- *   phase_recs[.., 2]     : {first fragment | count << 16, first unit} of (quad, pass, wave) at base + 4 pass + wave
- *   unit_recs[n_unit, 2]  : {output column of (v = 16 mt, k = 0) | d3 << 12 | valid v (<= 16) << 16 | first column tile << 21 |
- *                            column tiles (<= 4) << 25,  log2(nodes per wave of the round) | class lanes per node (log2) << 4};
- *                            a unit = (output irrep, 16-channel tile, column tiles); column n of a tile = (node n mod npw of
- *                            the round's node group, component n / npw)
- *   frag_recs[n_frag]     : one (piece, unit) product each: A fragment offset / 64 in a species' row of atab | first register
- *                            of the piece in its wave's dump << 14 | that wave << 19 | lanes per node (log2) of its entry << 21 |
- *                            last fragment of its unit << 24.  Dump: [wave][28 registers][68 floats], register r of lane l at
- *                            r 68 + l
- *   atab[S, a_stride]     : lin2 weights W[u, s, v] fan_in^-1/2 as MFMA A fragments [lane (g, c)][KS]: u = entry channel
- *                            g KS + t (KS = max(1, lanes per node / 4)), v = 16 mt + c; zero outside the piece's channels
- *   add[N, add_ld] (self-connection) or NULL; cmeta == NULL: out[N, out_ld >= d_out] = add + lin2(agg).
- *   cmeta[d_act, 4] (the table of matten_gate_bn: {source column, gate column or -1, act | gate act << 8, unused}),
- *   act_cst, bn_scale / bn_shift [d_act] (eval BatchNorm folded per activated column) or NULL:
- *   out[N, out_ld >= d_act] = BatchNorm(Gate(add + lin2(agg))).
- *   a_split / a_scale_inv as matten_tp_fused (required), indexed like `entries`; lds_floats_per_wave = max over entries
- *   of 16 (16 ceil(mul NC / 16) + 4).
- * ------------------------------------------------------------------------------------------ */
-int matten_conv_tile_nodes(void);        /* 16 */
-int matten_conv_tile_dump_regs(void);    /* registers per lane and pass of the LDS dump (plan_conv.DUMP_REGS) */
-int matten_conv_tile_dump_stride(void);  /* floats between two registers of a wave's dump (plan_conv.DUMP_RS) */
-int64_t matten_species_tiles_slots_per_block(int64_t block_nodes, int64_t n_species);
-int matten_species_tiles(const int32_t* species, int64_t n_nodes, int64_t n_species, int64_t block_nodes,
-                         int32_t* tile_nodes, int32_t* tile_species, matten_stream_t stream);
-int matten_conv_tile(const float* x, int64_t d_in, const uint16_t* h2s, const float* w2p, int64_t w_pad,
-                     const float* sh_sorted, int64_t sh_stride, const int32_t* rowptr, const int32_t* src_sorted,
-                     int64_t n_nodes, const int32_t* entries, int64_t n_entries, int64_t lds_floats_per_wave,
-                     const uint16_t* a_split, const float* a_scale_inv, float avg_num_neighbors, const float* num_neigh,
-                     const int32_t* tile_nodes, const int32_t* tile_species, int64_t n_slots, int64_t slots_per_block,
-                     const int32_t* quads, int64_t n_quads, const int32_t* rounds, int64_t n_rounds,
-                     const int32_t* frag_recs, int64_t n_frag, const int32_t* unit_recs, int64_t n_unit,
-                     const int32_t* phase_recs, int64_t n_phase, const float* atab, int64_t a_stride, const float* add, int64_t add_ld,
-                     int64_t d_out, const int32_t* cmeta, const float* act_cst, const float* bn_scale,
-                     const float* bn_shift, int64_t d_act, float* out, int64_t out_ld, matten_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * FullyConnectedTensorProduct(x, one_hot(species)) == species-indexed per-irrep linear
@@ -431,21 +376,6 @@ int matten_tp_backward(const float* x, int64_t d_in, const void* w_edge, int64_t
  * elements; step[0] (device) = the number of this step, already incremented by the caller; buffers 16-byte aligned. */
 int matten_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* step,
                      float lr, float beta1, float beta2, float eps, float weight_decay, matten_stream_t stream);
-
-/* Calibration work for the benchmark harness (bench.py "calibration"; nothing of the reference corresponds -- there the
- * host's wall clock is the only timer): fixed, model-independent kernels timed next to the benchmark so that lines taken
- * on different machines / DVFS states can be compared.
- *   matten_calib_valu: `iters` x 128 dependent-chain fp32 FMAs per lane at 8 waves per SIMD on every CU
- *     (matten_calib_valu_insts_per_simd(iters) wave64 instructions per SIMD); clocks[0] = shader-clock ticks (s_memtime),
- *     clocks[1] = 100 MHz reference ticks (s_memrealtime) the first wave spent in the loop.  out: one float, never written.
- *   matten_calib_copy: dst[0..n) = src[0..n), 16 bytes per lane (n a multiple of 4, pointers 16-byte aligned).
- *   matten_calib_clock_probe: ONE wave that watches s_memtime against s_memrealtime for ticks_100mhz reference ticks
- *     (<= 1 s), sleeping in between: on a side stream beside the benchmark's forwards it reports the average shader clock
- *     under THAT load (clocks[0] / clocks[1] x 100 MHz). */
-int64_t matten_calib_valu_insts_per_simd(int64_t iters);
-int matten_calib_clock_probe(int64_t ticks_100mhz, uint64_t* clocks, matten_stream_t stream);
-int matten_calib_valu(int64_t iters, float* out, uint64_t* clocks, matten_stream_t stream);
-int matten_calib_copy(const float* src, float* dst, int64_t n_floats, matten_stream_t stream);
 
 /* the same adjoint with the literal-coefficient coupling code of the forward kernels (cg_gen.h): a thread owns (edge,
  * channel of one input block) and walks the block's paths; one atomic per (edge, channel, component) into dx.

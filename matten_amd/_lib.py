@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 40
+ABI_VERSION = 41
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -44,21 +44,9 @@ SIGNATURES = {
                                        c_int64, P, P, P, P, c_int64, P, P]),
     "matten_agg_linear_gate_sets": (c_int, []),
     "matten_radial_hidden": (c_int, [P, c_int64, c_int, c_float, c_float, P, c_int, P, c_int, P, P, P]),
-    "matten_tp_compact": (c_int, []),
     "matten_tp_max_cols": (c_int, []),
     "matten_tp_max_cols_l0": (c_int, []),
     "matten_tp_max_cols_l1": (c_int, []),
-    "matten_conv_tile_nodes": (c_int, []),
-    "matten_conv_tile_dump_regs": (c_int, []),
-    "matten_conv_tile_dump_stride": (c_int, []),
-    "matten_species_tiles_slots_per_block": (c_int64, [c_int64, c_int64]),
-    "matten_species_tiles": (c_int, [P, c_int64, c_int64, c_int64, P, P, P]),
-    "matten_conv_tile": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64,              # x .. n_nodes
-                                 P, c_int64, c_int64, P, P, c_float, P,                             # entries .. num_neigh
-                                 P, P, c_int64, c_int64,                                            # tiles
-                                 P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64,        # quads, rounds, frags, units, phases
-                                 P, c_int64, P, c_int64, c_int64,                                   # atab, a_stride, add, add_ld, d_out
-                                 P, P, P, P, c_int64, P, c_int64, P]),                              # gate tables, d_act, out, out_ld, stream
     "matten_tp_fused": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
     "matten_species_linear": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
     "matten_species_linear_rows": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
@@ -96,10 +84,6 @@ SIGNATURES = {
     "matten_segment_minmax": (c_int, [P, c_int64, P, c_int64, c_int, P, P, P]),
     "matten_segment_minmax_bwd": (c_int, [P, c_int64, P, c_int64, P, P]),
     "matten_dense_rows": (c_int, [P, c_int64, P, c_int64, c_int64, P, P]),
-    "matten_calib_valu_insts_per_simd": (c_int64, [c_int64]),
-    "matten_calib_valu": (c_int, [c_int64, P, P, P]),
-    "matten_calib_copy": (c_int, [P, P, c_int64, P]),
-    "matten_calib_clock_probe": (c_int, [c_int64, P, P]),
 }
 
 _lib = None

@@ -1,3 +1,4 @@
+// libmatten_lab.so (make lab; include/matten_lab.h) -- NOT part of libmatten_hip.so.
 // Calibration kernels for bench.py (SURVEY.md 8d "measurement"): two fixed pieces of work whose cost depends on the box only,
 // timed next to the benchmark so that numbers taken on different pool machines (or at different DVFS states of one
 // machine: MI355X clocks to its power budget, /opt/skills/guides/MI355X_MICROARCH.md "DVFS give-back") can be compared.
@@ -8,6 +9,7 @@
 //   matten_calib_copy  a 16-byte-per-lane streaming copy: sustained HBM read + write rate.
 // Neither touches the model; they replace nothing in the reference (there the host's wall clock is the only timer).
 #include "common.h"
+#include "matten_lab.h"
 
 namespace {
 

@@ -95,12 +95,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
     const int ch_log2 = npw >= 16 ? 0 : (4 - (6 - cu_log2));  // CH = max(1, 16 / npw)
     const int CH = 1 << ch_log2;
     const int T = npw >= 16 ? (npw >> 4) : 1;     // N tiles of 16 edges per chunk
-#if TPF_COMPACT
-    const int ncl = __popc(mask);                 // [u][live c] weight columns (tp_walk.h run_group_shared)
-    const int ncols = ge.mul * ncl;
-#else
     const int ncols = ge.mul * NC;
-#endif
     const int MT = (ncols + 15) >> 4;
     const int ycol = MT * 16;                    // harmonics of the edge live behind its weight columns
     const int stride = MT * 16 + 32 + 4;         // floats per edge row of the LDS tile (+4: bank spread)
@@ -210,21 +205,13 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
                 src_nn = a.src_sorted[min(beg + s + 2, e_last)];
             }
             if (s < deg) {
-#if TPF_COMPACT
-                const float* wp = tile + ((j << ch_log2) + so) * stride + u * ncl;
-#else
                 const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
-#endif
                 const float* yp = tile + ((j << ch_log2) + so) * stride + ycol + G::Y0;
                 float y[G::NY], w[NC];
 #pragma unroll
                 for (int jj = 0; jj < G::NY; ++jj) y[jj] = yp[jj];
-#if TPF_COMPACT
-                load_weights<NC, 0u>(wp, mask, w);
-#else
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
-#endif
                 G::apply(mask, x, y, w, acc);
             }
         }
@@ -619,7 +606,6 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
     return MATTEN_OK;
 }
 
-extern "C" int matten_tp_compact(void) { return TPF_COMPACT; }
 extern "C" int matten_tp_max_cols(void) { return TPF_MAX_COLS; }
 extern "C" int matten_tp_max_cols_l0(void) { return TPF_MAX_COLS_L0; }
 extern "C" int matten_tp_max_cols_l1(void) { return TPF_MAX_COLS_L1; }

@@ -1,6 +1,6 @@
-// Shared device code of the tensor-product kernels that WALK a destination node's CSR segment in chunks with a
-// workgroup-shared stage: matten_tp_fused (csrc/tp_fused.hip: neighbour sums to HBM) and matten_conv_tile
-// (csrc/conv_tile.hip: neighbour sums stay on chip, lin2 applied per 16-node tile).  See the header comment of
+// The walk of matten_tp_fused (csrc/tp_fused.hip): a destination node's CSR segment in chunks with a workgroup-shared
+// stage.  (Until round 5 also included by the conv-tile kernel -- neighbour sums kept on chip, lin2 per 16-node tile --
+// which lost 8-20 % to tp_fused + agg_linear and was removed: docs/LAB_NOTES.md round 4.)  See the header comment of
 // tp_fused.hip for the arithmetic (fp16-split matrix products for the last radial layer, literal-coefficient CG code).
 //   reference nn/utils.py:246-251,260,263 (radial MLP -> per-edge weights -> uvu tensor product), nn/conv.py:113-120
 #pragma once
@@ -116,10 +116,8 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_MAX_COLS_L1
 #define TPF_MAX_COLS_L1 TPF_MAX_COLS   // vector (l1 = 1) input blocks; 7 couplings with l2 <= 2 (112 columns for 16 channels:
 #endif                                 // measured, spills), 5 with l2 = 3, 4 (80 columns)
-// weight block of an entry: 1 = [u][live c] (only the couplings of the entry's mask), 0 = [u][c] over all couplings of the
-// group with zero columns for the absent ones (plan.py TP_COMPACT, checked at load through matten_tp_compact)
-#ifndef TPF_COMPACT
-#define TPF_COMPACT 0
+#ifndef TPF_BRANCH_FREE_STEPS
+#define TPF_BRANCH_FREE_STEPS 0
 #endif
 __host__ __device__ constexpr int cap_channels(int l1, int nc) {
     int cap = 64;
@@ -193,24 +191,6 @@ __device__ __forceinline__ void mfma_tiles(const f16x8* __restrict__ ah, const f
     for (int mt = 0; mt < MTC; ++mt) dx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, dx[mt], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) *reinterpret_cast<f32x4*>(trow + mt * 16) = dh[mt] + SPLIT_LO_INV * dx[mt];
-}
-
-// w[c] of the lane's channel from its [live c] run in the weight tile: column rank(c) = live couplings below c (a dead
-// coupling reads its successor's column -- inside the row -- and is never used).  Full and compile-time masks keep
-// immediate offsets.
-template <int NC, unsigned CMASK>
-__device__ __forceinline__ void load_weights(const float* __restrict__ wp, unsigned mask, float (&w)[NC]) {
-    constexpr unsigned FULL = (1u << NC) - 1u;
-    if constexpr (CMASK != 0) {
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) w[cc] = wp[__builtin_popcount(CMASK & ((1u << cc) - 1u))];
-    } else if (mask == FULL) {
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
-    } else {
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) w[cc] = wp[__popc(mask & ((1u << cc) - 1u))];
-    }
 }
 
 // loader role of a thread: (edge row of the chunk, 16-byte piece of the row) per MFMA tile; fixed for the whole walk
@@ -387,15 +367,8 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const int npw = 64 >> cu_log2;
     const int ch_log2 = npw >= 16 ? 0 : 4 - (6 - cu_log2);
     const int CH = 1 << ch_log2;
-    // the weight block holds the columns of the LIVE couplings only, [u][live c] (plan.py add_entry): a layer that lacks
-    // some couplings of the group (the dead-output view of the last layer keeps 1-5 of up to 9) runs the matrix phase
-    // on ceil(mul * live / 16) tiles
-#if TPF_COMPACT
-    const int ncl = CMASK ? __builtin_popcount(CMASK) : __popc(mask);
-    const int ncols = ge.mul * ncl;
-#else
+    // the weight block holds the columns of ALL couplings of the group, [u][c] (absent ones: zero columns)
     const int ncols = ge.mul * NC;
-#endif
     const int MT = (ncols + 15) >> 4;
 
     const int j = lane >> cu_log2;
@@ -524,11 +497,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         const unsigned long long tr_b = tpf_stamp();
 #endif
         auto contract = [&](int so, const float* __restrict__ x) {
-#if TPF_COMPACT
-            const float* wp = tile + ((j << ch_log2) + so) * stride + u * ncl;
-#else
             const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
-#endif
             const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
             float y[G::NY], w[NC];
             {   // the harmonics of a staged row are 16-byte aligned: whole ds_read_b128 over [Y0, Y0 + NY)
@@ -543,15 +512,61 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 #pragma unroll
                 for (int jj = 0; jj < G::NY; ++jj) y[jj] = yq[G::Y0 - Q0 + jj];
             }
-#if TPF_COMPACT
-            load_weights<NC, CMASK>(wp, mask, w);
-#else
 #pragma unroll
             for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
-#endif
             G::apply(CMASK ? CMASK : mask, x, y, w, acc);
         };
         if constexpr (TPF_LAB_NO_VALU) {
+        } else if (two_deep && TPF_BRANCH_FREE_STEPS) {
+            // Branch-free slot pairs.  A step of a light kind is ~30-200 vector instructions behind ~8 LDS reads (harmonics
+            // row, weights): inside `if (s < deg)` regions the reads of step s + 1 cannot start before step s has finished
+            // and every step pays the LDS round trip (the l1 = 0 kind: 735 cycles per step for 30 instructions,
+            // tools/tp_trace.py).  Here the reads are unconditional (every slot of a chunk has a staged row: past the end of
+            // a segment its last edge again) and double-buffered one slot ahead; a slot past the segment's end contracts
+            // x = 0 instead of being skipped (w, Y finite: + 0 to every accumulator).
+            auto fetch = [&](int so, float (&y)[G::NY], float (&w)[NC]) {
+                const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
+                const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
+                constexpr int Q0 = G::Y0 / 4 * 4, NQ = (G::Y0 + G::NY - Q0 + 3) / 4;
+                float yq[4 * NQ];
+                const f32x4* y4 = reinterpret_cast<const f32x4*>(yp - (G::Y0 - Q0));
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 v = y4[q];
+                    yq[4 * q] = v[0], yq[4 * q + 1] = v[1], yq[4 * q + 2] = v[2], yq[4 * q + 3] = v[3];
+                }
+#pragma unroll
+                for (int jj = 0; jj < G::NY; ++jj) y[jj] = yq[G::Y0 - Q0 + jj];
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+            };
+            auto step = [&](bool on, const float (&x)[G::D1], const float (&y)[G::NY], const float (&w)[NC]) {
+                float xe[G::D1];
+#pragma unroll
+                for (int i = 0; i < G::D1; ++i) xe[i] = on ? x[i] : 0.0f;
+                G::apply(CMASK ? CMASK : mask, xe, y, w, acc);
+            };
+            float ya[G::NY], wa[NC], yb[G::NY], wb[NC];
+            fetch(0, ya, wa);
+            for (int so = 0; so < CH; so += 2) {   // CH is 2, 4 or 8 here: slot pairs, one row buffer per parity
+                const int s = s0 + so;
+                fetch(so + 1, yb, wb);
+                step(s < deg, xn, ya, wa);
+                {
+                    const float* xp = a.x + (int64_t)TPF_SRC(src_nn) * a.d_in + xcol;
+#pragma unroll
+                    for (int i = 0; i < G::D1; ++i) xn[i] = TPF_XLD(xp, i, src_nn);
+                    src_nn = a.src_sorted[min(beg + s + 4, e_last)];
+                }
+                fetch(min(so + 2, CH - 1), ya, wa);     // (the last pair re-reads its own slot: never used)
+                step(s + 1 < deg, xb, yb, wb);
+                {
+                    const float* xp = a.x + (int64_t)TPF_SRC(src_b) * a.d_in + xcol;
+#pragma unroll
+                    for (int i = 0; i < G::D1; ++i) xb[i] = TPF_XLD(xp, i, src_b);
+                    src_b = a.src_sorted[min(beg + s + 5, e_last)];
+                }
+            }
         } else if (two_deep) {
             for (int so = 0; so < CH; so += 2) {   // CH is 2, 4 or 8 here: slot pairs, one row buffer per parity
                 const int s = s0 + so;

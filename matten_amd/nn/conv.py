@@ -29,16 +29,6 @@ KEPT_ONLY = "_amd_kept_irreps_only"   # batch-dict marker: node_features hold th
 # inference: skip the output irreps of the last conv layer nothing reads (PointConv.build_inference_view); 0 = run them
 DEAD_PATH_ELIMINATION = _os.environ.get("MATTEN_DEAD_PATH_ELIMINATION", "1") != "0"
 AGG_KM_MIN_ROWS = int(_os.environ.get("MATTEN_AGG_KM_MIN_ROWS", "8192"))   # nodes per batch from which lin2 streams component-major rows
-# conv-tile kernel (matten_conv_tile: agg stays on chip).  OPT-IN (MATTEN_CONV_TILE=1): parity-green, but measured 8-20 %
-# slower per layer than tp_fused + agg_linear on MI355X (docs/LAB_NOTES.md round 4: the tile walk
-# without its lin2 phases only equals tp_fused WITH its agg stores, and lin2 on chip costs what agg_linear costs).  When on:
-# layers with at least CONV_TILE_MIN_DMID floats of neighbour sums per node, batches of at least CONV_TILE_MIN_ROWS nodes,
-# tiles cut from blocks of CONV_TILE_BLOCK nodes.  The plan is always built (host tests, A/B tools).
-CONV_TILE = _os.environ.get("MATTEN_CONV_TILE", "0")
-CONV_TILE_MIN_ROWS = int(_os.environ.get("MATTEN_CONV_TILE_MIN_ROWS", "8192"))
-CONV_TILE_MIN_DMID = int(_os.environ.get("MATTEN_CONV_TILE_MIN_DMID", "1000"))
-CONV_TILE_BLOCK = int(_os.environ.get("MATTEN_CONV_TILE_BLOCK", "2048"))
-TILES_KEY = "_amd_species_tiles"      # batch-dict cache: (tile_nodes, tile_species, slots per block, species tensor it was cut from)
 
 
 class PointConv(ModuleIrreps, torch.nn.Module):
@@ -77,20 +67,7 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         self.irreps_out[DataKey.NODE_FEATURES] = conv_layer_irreps
         self._lin1_sc = None  # built at first inference forward
         self._lin1_sc_packed = DerivedWeight(self._pack_lin1_sc)
-        # conv-tile inference path (matten_conv_tile): tensor product + neighbour sum + lin2 (+ Gate) per 16-node
-        # single-species tile, agg never reaches memory; None when the layer does not fit (plan_conv.plan_conv_tile)
         from .. import plan as _plan
-        from .. import plan_conv as _plan_conv
-        self.tile_plan = None
-        if self.tp.impl == "fused":
-            tpl = _plan_conv.plan_conv_tile(self.tp.plan, n_species, conv_layer_irreps)
-            if tpl is not None:
-                self.tile_plan = tpl
-                self._tile_tables = DeviceTables(entries=tpl.entries, quads=tpl.quads, rounds=tpl.rounds, frags=tpl.frag_recs,
-                                                 units=tpl.unit_recs, phases=tpl.phase_recs, gather=tpl.gather,
-                                                 scale=tpl.scale, cols=tpl.fused_cols)
-                self._tile_atab = DerivedWeight(self._pack_tile_atab)
-                self._tile_radial = DerivedWeight(self._pack_tile_radial)
         # component-major neighbour sums + streaming lin2 (matten_agg_linear): the inference path of the two-kernel conv
         import os
         self.agg_plan = None
@@ -137,40 +114,6 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         t, dev = self._agg_tables, w.device
         gather, scale = t.get("gather", dev), t.get("scale", dev)
         return torch.where(gather >= 0, w[gather.clamp(min=0)] * scale[None, :], w.new_zeros(())).contiguous()
-
-    # ---- conv-tile path: operands derived from the parameters (rebuilt when they change) --------------------------------
-    def _pack_tile_atab(self, w: torch.Tensor) -> torch.Tensor:
-        """lin2.weight (flat, reference layout) -> [S, a_stride] MFMA A fragments of matten_conv_tile"""
-        t, dev = self._tile_tables, w.device
-        gather, scale = t.get("gather", dev), t.get("scale", dev)
-        return torch.where(gather >= 0, w[gather.clamp(min=0)] * scale[None, :], w.new_zeros(())).contiguous()
-
-    def _pack_tile_radial(self, w0: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, h_scale: torch.Tensor):
-        """last radial layer in the tile entries' [entry][u][coupling] column order -> (w2p, fp16 hi/lo fragments,
-        1 / (fragment scale x hidden-feature scale) per entry), the operands matten_tp_fused gets from UVUTensorProduct"""
-        w2p = self.tp.weight_nn.pack_last(w2, self._tile_tables.get("cols", w2.device))
-        frag, scale_inv = ops.split_a_tiles(w2p, self.tile_plan.entries)
-        return w2p, frag, (scale_inv * h_scale[1]).contiguous()
-
-    def _forward_tile(self, x1, self_connection, data, gate):
-        """lin2(agg) + self_connection (Gate / BatchNorm applied when `gate` is given) with agg never leaving the chip"""
-        tpl, t, dev = self.tile_plan, self._tile_tables, x1.device
-        mlp = self.tp.weight_nn
-        nb, r0, r1 = data[DataKey.AMD_RBF].tolist()
-        avg = self.avg_num_neighbors if self.avg_num_neighbors is not None else 0.0
-        num_neigh = None if self.avg_num_neighbors is not None else data[DataKey.NUM_NEIGH]
-        h2p, _ = mlp.hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, data)
-        w2p, frag, scale_inv = self._tile_radial.get(mlp.layer0.weight, mlp.layer1.weight, mlp.layer2.weight,
-                                                     mlp.h_scale(r0, r1))
-        tiles = data.get(TILES_KEY)
-        s32 = data[DataKey.AMD_SPECIES_I32]
-        if tiles is None or tiles[3] is not s32:
-            tiles = ops.species_tiles(s32, self.lin2.n_species, CONV_TILE_BLOCK) + (s32,)
-            data[TILES_KEY] = tiles
-        return ops.conv_tile(x1, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC],
-                             t.get("entries", dev), tpl.lds_floats_per_wave, (frag, scale_inv), avg, num_neigh, tiles[:3],
-                             t.get("quads", dev), t.get("rounds", dev), t.get("frags", dev), t.get("units", dev), t.get("phases", dev),
-                             self._tile_atab.get(self.lin2.weight), self_connection, tpl.d_out, gate=gate)
 
     # ---- dead-output elimination (inference) ------------------------------------------------------------------------
     def build_inference_view(self, kept_irreps) -> bool:
@@ -253,15 +196,6 @@ class PointConv(ModuleIrreps, torch.nn.Module):
         else:
             self_connection = self.sc(x, species)
             x1 = self.lin1(x, species)
-        if (self.tile_plan is not None and CONV_TILE != "0" and x1.shape[0] >= CONV_TILE_MIN_ROWS
-                and self.tp.plan.d_mid >= CONV_TILE_MIN_DMID
-                and DataKey.AMD_SPECIES_I32 in data
-                and not _ag.needs_grad_lazy(lambda: (x1, self_connection, self.lin2.weight, *_ag.params_of(self.tp.weight_nn)))):
-            gate = self.__dict__.get("_gate_tile")   # set per call by PointConvWithActivation
-            data[DataKey.NODE_FEATURES] = self._forward_tile(x1, self_connection, data, gate)
-            if gate is not None:
-                data[GATE_APPLIED] = True
-            return data
         # (small batches keep the mul_ir row + row kernels: matten_agg_linear's per-workgroup set-up -- weight fragments
         # and tables into LDS, species lookup -- is ~35 us of latency per launch that only a long stream pays back:
         # n100, 473 rows: 1.25 vs 1.08 ms per forward; 64 000 rows: -3 %)
@@ -345,24 +279,6 @@ class PointConvWithActivation(ModuleIrreps, torch.nn.Module):
             scale, shift = self._fuse_bn.get(bn.running_mean, bn.running_var, bn.weight, bn.bias)
         return (fuse.get("cmeta", dev), self.act._tables.get("act_cst", dev), self.act.plan.irreps_out.dim, scale, shift)
 
-    def _gate_tile_args(self, dev):
-        """(gate table, act_cst, d_act, bn_scale, bn_shift) for matten_conv_tile's epilogue, or None when this layer / mode
-        keeps the separate Gate kernel (training-mode BatchNorm, instance normalisation, the norm activation)"""
-        if not GATE_FUSE or self.conv.tile_plan is None or getattr(self.act, "activation_type", "gate") != "gate":
-            return None
-        if self.norm.method not in ("batch", "none", None):
-            return None
-        bn = self.norm.n
-        if bn is not None and bn.training:
-            return None
-        scale = shift = None
-        if bn is not None:
-            if self.__dict__.get("_fuse_bn") is None:
-                self.__dict__["_fuse_bn"] = DerivedWeight(self._fold_bn)
-            scale, shift = self._fuse_bn.get(bn.running_mean, bn.running_var, bn.weight, bn.bias)
-        return (self.act._tables.get("meta", dev), self.act._tables.get("act_cst", dev), self.act.plan.irreps_out.dim,
-                scale, shift)
-
     def _fold_bn(self, rm, rv, w, b):
         """eval-mode BatchNorm as per-column (scale, shift) of the activated row (same folding as matten_gate_bn)"""
         meta = torch.as_tensor(np.asarray(self.act.plan.meta).reshape(-1, 4)[:, 3].astype(np.int64), device=w.device)
@@ -379,13 +295,10 @@ class PointConvWithActivation(ModuleIrreps, torch.nn.Module):
         if not _ag.needs_grad_lazy(lambda: (x, *_ag.params_of(self.conv))) and x.shape[0] >= AGG_KM_MIN_ROWS:
             fuse = self._gate_fuse_args(x.device)
         self.conv.__dict__["_gate_fuse"] = fuse
-        self.conv.__dict__["_gate_tile"] = (self._gate_tile_args(x.device)
-                                            if not _ag.needs_grad_lazy(lambda: (x, *_ag.params_of(self.conv))) else None)
         try:
             data = self.conv(data)
         finally:
             self.conv.__dict__["_gate_fuse"] = None
-            self.conv.__dict__["_gate_tile"] = None
         if data.pop(GATE_APPLIED, False):
             return data   # lin2's kernel wrote the activated (and normalised) row
         # Gate and (eval-mode) BatchNorm run as one elementwise kernel

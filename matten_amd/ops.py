@@ -460,9 +460,6 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
     if (lib.matten_tp_max_cols() != TP_MAX_COLS or lib.matten_tp_max_cols_l0() != TP_MAX_COLS_L0
             or lib.matten_tp_max_cols_l1() != TP_MAX_COLS_L1):
         raise _lib.MattenHipError("plan.TP_MAX_COLS does not match the library's entry width (-DTPF_MAX_COLS)")
-    from .plan import TP_COMPACT
-    if lib.matten_tp_compact() != TP_COMPACT:
-        raise _lib.MattenHipError("plan.TP_COMPACT does not match the library's weight-block layout (-DTPF_COMPACT)")
     x = _need_rows(x, torch.float32, "node_features")  # a column slice is fine: d_in below is the row stride
     h2p = _need(h2p, torch.float16, "h2s")
     if h2p.dim() != 3 or h2p.shape[1:] != (2, 32):
@@ -489,68 +486,6 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
                                  _ptr(a_split[1]) if a_split is not None else None, _ptr(agg), _stream())
     _lib.check(rc, "matten_tp_fused")
     return agg
-
-
-def species_tiles(species_i32: torch.Tensor, n_species: int, block_nodes: int):
-    """(tile_nodes [n_slots, 16] int32, tile_species [n_slots] int32, slots_per_block) of matten_species_tiles: the batch
-    in blocks of `block_nodes` consecutive nodes, every block's nodes grouped by species and cut into 16-node tiles"""
-    lib = _lib.load()
-    species_i32 = _need(species_i32, torch.int32, "species")
-    N = species_i32.shape[0]
-    spb = int(lib.matten_species_tiles_slots_per_block(block_nodes, n_species))
-    n_slots = -(-N // block_nodes) * spb
-    tile_nodes = torch.empty(n_slots, 16, dtype=torch.int32, device=species_i32.device)
-    tile_species = torch.empty(n_slots, dtype=torch.int32, device=species_i32.device)
-    _lib.check(lib.matten_species_tiles(_ptr(species_i32), N, n_species, block_nodes, _ptr(tile_nodes), _ptr(tile_species),
-                                        _stream()), "matten_species_tiles")
-    return tile_nodes, tile_species, spb
-
-
-def conv_tile(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, lds_floats_per_wave: int, a_split, avg_num_neighbors: float,
-              num_neigh, tiles, quads, rounds, frag_recs, unit_recs, phase_recs, atab, add, d_out: int, gate=None) -> torch.Tensor:
-    """out = add + lin2(neighbour sums) (or, with gate = (cmeta, act_cst, d_act, bn_scale, bn_shift), the activated and
-    normalised row) without agg ever reaching memory: include/matten_hip.h matten_conv_tile, tables from
-    plan_conv.plan_conv_tile, tiles = ops.species_tiles(...), a_split = (fragments, scale_inv per entry)."""
-    lib = _lib.load()
-    from . import plan_conv as pc
-
-    if (lib.matten_conv_tile_nodes() != pc.TILE_NODES or lib.matten_conv_tile_dump_regs() != pc.DUMP_REGS
-            or lib.matten_conv_tile_dump_stride() != pc.DUMP_RS):
-        raise _lib.MattenHipError("plan_conv constants do not match the library (csrc/conv_tile.hip)")
-    x = _need_rows(x, torch.float32, "node_features")
-    h2p = _need(h2p, torch.float16, "h2s")
-    if h2p.dim() != 3 or h2p.shape[1:] != (2, 32):
-        raise ValueError(f"h2s must be [E,2,32] fp16, got {tuple(h2p.shape)}")
-    w2p = _need(w2p, torch.float32, "w2p")
-    sh_sorted = _need(sh_sorted, torch.float32, "sh_sorted")
-    atab = _need(atab, torch.float32, "atab")
-    N, d_in = x.shape[0], x.stride(0)
-    if num_neigh is not None:
-        num_neigh = _need(num_neigh, torch.float32, "num_neigh")
-    frag, scale_inv = _need(a_split[0], torch.float16, "a_split"), _need(a_split[1], torch.float32, "a_scale_inv")
-    if scale_inv.numel() != entries.shape[0]:
-        raise ValueError("a_scale_inv needs one value per entry")
-    if add is not None:
-        add = _need_rows(add, torch.float32, "add")
-    tile_nodes, tile_species, spb = tiles
-    cmeta = act_cst = bn_scale = bn_shift = None
-    d_act = 0
-    if gate is not None:
-        cmeta, act_cst, d_act, bn_scale, bn_shift = gate
-    width = d_act if gate is not None else d_out
-    out = torch.empty(N, width, dtype=torch.float32, device=x.device)
-    with _timed(f"conv_tile/d_out={d_out}/d_in={x.shape[1]}"):
-        rc = lib.matten_conv_tile(_ptr(x), d_in, _ptr(h2p), _ptr(w2p), w2p.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
-                                  _ptr(rowptr), _ptr(src_sorted), N, _ptr(entries), entries.shape[0], lds_floats_per_wave,
-                                  _ptr(frag), _ptr(scale_inv), float(avg_num_neighbors or 0.0), _ptr(num_neigh),
-                                  _ptr(tile_nodes), _ptr(tile_species), tile_species.shape[0], spb, _ptr(quads),
-                                  quads.shape[0], _ptr(rounds), rounds.shape[0], _ptr(frag_recs), frag_recs.shape[0],
-                                  _ptr(unit_recs), unit_recs.shape[0], _ptr(phase_recs), phase_recs.shape[0],
-                                  _ptr(atab), atab.shape[1],
-                                  _ptr(add), add.stride(0) if add is not None else d_out, d_out, _ptr(cmeta), _ptr(act_cst),
-                                  _ptr(bn_scale), _ptr(bn_shift), d_act, _ptr(out), width, _stream())
-    _lib.check(rc, "matten_conv_tile")
-    return out
 
 
 def agg_linear(agg, species_order, wtab, io_table, blocks, d_out: int, add=None) -> torch.Tensor:

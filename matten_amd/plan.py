@@ -35,7 +35,6 @@ TP_MAX_COMBOS = 12
 TP_MAX_COLS = int(os.environ.get("MATTEN_TP_MAX_COLS", "64"))  # == matten_tp_max_cols() of the library (-DTPF_MAX_COLS)
 TP_MAX_COLS_L0 = int(os.environ.get("MATTEN_TP_MAX_COLS_L0", "96"))  # scalar input blocks (see plan_uvu); -DTPF_MAX_COLS_L0
 TP_MAX_COLS_L1 = int(os.environ.get("MATTEN_TP_MAX_COLS_L1", str(TP_MAX_COLS)))  # vector input blocks; -DTPF_MAX_COLS_L1
-TP_COMPACT = int(os.environ.get("MATTEN_TP_COMPACT", "0"))   # == matten_tp_compact() (-DTPF_COMPACT): weight block [u][live c]
 TP_KIND_STRIDE = 8
 
 ACT_CODE = {None: 0, "silu": 1, "tanh": 2, "sigmoid": 3, "ssp": 4, "abs": 5}
@@ -358,9 +357,9 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         # wave tile: [16 * n_tiles16 edge rows][weight columns + 4 (+ 32: units off the shared path park the
         # edge's harmonics behind the weights; sized for them so that any unit order is valid)].  Without the 32
         # a block needs 35.8 instead of 52 KB of LDS, but four blocks per CU do not pay (docs/LAB_NOTES.md round 2).
-        # weight block of the entry: [u][live c] -- only the couplings some half has (the dead-output view of the last layer
-        # keeps 1-5 of up to 9: 23 instead of 56 tiles of matrix work per edge)
-        live = [key for key in combos if any(key in present for _, present in halves)] if TP_COMPACT else list(combos)
+        # weight block of the entry: [u][c] over ALL couplings of the group (absent ones: zero columns; a block packed to the
+        # live couplings was measured 7-9 % slower, docs/LAB_NOTES.md round 4)
+        live = list(combos)
         lds_need = max(lds_need, 16 * n_tiles16 * (16 * (-(-(mul_c * len(live)) // 16)) + 32 + 4))
         n_mt = -(-(mul_c * len(live)) // 16)  # 16-column MFMA tiles of the entry's weight block
         merged = len(halves) == 2

@@ -1123,106 +1123,6 @@ def test_neighbor_list_slabs_match_single_launch(monkeypatch):
         assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), k
 
 
-def _tile_switch(monkeypatch, pconv, on: bool):
-    """force the conv-tile path for every layer and batch size, or switch it off (module-level thresholds of nn/conv.py)"""
-    monkeypatch.setattr(pconv, "CONV_TILE", "1" if on else "0")
-    monkeypatch.setattr(pconv, "CONV_TILE_MIN_ROWS", 0 if on else 10**12)
-    monkeypatch.setattr(pconv, "CONV_TILE_MIN_DMID", 0)
-    monkeypatch.setattr(pconv, "AGG_KM_MIN_ROWS", 0)
-
-
-@pytest.mark.parametrize("gate_fuse", [True, False])
-def test_conv_fused_kernel_matches_two_kernel_path(monkeypatch, gate_fuse):
-    """matten_conv_tile (tensor product + neighbour sum + lin2 + self-connection [+ Gate + eval BatchNorm] per 16-node
-    single-species tile, agg never written) against the two-kernel conv (matten_tp_fused -> agg -> matten_agg_linear) and
-    the oracle, layer by layer, all four layers at full width: mixed species (ragged tiles: every (block, species) run is
-    padded to 16), a node count that is not a multiple of 16, per-node neighbour normalisation, an isolated atom, a block
-    size that cuts a crystal in two."""
-    from matten_amd.data import synthetic
-    from matten_amd.data.graph import collate, crystal_graph
-    from matten_amd.nn import conv as pconv
-
-    monkeypatch.setattr(pconv, "DEAD_PATH_ELIMINATION", False)   # all four layers at their full width
-    monkeypatch.setattr(pconv, "GATE_FUSE", gate_fuse)
-    monkeypatch.setattr(pconv, "CONV_TILE_BLOCK", 48)            # three tiles' worth of nodes per block: crystals straddle blocks
-    lone = crystal_graph(np.array([[0.0, 0, 0], [1.5, 0, 0], [6.0, 6.0, 6.0]]), 12.0 * np.eye(3), [29, 79, 29], 5.0)
-    lone_pair = crystal_graph(np.array([[0.0, 0, 0], [1.5, 0, 0], [2.5, 1.0, 0]]), 12.0 * np.eye(3), [29, 79, 29], 5.0)
-    for avg in (18.0, None):
-        # per-node normalisation divides by sqrt(num_neigh): 0 / 0 for the isolated atom in the reference too, so that
-        # case only goes with the fixed normalisation
-        graphs = synthetic.fcc64_graphs(2) + ([lone] if avg else [lone_pair])
-        ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": avg}
-        hp = dict(PAPER, average_num_neighbors="auto" if avg else None)
-        ref, model = build_pair(hp, ds, randomize_bn=True)
-        convs = [m for m in model.backbone.modules() if type(m).__name__ == "PointConv"]
-        assert all(m.tile_plan is not None for m in convs) and len(convs) == 4
-        outs = {}
-        for on in (True, False):
-            _tile_switch(monkeypatch, pconv, on)
-            cpu, dev = collate(graphs), collate(graphs, device=DEV)
-            feats = {}
-            with torch.no_grad():
-                for (name, rmod), (_, pmod) in zip(ref.backbone.named_children(), model.backbone.named_children()):
-                    cpu, dev = rmod(cpu), pmod(dev)
-                    if "node_features" in cpu:
-                        feats[name] = dev["node_features"].clone()
-                        close(dev["node_features"], cpu["node_features"], RTOL, f"{name}: tile={on} vs oracle")
-                # run twice: the accumulation order is fixed
-                again = model.backbone(collate(graphs, device=DEV))["my_model_output"]
-                assert torch.equal(again, dev["my_model_output"])
-            outs[on] = feats
-        for name in outs[True]:
-            close(outs[True][name], outs[False][name], 2e-5, f"{name}: conv-tile vs two-kernel")
-
-
-def test_conv_tile_kernel_on_the_n100_sample(golden_dir, monkeypatch):
-    """matten_conv_tile on the reference's n100 example set: 73 species in 473 atoms (almost every tile is a padded
-    single-species run of 1-16 nodes), degrees from 12 to 80, blocks of 64 nodes; against the two-kernel path and the oracle."""
-    from matten_amd.data.graph import average_num_neighbors, collate, crystal_graph
-    from matten_amd.nn import conv as pconv
-    from oracle.matten_ref import data as rdata
-
-    structs = rdata.structures_from_json(os.path.join(golden_dir, "example_crystal_elasticity_tensor_n100.json"))
-    graphs = [crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs]
-    species = sorted({int(z) for s in structs for z in s["atomic_numbers"]})
-    ref, model = build_pair(PAPER, {"allowed_species": species, "average_num_neighbors": average_num_neighbors(graphs)},
-                            randomize_bn=True)
-    monkeypatch.setattr(pconv, "CONV_TILE_BLOCK", 64)
-    batch = collate(graphs, device=DEV)
-    outs = {}
-    with torch.no_grad():
-        for on in (True, False):
-            _tile_switch(monkeypatch, pconv, on)
-            outs[on] = model(dict(batch))[0]["elastic_tensor_full"].clone()
-        want = ref.decode(collate(graphs))
-    close_blocks(outs[True], outs[False].cpu(), rtol=5e-6, floor=2e-6, what="n100: conv-tile vs two-kernel")
-    close_blocks(outs[True], want, what="n100: conv-tile vs oracle", want64=_want64(ref, graphs))
-
-
-def test_conv_tile_kernel_at_the_bench_batch(monkeypatch):
-    """the same comparison on the 1000-crystal fcc-64 batch of BASELINE configs[2] (64 000 nodes, 1.15 M edges; default
-    block size, Gate + BatchNorm inside the kernel, dead-output view of the last layer): conv-tile vs two-kernel model
-    output per irrep block, and a crystal's prediction does not depend on what else is in the batch (bitwise: the tiles
-    it lands in change with the batch, its arithmetic does not)."""
-    from matten_amd.data.graph import collate
-    from matten_amd.nn import conv as pconv
-
-    graphs, ds = _fcc(1000)
-    _, model = build_pair(PAPER, ds, randomize_bn=True)
-    batch = collate(graphs, device=DEV)
-    small = collate(graphs[37:187], device=DEV)
-    monkeypatch.setattr(pconv, "CONV_TILE", "1")
-    monkeypatch.setattr(pconv, "CONV_TILE_MIN_ROWS", 8192)
-    with torch.no_grad():
-        tiled = model(dict(batch))[0]["elastic_tensor_full"].clone()
-        tiled_small = model(dict(small))[0]["elastic_tensor_full"].clone()
-        monkeypatch.setattr(pconv, "CONV_TILE_MIN_ROWS", 10**12)
-        plain = model(dict(batch))[0]["elastic_tensor_full"].clone()
-    assert torch.isfinite(tiled).all()
-    close_blocks(tiled, plain.cpu(), rtol=5e-6, floor=2e-6, what="conv-tile vs two-kernel, 1000 crystals")
-    assert torch.equal(tiled[37:187], tiled_small), "a crystal's rows depend on the rest of the batch"
-
-
 def test_debug_mode_catches_nan_on_device():
     """log level DEBUG: the DetectAnomaly layers (reference nn/utils.py:370-394) name the first layer whose output holds
     a NaN; the same batch passes silently (NaN output) without them"""
@@ -1392,21 +1292,18 @@ def test_species_linear_selfcheck_runs_and_detects_a_wrong_result(monkeypatch):
     selfcheck.check_species_linear(DEV)
 
 
-@pytest.mark.parametrize("mode", ["streaming_lin2", "conv_tile", "hub_pieces_of_3"])
+@pytest.mark.parametrize("mode", ["streaming_lin2", "hub_pieces_of_3"])
 def test_fuzzed_models_on_poisoned_buffers(mode):
     """tests/fuzz_models.py (random irreps / multiplicities incl. non-powers of two / depth / normalisation on random small
     crystals, product vs oracle) with every torch.empty buffer starting as NaN (NAN_EMPTY=1) and one opt-in or
     size-dependent path forced for every layer and batch size:
       streaming_lin2   component-major neighbour sums + matten_agg_linear (the mode that found the alignment holes of
                        non-power-of-two multiplicities, plan.plan_agg_linear; MATTEN_AGG_KM_MIN_ROWS=0)
-      conv_tile        matten_conv_tile on 32-node blocks (MATTEN_CONV_TILE=1, thresholds 0)
       hub_pieces_of_3  every CSR segment walked in pieces of 3 edges (MATTEN_HUB_SPLIT_LEN=3)"""
     import subprocess
     import sys
 
     extra = {"streaming_lin2": {"MATTEN_AGG_KM_MIN_ROWS": "0"},
-             "conv_tile": {"MATTEN_CONV_TILE": "1", "MATTEN_CONV_TILE_MIN_ROWS": "0", "MATTEN_CONV_TILE_MIN_DMID": "0",
-                           "MATTEN_CONV_TILE_BLOCK": "32"},
              "hub_pieces_of_3": {"MATTEN_HUB_SPLIT_LEN": "3"}}[mode]
     env = dict(os.environ, NAN_EMPTY="1", **extra)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -31,6 +31,16 @@ def test_library_exports_every_declared_symbol():
     from matten_amd.plan import TP_TILE_NODES
 
     assert lib.matten_tp_tile_nodes() == TP_TILE_NODES
+    # the measurement helpers live in their own library with their own header (include/matten_lab.h): none of them in the
+    # product, all of them exported there
+    from matten_amd import lab
+
+    lab_header = open(os.path.join(ROOT, "include", "matten_lab.h")).read()
+    lab_declared = set(re.findall(r"\b(matten_[a-z0-9_]+)\s*\(", lab_header)) - {"matten_lab_stream_t"}
+    assert lab_declared == set(lab.SIGNATURES) and not (lab_declared & declared)
+    assert not any(hasattr(lib, n) for n in lab_declared)
+    lablib = lab.load()
+    assert lablib is not None and all(hasattr(lablib, n) for n in lab_declared)
     # host-detectable argument errors are reported without touching a GPU
     assert lib.matten_radial_mlp(None, -1, 8, 0.0, 5.0, None, 8, None, None, 32, 848, 1.0, None, 0, None) == -1
     assert lib.matten_species_linear(None, 0, None, None, 1, None, 0, None, 0, 0, None, 0, 1, None, None) == -1
@@ -428,93 +438,6 @@ def test_unsupported_configs_fail_up_front_with_the_full_list():
     assert isinstance(ei.value, NotImplementedError)
     with pytest.raises(UnsupportedConfig, match="allowed_species"):
         validate_hparams(PAPER, {"average_num_neighbors": 18.0})
-
-
-@pytest.mark.parametrize("case", ["paper_last", "paper_l2", "paper_l1", "paper_l0", "view", "ragged"])
-def test_conv_tile_plan_reproduces_lin2(case):
-    """plan_conv.plan_conv_tile turns lin2(agg) + add of a conv layer (reference nn/conv.py:77-79,123:
-    FullyConnectedTensorProduct(irreps_mid.simplify(), Sx0e, out)) into rounds / passes / units / pieces over the LDS dump
-    of matten_conv_tile; ``plan_conv.emulate_lin2`` walks those tables exactly as the kernel does.  Checked against the
-    dense contraction of the whole lin2 on the reference's mul_ir rows, plus the structural contracts the kernel relies
-    on: every entry in exactly one round slot, every (entry, coupling) consumed exactly once, passes within the dump,
-    weight columns of the entries a permutation of the reference's."""
-    from matten_amd import plan as mplan
-    from matten_amd import plan_conv as pc
-
-    sh = "0e+1o+2e+3o+4e"
-    full = "32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e"
-    cases = {
-        "paper_last": (full, sh, full, 3),
-        "paper_l2": ("32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e", sh, "32x0o+78x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e", 3),
-        "paper_l1": ("32x0e+16x1o+4x2e+2x3o+2x4e", sh, "78x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e", 4),
-        "paper_l0": ("16x0e", sh, "56x0e+16x1o+4x2e+2x3o+2x4e", 2),
-        "view": (full, sh, "32x0e+4x2e+2x4e", 3),
-        # 20 channels: chunks 8, 8, 4; 11x1o: 8 + 3 (an idle lane); odd output multiplicities; a lone 2-channel block
-        "ragged": ("20x0e+11x1o+3x2e+2x3o", "0e+1o+2e", "7x0e+5x1o+3x1e+2x2e+17x2o+1x3o", 3),
-    }
-    i1, ish, tgt, S = cases[case]
-    uvu = mplan.plan_uvu(i1, ish, tgt)
-    tp = pc.plan_conv_tile(uvu, S, tgt)
-    assert tp is not None
-    lin2 = mplan.plan_fctp(uvu.irreps_mid.simplify(), S, tgt)
-    rng = np.random.default_rng(11)
-    agg = rng.standard_normal((pc.TILE_NODES, uvu.d_mid))          # one tile, the reference's mul_ir row per node
-    add = rng.standard_normal((pc.TILE_NODES, lin2.d_out))
-    w = rng.standard_normal(lin2.weight_numel)
-    sp = 1
-    want = add.copy()
-    wp = w[lin2.gather[sp]] * lin2.scale
-    for p in lin2.passes:
-        for (xo, d, mi, wo, mo, oo, _, _) in p.tolist():
-            W = wp[wo:wo + mi * mo].reshape(mi, mo)
-            X = agg[:, xo:xo + mi * d].reshape(-1, mi, d)
-            want[:, oo:oo + mo * d] += np.einsum("uv,num->nvm", W, X).reshape(-1, mo * d)
-    # the walk's accumulators of an entry, from the mul_ir row: acc[node, lane channel, OFF[c] + k]
-    halves = {}
-    rows = tp.entries
-    col_seen = []
-
-    def acc_of_entry(e):
-        kind = int(rows[e][0])
-        l1, gi = kind // mplan.TP_KIND_STRIDE, kind % mplan.TP_KIND_STRIDE
-        combos = pc.kind_combos(l1, gi)
-        cu, mul, w_base = 1 << int(rows[e][3]), int(rows[e][2]), int(rows[e][5])
-        nacc = sum(2 * l3 + 1 for _, l3 in combos)
-        acc = np.zeros((pc.TILE_NODES, cu, nacc))
-        off = 0
-        mask = int(rows[e][4])
-        n_live = bin(mask).count("1") if mplan.TP_COMPACT else len(combos)   # weight block [u][live c] or [u][c]
-        for c, (l2, l3) in enumerate(combos):
-            d3 = 2 * l3 + 1
-            for uu in range(mul):
-                if mplan.TP_COMPACT and not (mask >> c) & 1:
-                    continue
-                rank = bin(mask & ((1 << c) - 1)).count("1") if mplan.TP_COMPACT else c
-                col = int(tp.fused_cols[w_base + uu * n_live + rank])   # reference weight column of (channel, coupling)
-                if col >= 0:
-                    pth = next(q for q in uvu.paths if q.w_off <= col < q.w_off + q.mul)
-                    assert (pth.l1, pth.l2, pth.l3) == (l1, l2, l3) and (int(rows[e][4]) >> c) & 1
-                    uch = col - pth.w_off
-                    acc[:, uu, off:off + d3] = agg[:, pth.out_off + uch * d3: pth.out_off + (uch + 1) * d3]
-            off += d3
-        return acc
-
-    got = pc.emulate_lin2(tp, uvu, w, sp, acc_of_entry, add)
-    assert np.isfinite(got).all()
-    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
-    # structure
-    used = sorted(int(e) for q in tp.quads for e in q[:4] if e >= 0)
-    assert used == list(range(len(rows)))
-    cols = np.sort(tp.fused_cols[tp.fused_cols >= 0])
-    assert (cols == np.arange(uvu.weight_numel)).all()           # every reference weight column exactly once
-    for q in tp.quads:
-        kinds = [int(rows[e][0]) for e in q[:4] if e >= 0]
-        assert int(q[5]) == max(max(pc.kind_passes(k // mplan.TP_KIND_STRIDE, k % mplan.TP_KIND_STRIDE)) for k in kinds) + 1
-        lanes = {max(2, int(rows[e][3])) for e in q[:4] if e >= 0}
-        assert lanes == {int(q[4])}                               # one chunk shape per round
-    assert (tp.pieces[:, 0] >= 0).all() and (tp.pieces[:, 0] + 9 * pc.DUMP_RS <= 4 * pc.DUMP_REGS * pc.DUMP_RS + 9 * pc.DUMP_RS).all()
-    assert (tp.pieces[:, 1] >= 0).all() and (tp.pieces[:, 1] < tp.a_stride).all()
-    assert tp.lds_bytes <= 64 * 1024 and int(rows[:, 3].max()) <= 4
 
 
 def test_debug_log_level_inserts_anomaly_detectors():
