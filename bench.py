@@ -452,6 +452,34 @@ def extras(dev):
     dt = (time.perf_counter() - t0) / 2
     pr["4000_structures"] = {"ms_per_1000_structures": 1e3 * dt / 4, "crystals_per_sec": len(many) / dt}
     del many
+    # where a 1000-structure call spends its time when nothing overlaps (each stage synchronised): host packing, species
+    # check, evaluate_soa = H2D + device neighbour lists + forward + to_cartesian + D2H, the result list.  predict() itself
+    # packs slab k + 1 behind the forwards of slab k (first slab PREDICT_FIRST_SLAB structures, then growing 4x)
+    def _t():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    stages = []
+    for _ in range(3):
+        t0 = _t(); pos_, cell_, Z_, ptr_, keep_, _f = P.pack_structures(structs)
+        t1 = _t(); P.check_species(model, structs, Z=Z_, ptr=ptr_, index=keep_)
+        t2 = _t(); out_, _e = P.evaluate_soa(model, pos_, cell_, Z_, ptr_, 5.0, batch_size=200)
+        t3 = _t(); _res = [out_[i] for i in range(len(out_))]
+        t4 = _t()
+        from matten_amd.data.graph import batch_graphs_gpu_soa
+        t5 = _t(); _b = batch_graphs_gpu_soa(pos_, cell_, Z_, ptr_, 5.0, dev)
+        t6 = _t()
+        with torch.no_grad():
+            _p = model(_b)[0]["elastic_tensor_full"]
+        t7 = _t(); _h = _p.cpu()
+        t8 = _t()
+        stages.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t6 - t5, t7 - t6, t8 - t7))
+    st = [1e3 * sorted(c)[1] for c in zip(*stages)]
+    pr["stage_split_1000_structures_ms"] = {
+        "host_pack": st[0], "species_check": st[1], "evaluate_soa_total": st[2], "result_list": st[3],
+        "inside_evaluate_soa": {"h2d_plus_device_graph_build": st[4], "forward": st[5], "d2h": st[6]},
+        "note": "median of 3, every stage synchronised (serial sum); predict() overlaps host_pack of later slabs and the graph "
+                "build of batch k + 1 with the forward of batch k"}
     ex["predict_end_to_end_fcc64"] = dict(pr, note="host structure dicts -> device neighbour lists -> forward -> Cartesian "
                                                      "tensors on the host (PCIe and host packing inside the time)")
     # the reference's real use: small crystals (the n100 sample, 4.7 atoms each, tiled to 1000 structures) at its default

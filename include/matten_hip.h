@@ -478,19 +478,25 @@ int matten_segment_reduce_bwd(const float* dy, int64_t dim, const int64_t* ptr, 
  * of a crystal} (the builder's one read-back); matten_neighbor_fill writes edge_index[2,n_edges] (int64),
  * edge_cell_shift[n_edges,3] (fp32) and num_neigh[N] (fp32, optional: edges per centre atom, the reference's
  * bincount(i), data/data.py:401-411).  max_atoms = largest n_b; at most 65535 crystals per call.
+ * The destination-sorted CSR of the list (what matten_csr_build derives from edge_index: destination = edge_index[1],
+ * stable in the edge id) comes out of the same two passes when asked for: counts_t[pair_ptr[B]] (optional) receives each
+ * pair's count at its j-major number pair_ptr[b] + (j - lo) n_b + (i - lo); the caller scans it into offsets_t like
+ * offsets (offsets_t[0] is subtracted: the scan may continue the i-major one), and matten_neighbor_fill then also writes rowptr[n_atoms + 1], src_sorted[n_edges], perm[n_edges] (int32; all
+ * four of offsets_t / rowptr / src_sorted / perm or none: NULL) -- bit for bit matten_csr_build's outputs.
  * ========================================================================================== */
 int matten_graph_prep(const double* pos, const double* cell, const int64_t* ptr, int64_t n_crystals, double r_cut,
                       double* frac, double* bound, int64_t* batch, float* pos_f32, float* cell_f32,
                       matten_stream_t stream);
 int matten_neighbor_count(const double* pos, const double* cell, const int64_t* ptr, const double* frac,
                           const double* bound, const int64_t* pair_ptr, double r_cut, int64_t n_crystals,
-                          int64_t max_atoms, int32_t* counts, matten_stream_t stream);
+                          int64_t max_atoms, int32_t* counts, int32_t* counts_t, matten_stream_t stream);
 int matten_neighbor_summary(const int64_t* offsets, const int64_t* pair_ptr, int64_t n_crystals, int64_t* out2,
                             matten_stream_t stream);
 int matten_neighbor_fill(const double* pos, const double* cell, const int64_t* ptr, const double* frac,
                          const double* bound, const int64_t* pair_ptr, double r_cut, int64_t n_crystals,
                          int64_t max_atoms, const int64_t* offsets, int64_t n_edges, int64_t* edge_index,
-                         float* edge_cell_shift, float* num_neigh, matten_stream_t stream);
+                         float* edge_cell_shift, float* num_neigh, const int64_t* offsets_t, int64_t n_atoms,
+                         int32_t* rowptr, int32_t* src_sorted, int32_t* perm, matten_stream_t stream);
 
 #ifdef __cplusplus
 }

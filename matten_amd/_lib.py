@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 41
+ABI_VERSION = 42
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -76,9 +76,10 @@ SIGNATURES = {
     "matten_instance_norm_bwd": (c_int, [P, P, c_int64, c_int64, P, P, c_int64, P, P, c_int64, P, P, P, c_float, P, P, P, P]),
     "matten_segment_reduce_bwd": (c_int, [P, c_int64, P, c_int64, c_int, P, P]),
     "matten_graph_prep": (c_int, [P, P, P, c_int64, ctypes.c_double, P, P, P, P, P, P]),
-    "matten_neighbor_count": (c_int, [P, P, P, P, P, P, ctypes.c_double, c_int64, c_int64, P, P]),
+    "matten_neighbor_count": (c_int, [P, P, P, P, P, P, ctypes.c_double, c_int64, c_int64, P, P, P]),
     "matten_neighbor_summary": (c_int, [P, P, c_int64, P, P]),
-    "matten_neighbor_fill": (c_int, [P, P, P, P, P, P, ctypes.c_double, c_int64, c_int64, P, c_int64, P, P, P, P]),
+    "matten_neighbor_fill": (c_int, [P, P, P, P, P, P, ctypes.c_double, c_int64, c_int64, P, c_int64, P, P, P, P, c_int64,
+                                     P, P, P, P]),
     "matten_gate_bn": (c_int, [P, c_int64, P, c_int64, P, P, P, P, P, c_float, c_int64, P, P]),
     "matten_segment_reduce": (c_int, [P, c_int64, P, c_int64, c_int, P, P]),
     "matten_segment_minmax": (c_int, [P, c_int64, P, c_int64, c_int, P, P, P]),

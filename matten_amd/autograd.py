@@ -138,10 +138,12 @@ class TensorProductScatterFn(torch.autograd.Function):
 
         rowptr, split = data[DataKey.AMD_ROWPTR], None
         if nnu.HUB_SPLIT_LEN > 0 and x.shape[0] < TRAIN_HUB_SPLIT_MAX_ROWS:
-            split = data.get("_amd_csr_split")
+            # (its own cache key: the inference forward cuts the same rowptr into pieces of another length)
+            key = ("_amd_csr_split", nnu.HUB_SPLIT_LEN, num_neigh is None)
+            split = data.get(key)
             if split is None or split[3] is not rowptr:
                 split = ops.csr_split(rowptr, data[DataKey.AMD_SRC].shape[0], nnu.HUB_SPLIT_LEN, num_neigh) + (rowptr,)
-                data["_amd_csr_split"] = split
+                data[key] = split
         agg = ops.tp_paths(x, w_edge, data[DataKey.AMD_SH], rowptr if split is None else split[0], data[DataKey.AMD_SRC],
                            mod._tables.get("entries", dev), mod._tables.get("unit_start", dev), p.units_per_tile,
                            p.d_mid, avg, num_neigh if split is None else split[2])

@@ -12,8 +12,13 @@
 // decides) -- ~2 values per axis instead of the 2 reach + 1 of a per-crystal box (5^3 = 125 images per pair for an
 // fcc-64 cell, 8 now).  The shifts are walked in lexicographic order twice: a counting pass, then (after an exclusive
 // scan of the per-pair counts by the caller) a fill pass that writes the pair's edges contiguously.  Pairs are
-// numbered crystal by crystal, i-major, so the scan order IS the canonical edge order.  Distances use the host
-// builder's fp64 expression with contraction disabled; the square root is only evaluated for the pairs within 1e-15
+// numbered crystal by crystal, i-major, so the scan order IS the canonical edge order.
+// The destination-sorted CSR the conv layers walk (destination = edge_index[1] = j, stable in the edge id: what
+// matten_csr_build derives from the finished list in seven launches) falls out of the same two passes: the counting
+// pass also stores each pair's count at its TRANSPOSED (j-major) pair number, the caller scans those too, and the fill
+// pass drops the pair's edge ids / centre atoms at that second offset -- for a fixed j the pairs come i-ascending and a
+// pair's edges in shift order, i.e. in ascending edge id.  rowptr[j] is the j-major offset of pair (first atom, j).
+// Distances use the host builder's fp64 expression with contraction disabled; the square root is only evaluated for the pairs within 1e-15
 // (relative) of the cutoff, which leaves the decision bit-identical.
 #include "common.h"
 
@@ -70,11 +75,21 @@ __device__ __forceinline__ void shift_range(double bound, double df, int& lo, in
     hi = (int)floor(bound - df + slack);
 }
 
+struct CsrOut {                // optional outputs of the fill pass: the destination-sorted view (all or none)
+    const int64_t* offsets_t;  // [n_pairs + 1] scan of the j-major counts; offsets_t[0] (any constant) is subtracted
+    int32_t* rowptr;           // [N + 1]
+    int32_t* src_sorted;       // [E] centre atom i of the edge at each sorted position
+    int32_t* perm;             // [E] sorted position -> edge id
+    int64_t n_atoms;
+};
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void neighbor_kernel(Cry c, double r_cut, int32_t* __restrict__ counts,
+                                                       int32_t* __restrict__ counts_t,
                                                        const int64_t* __restrict__ offsets,
                                                        int64_t* __restrict__ edge_index, int64_t n_edges,
-                                                       float* __restrict__ shifts, float* __restrict__ num_neigh) {
+                                                       float* __restrict__ shifts, float* __restrict__ num_neigh,
+                                                       CsrOut csr) {
     const int64_t b = blockIdx.y;
     const int64_t lo = c.ptr[b];
     const int64_t n = c.ptr[b + 1] - lo;
@@ -93,6 +108,13 @@ __global__ __launch_bounds__(256) void neighbor_kernel(Cry c, double r_cut, int3
     const double r2_in = r2 * (1.0 - 1e-15), r2_out = r2 * (1.0 + 1e-15);
     int64_t out = FILL ? offsets[pair] : 0;
     if (FILL && num_neigh && j == lo) num_neigh[i] = (float)(offsets[pair + n] - offsets[pair]);   // atom i's n pairs
+    const int64_t pair_t = c.pair_ptr[b] + (j - lo) * n + (i - lo);   // the same pair numbered j-major
+    int64_t out_t = 0;
+    if (FILL && csr.rowptr) {
+        out_t = csr.offsets_t[pair_t] - csr.offsets_t[0];   // (a scan that continues the i-major one starts at n_edges)
+        if (i == lo) csr.rowptr[j] = (int32_t)out_t;
+        if (pair == 0) csr.rowptr[csr.n_atoms] = (int32_t)n_edges;
+    }
     int cnt = 0;
     for (int sx = x0; sx <= x1; ++sx)
         for (int sy = y0; sy <= y1; ++sy) {
@@ -115,13 +137,21 @@ __global__ __launch_bounds__(256) void neighbor_kernel(Cry c, double r_cut, int3
                         shifts[3 * out] = (float)sx;
                         shifts[3 * out + 1] = (float)sy;
                         shifts[3 * out + 2] = (float)sz;
+                        if (csr.rowptr) {
+                            csr.perm[out_t] = (int32_t)out;
+                            csr.src_sorted[out_t] = (int32_t)i;
+                            ++out_t;
+                        }
                         ++out;
                     }
                     ++cnt;
                 }
             }
         }
-    if (!FILL) counts[pair] = cnt;
+    if (!FILL) {
+        counts[pair] = cnt;
+        if (counts_t) counts_t[pair_t] = cnt;
+    }
 }
 
 // {number of edges, smallest edge count of a crystal} from the scanned pair counts: the one read-back of the builder
@@ -160,14 +190,14 @@ extern "C" int matten_graph_prep(const double* pos, const double* cell, const in
 
 extern "C" int matten_neighbor_count(const double* pos, const double* cell, const int64_t* ptr, const double* frac,
                                      const double* bound, const int64_t* pair_ptr, double r_cut, int64_t n_crystals,
-                                     int64_t max_atoms, int32_t* counts, matten_stream_t stream_) {
+                                     int64_t max_atoms, int32_t* counts, int32_t* counts_t, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_crystals < 0 || max_atoms < 0 || !(r_cut > 0.0) || n_crystals > 65535) return MATTEN_EINVAL;
     if (n_crystals == 0 || max_atoms == 0) return MATTEN_OK;
     if (!pos || !cell || !ptr || !frac || !bound || !pair_ptr || !counts) return MATTEN_EINVAL;
     Cry c{pos, cell, ptr, frac, bound, pair_ptr};
     dim3 grid((unsigned)matten_cdiv(max_atoms * max_atoms, 256), (unsigned)n_crystals);
-    neighbor_kernel<false><<<grid, 256, 0, stream>>>(c, r_cut, counts, nullptr, nullptr, 0, nullptr, nullptr);
+    neighbor_kernel<false><<<grid, 256, 0, stream>>>(c, r_cut, counts, counts_t, nullptr, nullptr, 0, nullptr, nullptr, CsrOut{});
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }
@@ -184,16 +214,22 @@ extern "C" int matten_neighbor_summary(const int64_t* offsets, const int64_t* pa
 extern "C" int matten_neighbor_fill(const double* pos, const double* cell, const int64_t* ptr, const double* frac,
                                     const double* bound, const int64_t* pair_ptr, double r_cut, int64_t n_crystals,
                                     int64_t max_atoms, const int64_t* offsets, int64_t n_edges, int64_t* edge_index,
-                                    float* edge_cell_shift, float* num_neigh, matten_stream_t stream_) {
+                                    float* edge_cell_shift, float* num_neigh, const int64_t* offsets_t, int64_t n_atoms,
+                                    int32_t* rowptr, int32_t* src_sorted, int32_t* perm, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_crystals < 0 || max_atoms < 0 || n_edges < 0 || !(r_cut > 0.0) || n_crystals > 65535) return MATTEN_EINVAL;
     if (n_crystals == 0 || max_atoms == 0) return MATTEN_OK;
     if (!pos || !cell || !ptr || !frac || !bound || !pair_ptr || !offsets) return MATTEN_EINVAL;
     if (n_edges > 0 && (!edge_index || !edge_cell_shift)) return MATTEN_EINVAL;
+    const bool want_csr = offsets_t || rowptr || src_sorted || perm;
+    if (want_csr && (!offsets_t || !rowptr || n_atoms < 0 || n_edges >= ((int64_t)1 << 31) ||
+                     (n_edges > 0 && (!src_sorted || !perm))))
+        return MATTEN_EINVAL;
     Cry c{pos, cell, ptr, frac, bound, pair_ptr};
+    CsrOut csr{offsets_t, want_csr ? rowptr : nullptr, src_sorted, perm, n_atoms};
     dim3 grid((unsigned)matten_cdiv(max_atoms * max_atoms, 256), (unsigned)n_crystals);
-    neighbor_kernel<true><<<grid, 256, 0, stream>>>(c, r_cut, nullptr, offsets, edge_index, n_edges, edge_cell_shift,
-                                                    num_neigh);
+    neighbor_kernel<true><<<grid, 256, 0, stream>>>(c, r_cut, nullptr, nullptr, offsets, edge_index, n_edges, edge_cell_shift,
+                                                    num_neigh, csr);
     MATTEN_LAUNCH_CHECK();
     return MATTEN_OK;
 }

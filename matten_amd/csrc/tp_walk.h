@@ -119,6 +119,12 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_BRANCH_FREE_STEPS
 #define TPF_BRANCH_FREE_STEPS 0
 #endif
+#ifndef TPF_EXACT_Y
+#define TPF_EXACT_Y 0
+#endif
+#ifndef TPF_PUBLISH_EARLY
+#define TPF_PUBLISH_EARLY 0
+#endif
 __host__ __device__ constexpr int cap_channels(int l1, int nc) {
     int cap = 64;
     while (cap > 1 && cap * nc > (l1 == 0 ? TPF_MAX_COLS_L0 : l1 == 1 ? TPF_MAX_COLS_L1 : TPF_MAX_COLS)) cap /= 2;
@@ -191,6 +197,41 @@ __device__ __forceinline__ void mfma_tiles(const f16x8* __restrict__ ah, const f
     for (int mt = 0; mt < MTC; ++mt) dx[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, dx[mt], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) *reinterpret_cast<f32x4*>(trow + mt * 16) = dh[mt] + SPLIT_LO_INV * dx[mt];
+}
+
+
+// y[0..NY) = the staged row's harmonics [Y0, Y0 + NY): 16-byte reads over the aligned middle, 4- / 8-byte reads at the ragged
+// ends -- exactly NY registers.  (Whole quads over the covering range left 3-4 dead registers per step that the allocator
+// reused for the weights: a write-after-read on a load still in flight, i.e. a second LDS round trip per edge step.)
+template <int Y0, int NY>
+__device__ __forceinline__ void read_harmonics(const float* __restrict__ row, float (&y)[NY]) {
+    constexpr int A = (Y0 + 3) / 4 * 4;                 // first 16-byte aligned column at or after Y0
+    constexpr int B = (Y0 + NY) / 4 * 4;                // end of the aligned middle
+    if constexpr (A >= B) {
+#pragma unroll
+        for (int j = 0; j < NY; ++j) y[j] = row[Y0 + j];
+    } else {
+        constexpr int HEAD = A - Y0, TAIL = Y0 + NY - B;
+        if constexpr (HEAD == 1) y[0] = row[Y0];
+        if constexpr (HEAD == 2) { const float2 v = *reinterpret_cast<const float2*>(row + Y0); y[0] = v.x, y[1] = v.y; }
+        if constexpr (HEAD == 3) {
+            y[0] = row[Y0];
+            const float2 v = *reinterpret_cast<const float2*>(row + Y0 + 1);
+            y[1] = v.x, y[2] = v.y;
+        }
+#pragma unroll
+        for (int q = A; q < B; q += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + q);
+            y[q - Y0] = v[0], y[q - Y0 + 1] = v[1], y[q - Y0 + 2] = v[2], y[q - Y0 + 3] = v[3];
+        }
+        if constexpr (TAIL == 1) y[NY - 1] = row[B];
+        if constexpr (TAIL == 2) { const float2 v = *reinterpret_cast<const float2*>(row + B); y[NY - 2] = v.x, y[NY - 1] = v.y; }
+        if constexpr (TAIL == 3) {
+            const float2 v = *reinterpret_cast<const float2*>(row + B);
+            y[NY - 3] = v.x, y[NY - 2] = v.y;
+            y[NY - 1] = row[B + 2];
+        }
+    }
 }
 
 // loader role of a thread: (edge row of the chunk, 16-byte piece of the row) per MFMA tile; fixed for the whole walk
@@ -498,9 +539,11 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 #endif
         auto contract = [&](int so, const float* __restrict__ x) {
             const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
-            const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
             float y[G::NY], w[NC];
-            {   // the harmonics of a staged row are 16-byte aligned: whole ds_read_b128 over [Y0, Y0 + NY)
+            if constexpr (TPF_EXACT_Y) {
+                read_harmonics<G::Y0, G::NY>(sb + ((j << ch_log2) + so) * STAGE_ROW + 32, y);
+            } else {   // the harmonics of a staged row are 16-byte aligned: whole ds_read_b128 over [Y0, Y0 + NY)
+                const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
                 constexpr int Q0 = G::Y0 / 4 * 4, NQ = (G::Y0 + G::NY - Q0 + 3) / 4;
                 float yq[4 * NQ];
                 const f32x4* y4 = reinterpret_cast<const f32x4*>(yp - (G::Y0 - Q0));
@@ -568,22 +611,33 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                 }
             }
         } else if (two_deep) {
+            auto refill_n = [&](int s) {
+                const float* xp = a.x + (int64_t)TPF_SRC(src_nn) * a.d_in + xcol;
+#pragma unroll
+                for (int i = 0; i < G::D1; ++i) xn[i] = TPF_XLD(xp, i, src_nn);
+                src_nn = a.src_sorted[min(beg + s + 4, e_last)];
+            };
+            auto refill_b = [&](int s) {
+                const float* xp = a.x + (int64_t)TPF_SRC(src_b) * a.d_in + xcol;
+#pragma unroll
+                for (int i = 0; i < G::D1; ++i) xb[i] = TPF_XLD(xp, i, src_b);
+                src_b = a.src_sorted[min(beg + s + 5, e_last)];
+            };
             for (int so = 0; so < CH; so += 2) {   // CH is 2, 4 or 8 here: slot pairs, one row buffer per parity
                 const int s = s0 + so;
+                const bool last = TPF_PUBLISH_EARLY && so + 2 >= CH;
                 if (s < deg) contract(so, xn);
-                {
-                    const float* xp = a.x + (int64_t)TPF_SRC(src_nn) * a.d_in + xcol;
-#pragma unroll
-                    for (int i = 0; i < G::D1; ++i) xn[i] = TPF_XLD(xp, i, src_nn);
-                    src_nn = a.src_sorted[min(beg + s + 4, e_last)];
-                }
+                if (!last) refill_n(s);
                 if (s + 1 < deg) contract(so + 1, xb);
-                {
-                    const float* xp = a.x + (int64_t)TPF_SRC(src_b) * a.d_in + xcol;
-#pragma unroll
-                    for (int i = 0; i < G::D1; ++i) xb[i] = TPF_XLD(xp, i, src_b);
-                    src_b = a.src_sorted[min(beg + s + 5, e_last)];
-                }
+                if (!last) refill_b(s);
+            }
+            if (TPF_PUBLISH_EARLY) {
+                // the stage rows requested at the top of the chunk go to LDS BEFORE the chunk's last gathers are issued: the
+                // publish waits on the vector-memory counter, which retires in order -- behind freshly issued gathers it
+                // waited for THEIR round trip too (400-500 cycles per chunk of the l1 <= 1 kinds, tools/tp_trace.py)
+                ld.publish(buf ^ 1);
+                refill_n(s0 + CH - 2);
+                refill_b(s0 + CH - 2);
             }
         } else {
             for (int so = 0; so < CH; ++so) {
@@ -604,7 +658,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 #if TPF_TRACING
         const unsigned long long tr_c = tpf_stamp_after(acc);
 #endif
-        ld.publish(buf ^ 1);
+        if (!(two_deep && TPF_PUBLISH_EARLY && !TPF_BRANCH_FREE_STEPS)) ld.publish(buf ^ 1);
 #if TPF_TRACING
         const unsigned long long tr_d = tpf_stamp();
 #endif

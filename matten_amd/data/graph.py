@@ -14,6 +14,8 @@ lexicographic order (i, j, Sx, Sy, Sz).
 """
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import numpy as np
 import torch
 from scipy.spatial import cKDTree
@@ -105,6 +107,7 @@ def average_num_neighbors(graphs: Sequence[Dict[str, torch.Tensor]]) -> float:
 
 
 _MAX_CRYSTALS_PER_LAUNCH = 65535
+EMIT_CSR = os.environ.get("MATTEN_GRAPH_EMIT_CSR", "1") != "0"   # device builder: batches carry their destination-sorted CSR
 
 
 class EdgelessStructures(ValueError):
@@ -154,6 +157,8 @@ def batch_graphs_gpu_soa(pos: np.ndarray, cell: np.ndarray, Z: np.ndarray, ptr: 
             a, b = ptr[lo], ptr[hi]
             try:
                 parts.append(batch_graphs_gpu_soa(pos[a:b], cell[lo:hi], Z[a:b], ptr[lo : hi + 1] - a, r_cut, device))
+                for k in [k for k in parts[-1] if k.startswith("_amd_")]:
+                    del parts[-1][k]   # a slab's own CSR does not concatenate: the forward builds the whole batch's
             except EdgelessStructures as e:
                 raise EdgelessStructures([lo + k for k in e.indices]) from None
         out, node_off, cry_off = {}, 0, 0
@@ -185,7 +190,7 @@ def batch_graphs_gpu_soa(pos: np.ndarray, cell: np.ndarray, Z: np.ndarray, ptr: 
     ptrs_d = torch.from_numpy(np.stack([ptr, pair_ptr])).to(dev)
     ptr_d, pair_ptr_d = ptrs_d[0], ptrs_d[1]
     frac_d, bound_d, batch_d, pos32, cell32 = ops.graph_prep(pos_d, cell_d, ptr_d, r_cut)
-    edge_index, shifts, num_neigh, pair_off, min_edges = ops.neighbor_list(
+    edge_index, shifts, num_neigh, pair_off, min_edges, csr = ops.neighbor_list(
         pos_d, cell_d, ptr_d, frac_d, bound_d, pair_ptr_d, r_cut, int(sizes.max()), n_pairs)
     if min_edges == 0:   # (came back with the edge count: no second sync on the common path)
         per_crystal = pair_off[pair_ptr_d[1:]] - pair_off[pair_ptr_d[:-1]]
@@ -202,4 +207,11 @@ def batch_graphs_gpu_soa(pos: np.ndarray, cell: np.ndarray, Z: np.ndarray, ptr: 
         out[k] = torch.as_tensor(v).to(dev)
     out["batch"] = batch_d
     out["ptr"] = ptr_d
+    if csr is not None and EMIT_CSR:
+        # the destination-sorted view every conv layer walks, emitted by the search itself (bit-identical to what
+        # matten_csr_build derives from edge_index: tests/test_gpu_parity.py); the forward then skips that build.  Private
+        # keys: whoever edits edge_index afterwards must drop them (nn/_nequip.ensure_graph trusts them when present)
+        from ._key import AMD_PERM, AMD_ROWPTR, AMD_SRC
+
+        out[AMD_PERM], out[AMD_ROWPTR], out[AMD_SRC] = csr
     return out

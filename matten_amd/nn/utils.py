@@ -349,10 +349,11 @@ class UVUTensorProduct(torch.nn.Module):
             if out_layout is None and piece > 0 and node_feats.shape[0] < HUB_SPLIT_MAX_ROWS:
                 # small batch: the launch lasts as long as its longest CSR segment (one hub node walked serially by one
                 # wave): walk pieces of at most hub_split_len() edges as virtual nodes and sum them afterwards, in order
-                split = data.get("_amd_csr_split")
+                key = ("_amd_csr_split", piece, num_neigh is None)   # (the training forward cuts at its own length)
+                split = data.get(key)
                 if split is None or split[3] is not rowptr:
                     split = ops.csr_split(rowptr, data[DataKey.AMD_SRC].shape[0], piece, num_neigh) + (rowptr,)
-                    data["_amd_csr_split"] = split
+                    data[key] = split
             agg = ops.tp_fused(
                 node_feats, h2p, w2p, data[DataKey.AMD_SH], rowptr if split is None else split[0], data[DataKey.AMD_SRC],
                 out_layout[0] if out_layout is not None else self._tables.get("gentries", dev),

@@ -858,12 +858,14 @@ def graph_prep(pos64, cell64, ptr, r_cut: float):
     return frac, bound, batch, pos32, cell32
 
 
-def neighbor_list(pos64, cell64, ptr, frac, bound, pair_ptr, r_cut: float, max_atoms: int, n_pairs: int):
+def neighbor_list(pos64, cell64, ptr, frac, bound, pair_ptr, r_cut: float, max_atoms: int, n_pairs: int, want_csr: bool = True):
     """Periodic neighbour list of a batch of crystals, canonical (i, j, Sx, Sy, Sz) order.
     frac / bound: ops.graph_prep; pair_ptr[B+1] = running sum of n_b^2 (ordered pairs numbered crystal by crystal,
     i-major), n_pairs = pair_ptr[B].
     -> (edge_index [2,E] i64 (global ids), edge_cell_shift [E,3] f32, num_neigh [N] f32 (edges per centre atom),
-        pair_offsets [n_pairs+1] i64, smallest edge count of a crystal: an int, read back together with the edge count)"""
+        pair_offsets [n_pairs+1] i64, smallest edge count of a crystal: an int, read back together with the edge count,
+        csr = (perm [E] i32, rowptr [N+1] i32, src_sorted [E] i32) -- the destination-sorted view ops.csr_build would derive
+        from edge_index, bit for bit -- or None)"""
     lib = _lib.load()
     pos64 = _need(pos64, torch.float64, "pos")
     cell64 = _need(cell64, torch.float64, "cell")
@@ -872,16 +874,20 @@ def neighbor_list(pos64, cell64, ptr, frac, bound, pair_ptr, r_cut: float, max_a
     bound = _need(bound, torch.float64, "bound")
     pair_ptr = _need(pair_ptr, torch.int64, "pair_ptr")
     B = ptr.shape[0] - 1
+    N = pos64.shape[0]
     dev = pos64.device
-    counts = torch.empty(n_pairs, dtype=torch.int32, device=dev)
+    # i-major counts in the first half, the same counts numbered j-major in the second: ONE scan serves both orders
+    counts = torch.empty((2 if want_csr else 1) * n_pairs, dtype=torch.int32, device=dev)
     with _timed("neighbor_count"):
         _lib.check(
             lib.matten_neighbor_count(_ptr(pos64), _ptr(cell64), _ptr(ptr), _ptr(frac), _ptr(bound), _ptr(pair_ptr),
-                                      float(r_cut), B, int(max_atoms), _ptr(counts), _stream()),
+                                      float(r_cut), B, int(max_atoms), _ptr(counts),
+                                      counts.data_ptr() + 4 * n_pairs if (want_csr and n_pairs) else None, _stream()),
             "matten_neighbor_count",
         )
-    offsets = torch.zeros(n_pairs + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(counts, 0, dtype=torch.int64, out=offsets[1:])
+    scan = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, dtype=torch.int64, out=scan[1:])
+    offsets = scan[: n_pairs + 1]
     # the one host sync of graph construction: the edge count sizes the outputs; the smallest edge count of a crystal
     # (0: the caller has to find and report the edgeless ones) rides on the same read-back
     if n_pairs:
@@ -893,12 +899,18 @@ def neighbor_list(pos64, cell64, ptr, frac, bound, pair_ptr, r_cut: float, max_a
         E, min_edges = 0, 0
     edge_index = torch.empty(2, E, dtype=torch.int64, device=dev)
     shifts = torch.empty(E, 3, dtype=torch.float32, device=dev)
-    num_neigh = torch.empty(pos64.shape[0], dtype=torch.float32, device=dev)
+    num_neigh = torch.empty(N, dtype=torch.float32, device=dev)
+    csr = offsets_t = None
+    if want_csr and n_pairs and E < 2 ** 31:
+        offsets_t = scan[n_pairs:]               # the j-major half of the scan (starts at E: the kernel subtracts it)
+        csr = (torch.empty(E, dtype=torch.int32, device=dev), torch.empty(N + 1, dtype=torch.int32, device=dev),
+               torch.empty(E, dtype=torch.int32, device=dev))
     with _timed("neighbor_fill"):
         _lib.check(
             lib.matten_neighbor_fill(_ptr(pos64), _ptr(cell64), _ptr(ptr), _ptr(frac), _ptr(bound), _ptr(pair_ptr),
                                      float(r_cut), B, int(max_atoms), _ptr(offsets), E, _ptr(edge_index), _ptr(shifts),
-                                     _ptr(num_neigh), _stream()),
+                                     _ptr(num_neigh), _ptr(offsets_t), N, _ptr(csr[1]) if csr else None,
+                                     _ptr(csr[2]) if csr else None, _ptr(csr[0]) if csr else None, _stream()),
             "matten_neighbor_fill",
         )
-    return edge_index, shifts, num_neigh, offsets, int(min_edges)
+    return edge_index, shifts, num_neigh, offsets, int(min_edges), csr

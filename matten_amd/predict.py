@@ -151,6 +151,18 @@ _SIDE_STREAMS: Dict[Any, Any] = {}
 NODE_BUDGET = int(__import__("os").environ.get("MATTEN_PREDICT_NODE_BUDGET", "65536"))
 
 
+REFERENCE_BATCH_SIZE = 200   # predict.py:155 of the reference
+
+
+def effective_node_budget(batch_size: int, node_budget: int = None) -> int:
+    """atoms a merged forward may hold: the caller's `node_budget` when given; otherwise NODE_BUDGET -- unless the caller
+    LOWERED batch_size below the reference's default, which is how one makes a forward fit a small or shared GPU there:
+    such batches are run as they are (0 = no merging)"""
+    if node_budget is not None:
+        return max(0, int(node_budget))
+    return NODE_BUDGET if batch_size >= REFERENCE_BATCH_SIZE else 0
+
+
 def coalesce_batches(ptr, batch_size: int, node_budget: int = None):
     """Crystal index ranges of the forwards evaluate_soa runs.  ``batch_size`` is the reference's knob for how many
     structures share a forward (predict.py:155, default 200); a crystal's prediction does not depend on its batch mates
@@ -211,7 +223,8 @@ class _deferred_input_checks:
 
 
 def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
-                 tensor_target_name: str = "elastic_tensor_full", tensor_target_formula: str = "ijkl=jikl=klij"):
+                 tensor_target_name: str = "elastic_tensor_full", tensor_target_formula: str = "ijkl=jikl=klij",
+                 node_budget: int = None):
     """Batched forward straight from the flat arrays of ``pack_structures``.  Graphs are built on the device batch
     by batch on a SECOND stream: the neighbour search of batch k+1 (and its one host sync, the edge count) overlaps
     the forward of batch k, which runs on the caller's stream.
@@ -219,10 +232,10 @@ def evaluate_soa(model, pos, cell, Z, ptr, r_cut: float, batch_size: int = 200,
     model.eval()
     with _deferred_input_checks(model):
         return _soa_end(model, _soa_begin(model, pos, cell, Z, ptr, r_cut, batch_size, tensor_target_name,
-                                          tensor_target_formula))
+                                          tensor_target_formula, node_budget))
 
 
-def _soa_begin(model, pos, cell, Z, ptr, r_cut, batch_size, tensor_target_name, tensor_target_formula):
+def _soa_begin(model, pos, cell, Z, ptr, r_cut, batch_size, tensor_target_name, tensor_target_formula, node_budget=None):
     """enqueue every forward of the packed structures (inside _deferred_input_checks) -> (device tensors [B, 3, ...],
     indices of crystals without any edge); nothing here waits for the forwards"""
     from .data.graph import batch_graphs_gpu_soa
@@ -256,8 +269,22 @@ def _soa_begin(model, pos, cell, Z, ptr, r_cut, batch_size, tensor_target_name, 
                     ids = np.delete(ids, e.indices)
         return ids, None
 
-    chunks = coalesce_batches(ptr, batch_size)
-    _evaluate_soa_loop(model, chunks, build, main, side, out, edgeless, converter, tensor_target_name, device)
+    budget = effective_node_budget(batch_size, node_budget)
+    try:
+        _evaluate_soa_loop(model, coalesce_batches(ptr, batch_size, budget), build, main, side, out, edgeless, converter,
+                           tensor_target_name, device)
+    except torch.cuda.OutOfMemoryError:
+        if budget == 0:
+            raise
+        # a merged forward did not fit (a shared or small GPU): start over with the caller's own batches
+        torch.cuda.synchronize(device)
+        torch.cuda.empty_cache()
+        warnings.warn(f"a merged forward of up to {budget} atoms ran out of device memory: running batches of {batch_size} "
+                      "structures unmerged (pass node_budget= to predict() to set the limit)")
+        out.fill_(float("nan"))
+        del edgeless[:]
+        _evaluate_soa_loop(model, coalesce_batches(ptr, batch_size, 0), build, main, side, out, edgeless, converter,
+                           tensor_target_name, device)
     return out, edgeless
 
 
@@ -389,11 +416,16 @@ def evaluate_atomic(model, graphs: List, batch_size: int = 200, tensor_target_na
 
 
 PREDICT_SLAB = int(__import__("os").environ.get("MATTEN_PREDICT_SLAB", "1024"))   # structures packed per slab
+# the FIRST slab is small and the following ones grow by 4x up to the full size: the device starts after ~0.3 ms of host
+# packing instead of after the 2-3 ms a full slab takes, and from then on packs slab k + 1 behind the forwards of slab k
+PREDICT_FIRST_SLAB = int(__import__("os").environ.get("MATTEN_PREDICT_FIRST_SLAB", "128"))
+PREDICT_SLAB_GROWTH = 4
 
 
-def _predict_slabs(model, structures, r_cut, batch_size, tensor_target_name, tensor_target_formula):
+def _predict_slabs(model, structures, r_cut, batch_size, tensor_target_name, tensor_target_formula, node_budget=None):
     """-> (predictions of the usable structures in input order, sorted indices of the failed ones)"""
     n = len(structures)
+    budget = effective_node_budget(batch_size, node_budget)
 
     def pack(lo, hi):
         try:
@@ -407,7 +439,8 @@ def _predict_slabs(model, structures, r_cut, batch_size, tensor_target_name, ten
     failed, inflight = [], []
     model.eval()
     with _deferred_input_checks(model):
-        lo, size = 0, PREDICT_SLAB
+        ramp = max(1, min(PREDICT_FIRST_SLAB, PREDICT_SLAB))
+        lo, size = 0, (ramp if n >= 2 * ramp else PREDICT_SLAB)
         nxt = pack(0, min(n, size)) if n else None
         while nxt is not None:
             cur, bad = nxt
@@ -416,11 +449,12 @@ def _predict_slabs(model, structures, r_cut, batch_size, tensor_target_name, ten
             if cur is not None:
                 pos, cell, Z, ptr, keep = cur
                 inflight.append((keep, _soa_begin(model, pos, cell, Z, ptr, r_cut, batch_size, tensor_target_name,
-                                                  tensor_target_formula)))
+                                                  tensor_target_formula, node_budget)))
                 # a slab should fill a forward: ~NODE_BUDGET atoms (1024 fcc-64 crystals, ~14 000 of the reference's
                 # 4.7-atom ones), between PREDICT_SLAB and 16 PREDICT_SLAB structures
                 per = max(1.0, len(pos) / max(1, len(keep)))
-                size = int(min(16 * PREDICT_SLAB, max(PREDICT_SLAB, NODE_BUDGET / per)))
+                ramp *= PREDICT_SLAB_GROWTH
+                size = int(min(16 * PREDICT_SLAB, max(PREDICT_SLAB, max(NODE_BUDGET, budget) / per), ramp))
             nxt = pack(lo, min(n, lo + size)) if lo < n else None   # overlaps the forwards just enqueued
         predictions = []
         for keep, handle in inflight:
@@ -444,8 +478,13 @@ def predict(
     is_atomic_tensor: bool = False,
     model: ScalarTensorModel = None,
     config: Dict[str, Any] = None,
+    node_budget: int = None,
 ):
-    """See the module docstring.  ``model`` / ``config`` let a caller reuse an already loaded model."""
+    """See the module docstring.  ``model`` / ``config`` let a caller reuse an already loaded model.
+    ``batch_size`` (reference predict.py:155) is the memory knob it is there: consecutive batches are merged into one forward
+    only while the merged batch stays within ``node_budget`` atoms (default MATTEN_PREDICT_NODE_BUDGET = 65536, ~2 GB) and
+    only when batch_size is at least the reference's default of 200; ``node_budget=0`` never merges.  A merged forward
+    that runs out of device memory is retried unmerged."""
     from .log import set_logger
 
     set_logger(logger_level)  # reference predict.py:194
@@ -476,7 +515,7 @@ def predict(
     # device runs the forwards of slab k the host packs slab k + 1 (a 1000-structure slab packs in 2-3 ms, its forwards
     # take 4-5 ms: the host work of all slabs but the first disappears behind the device)
     predictions, failed = _predict_slabs(model, structures, r_cut, batch_size, config["data"]["tensor_target_name"],
-                                         config["data"]["tensor_target_formula"])
+                                         config["data"]["tensor_target_formula"], node_budget)
     if not predictions:
         raise RuntimeError("Cannot successfully convert any structures.")
     if is_elasticity_tensor:

@@ -805,6 +805,7 @@ def test_predict_packs_in_slabs_behind_the_device(monkeypatch):
         W.simplefilter("always")
         one = P.predict(structs, model=model, config=cfg, batch_size=2)
     monkeypatch.setattr(P, "PREDICT_SLAB", 3)
+    monkeypatch.setattr(P, "PREDICT_SLAB_GROWTH", 1)     # (slabs of exactly 3: the ramp from a small first slab is switched off)
     with W.catch_warnings(record=True) as w3:
         W.simplefilter("always")
         three = P.predict(structs, model=model, config=cfg, batch_size=2)
@@ -819,9 +820,33 @@ def test_predict_packs_in_slabs_behind_the_device(monkeypatch):
         for i in holes:
             assert f"structure {i}," in text, (i, text)
         assert f"{holes}" in text
+    monkeypatch.setattr(P, "PREDICT_SLAB_GROWTH", 4)     # slabs of 3, 12: the default ramp
+    with W.catch_warnings(record=True):
+        W.simplefilter("always")
+        ramped = P.predict(structs, model=model, config=cfg, batch_size=2)
+    assert [i for i, t in enumerate(ramped) if t is None] == holes
+    assert all(np.abs(np.asarray(ramped[i]) - np.asarray(one[i])).max() <= 2e-6 * np.abs(np.asarray(one[i])).max()
+               for i in range(len(structs)) if i not in holes)
     bad_species = dict(good[0], atomic_numbers=np.full(64, 8))
     with pytest.raises(RuntimeError, match="structure 4. It contains species 8 not supported"):
         P.predict(structs[:4] + [bad_species], model=model, config=cfg)
+
+
+def _assert_emitted_csr(batch):
+    """SURVEY 8(f)-1, last clause: the device search emits the destination-sorted CSR itself (private keys of the batch
+    dict); it must be, bit for bit, what matten_csr_build derives from the finished edge list -- which in turn is pinned to
+    torch.sort(stable=True) -- and the keys are popped so that the dict compares equal to the oracle's collate."""
+    from matten_amd import ops
+    from matten_amd.data._key import AMD_PERM, AMD_ROWPTR, AMD_SRC
+
+    perm, rowptr, src = batch.pop(AMD_PERM), batch.pop(AMD_ROWPTR), batch.pop(AMD_SRC)
+    n = batch["pos"].shape[0]
+    perm2, rowptr2, src2, err = ops.csr_build(batch["edge_index"], n)
+    assert int(err.item()) == 0
+    assert perm.dtype == rowptr.dtype == src.dtype == torch.int32
+    assert torch.equal(rowptr, rowptr2) and torch.equal(perm, perm2) and torch.equal(src, src2)
+    order = torch.sort(batch["edge_index"][1], stable=True).indices
+    assert torch.equal(perm.long(), order) and torch.equal(src.long(), batch["edge_index"][0][order])
 
 
 def test_gpu_neighbor_list_is_identical_to_oracle_builder(golden_dir):
@@ -839,6 +864,7 @@ def test_gpu_neighbor_list_is_identical_to_oracle_builder(golden_dir):
     triples = [(s["cart_coords"], s["lattice"], s["atomic_numbers"]) for s in structs]
     got = batch_graphs_gpu(triples, 5.0, DEV)
     want = rdata.collate([rdata.crystal_graph(s["cart_coords"], s["lattice"], s["atomic_numbers"], 5.0) for s in structs])
+    _assert_emitted_csr(got)
     assert set(got) == set(want)
     for k in want:
         g = got[k].cpu()
@@ -877,6 +903,7 @@ def test_gpu_neighbor_list_on_random_cells():
             triples.append((frac @ cell, cell, rng.integers(1, 90, n)))
         got = batch_graphs_gpu(triples, r_cut, DEV)
         want = rdata.collate([rdata.crystal_graph(p, c, z, r_cut) for p, c, z in triples])
+        _assert_emitted_csr(got)
         for k in ("edge_index", "edge_cell_shift", "num_neigh", "batch", "ptr", "pos", "cell"):
             assert torch.equal(got[k].cpu(), want[k]), (r_cut, k)
 
@@ -1118,8 +1145,9 @@ def test_neighbor_list_slabs_match_single_launch(monkeypatch):
     want = graph.batch_graphs_gpu(triples, 5.0, DEV)
     monkeypatch.setattr(graph, "_MAX_CRYSTALS_PER_LAUNCH", 3)
     got = graph.batch_graphs_gpu(triples, 5.0, DEV)
-    assert set(got) == set(want)
-    for k in want:
+    # (a single launch also emits its destination-sorted CSR as private keys; slabs leave it to the forward)
+    assert set(got) == {k for k in want if not k.startswith("_amd_")}
+    for k in got:
         assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), k
 
 

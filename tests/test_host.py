@@ -244,6 +244,14 @@ def test_predict_coalesces_user_batches_within_the_node_budget():
     big = np.concatenate([[0], np.cumsum(np.array([64] * 1000))])
     ch = coalesce_batches(big, 200, node_budget=10000)          # a user batch is 12800 atoms: above the budget, kept whole
     assert [len(c) for c in ch] == [200] * 5
+    from matten_amd.predict import NODE_BUDGET, effective_node_budget
+
+    # batch_size is the reference's memory knob (predict.py:155): lowered below its default of 200 nothing is merged; an
+    # explicit node_budget wins either way (advisor finding of round 4)
+    assert effective_node_budget(200) == NODE_BUDGET and effective_node_budget(1000) == NODE_BUDGET
+    assert effective_node_budget(50) == 0 and effective_node_budget(50, 4096) == 4096 and effective_node_budget(500, 0) == 0
+    ch = coalesce_batches(ptr, 50, node_budget=effective_node_budget(50))
+    assert all(len(c) <= 50 for c in ch) and np.array_equal(np.concatenate(ch), np.arange(len(ptr) - 1))
     ch = coalesce_batches(big, 7, node_budget=64 * 20)          # ragged tail
     assert (np.concatenate(ch) == np.arange(1000)).all() and max(len(c) for c in ch) <= 21
 

@@ -39,5 +39,13 @@ def run_fused(entries_np, label):
     print(f"fused {label:14s} entries {len(entries_np):2d} waves/tile {upt:3d} cols {cols:4d}  {dt*1e3:7.3f} ms", flush=True)
 
 run_fused(p.group_entries, "all")
-for kind in sorted(set(p.group_entries[:, 0])):
-    run_fused(p.group_entries[p.group_entries[:, 0] == kind], f"l1={kind // mplan.TP_KIND_STRIDE} g={kind % mplan.TP_KIND_STRIDE}")
+ge = p.group_entries
+for kind in sorted(set(int(k) for k in ge[:, 0] if k >= 0)):
+    sel = np.zeros(len(ge), dtype=bool)
+    for i in range(len(ge)):
+        if ge[i, 0] == kind:
+            sel[i] = True
+            if kind & mplan.TP_KIND_MERGED:
+                sel[i + 1] = True          # the continuation record of a merged entry travels with it
+    k = kind & (mplan.TP_KIND_MERGED - 1)
+    run_fused(ge[sel], f"l1={k // mplan.TP_KIND_STRIDE} g={k % mplan.TP_KIND_STRIDE}{'m' if kind & mplan.TP_KIND_MERGED else ''}")
