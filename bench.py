@@ -715,7 +715,8 @@ def run_rank(args):
         for m in convs:
             p = m.tp.plan
             # the row stride of the neighbour sums names the launch: component-major rows are padded (plan_agg_linear)
-            k = f"tp_scatter/d_mid={m.agg_plan.ld if getattr(m, 'agg_plan', None) is not None else p.d_mid}/d_in={p.d_in}"
+            km = getattr(m, "agg_plan", None) is not None and n_nodes >= pconv.AGG_KM_MIN_ROWS   # (small batches keep mul_ir rows)
+            k = f"tp_scatter/d_mid={m.agg_plan.ld if km else p.d_mid}/d_in={p.d_in}"
             kern = "tp_fused_kernel"
             rec = {"kernel": kern, "d_mid": p.d_mid, "weight_numel": p.weight_numel, "ms": per_kernel.get(k),
                    "algorithmic_bytes": contract_bytes(p, p.weight_numel, p.d_in, p.d_mid)}
@@ -723,7 +724,7 @@ def run_rank(args):
             # what THIS design has to move per launch (w[E, W] never exists): split hidden features 128 B + harmonics row
             # 128 B + source index 4 B per edge; row pointer 4 B, the input row once and the neighbour-sum row as laid
             # out (component-major, padded) per node; the layer's pre-split A fragments
-            ld_out = m.agg_plan.ld if getattr(m, "agg_plan", None) is not None else p.d_mid
+            ld_out = m.agg_plan.ld if km else p.d_mid
             rec["compulsory_bytes_fused_design"] = ((128.0 + 128.0 + 4.0) * n_edges + (4.0 + 4.0 * p.d_in + 4.0 * ld_out) * n_nodes
                                                     + 2.0 * 2 * 32 * 16 * p.fused_a_tiles)
             layers.append(rec)
@@ -816,7 +817,7 @@ def run_rank(args):
         # ---- matrix-core use of the radial MLP (the only GEMM of the path): hidden layers nb -> 32 -> 32 in
         # radial_hidden_kernel (fp32 MFMA), last layer 32 -> W inside the tensor-product kernels (three fp16-split products) ----
         rh_key = next((k for k in ("radial_hidden_multi", "radial_hidden") if k in per_kernel), None)
-        if layers and rh_key:
+        if layers and rh_key and any(r["ms"] for r in layers):
             nb = int(PAPER_HPARAMS.get("num_radial_basis", 8))
             # radial_hidden_multi evaluates the two hidden layers of ALL conv layers' MLPs in one launch
             n_mlps = n_layers if rh_key == "radial_hidden_multi" else 1

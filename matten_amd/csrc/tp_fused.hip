@@ -220,7 +220,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
     StoreAgg{}.store<G>(a, ge, acc, a_scale_inv, node, j, u, valid);   // (a_scale_inv undoes the power-of-two scale of the A tile)
 }
 
-#define MATTEN_RGS_ARGS a, ge, tile, stage, (um >> 8) & 0xffff, node, lane, valid, beg, deg, maxdeg, StoreAgg{}
+#define MATTEN_RGS_ARGS a, ge, tile, stage, (um >> 8) & 0xffff, tile_id, r, reps, lane, StoreAgg{}
 #define MATTEN_RGS(L1, GI, TT, TD, P) \
     do { \
         using HM = HotMask<L1, GI>; \
@@ -237,7 +237,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
         break;
 
 #define MATTEN_GROUP_CASE(L1, GI) \
-    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, node, lane, valid, beg, deg, maxdeg); break;
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, un.node, lane, un.valid, un.beg, un.deg, un.maxdeg); break;
 
 #ifndef TPF_MIN_BLOCKS
 #define TPF_MIN_BLOCKS 3
@@ -274,30 +274,16 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
     const GroupEntry& ge = entries[(um >> 8) & 0xffff];
     const int r = um & 255;
     const bool shared_stage = (um >> 24) & 1;  // uniform over the workgroup (host contract)
+    const int reps = 1 << ((um >> 27) & 3);    // persistent unit: node groups r, r + 1, ... (paired: r, r + 2, ...) in turn
 
     const int cu_log2 = ge.cu_log2;
-    const int cu = 1 << cu_log2;
     const int nodes_per_wave = 64 >> cu_log2;
-    const int g_in_tile = r * nodes_per_wave + (lane >> cu_log2);
-    const int u = lane & (cu - 1);
-    const int node = tile_id * TILE_NODES + g_in_tile;
-    const bool in_range = (g_in_tile < TILE_NODES) && (node < a.n_nodes);
-    const bool valid = in_range && (u < ge.mul);
-    int beg = 0, deg = 0;
-    if (in_range) {  // every lane of a node (also idle channels) knows the segment: the MFMA role needs it
-        beg = a.rowptr[node];
-        deg = a.rowptr[node + 1] - beg;
-    }
-    int maxdeg = deg;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
-    if constexpr (TPF_LAB_NO_LOOP) maxdeg = 0;  // timing build: prologue (segment, gather, fragment and stage set-up) + epilogue only
     if (shared_stage) {
         float* stage = lds + WAVES_PER_BLOCK * a.lds_per_wave;
         const bool paired = (um >> 26) & 1;   // uniform over the workgroup: two entries x two node groups (PairLoader)
         if ((um >> 25) & 1) {  // loader-only unit: fills the workgroup up to four waves
-            if (paired) run_loader_only_paired(a, cu_log2, stage, beg, deg, maxdeg);
-            else run_loader_only(a, cu_log2, stage, beg, deg, maxdeg);
+            if (paired) run_loader_only_paired(a, ge, stage, tile_id, r, reps, lane);
+            else run_loader_only(a, ge, stage, tile_id, r, reps, lane);
             return;
         }
         switch (ge.kind & (KIND_MERGED - 1)) {
@@ -306,6 +292,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
         }
         return;
     }
+    const UnitNodes un = unit_nodes(a, ge, tile_id, r, lane);
     switch (ge.kind & (KIND_MERGED - 1)) {
         TPF_FOR_EACH_GROUP(MATTEN_GROUP_CASE)
         default: break;

@@ -105,6 +105,12 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_SETPRIO
 #define TPF_SETPRIO 3
 #endif
+#ifndef TPF_EXACT_Y0
+#define TPF_EXACT_Y0 0
+#endif
+#ifndef TPF_REP_PREFETCH
+#define TPF_REP_PREFETCH 1   // persistent units: the next node group's loads go out in front of this group's agg stores
+#endif
 // weight columns ([u][coupling]) an entry may have: the plan caps an entry at the largest power-of-two channel count whose
 // block fits (plan.py TP_MAX_COLS, checked at load through matten_tp_max_cols); its MFMA A operand stays in registers
 #ifndef TPF_MAX_COLS
@@ -116,15 +122,6 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_MAX_COLS_L1
 #define TPF_MAX_COLS_L1 TPF_MAX_COLS   // vector (l1 = 1) input blocks; 7 couplings with l2 <= 2 (112 columns for 16 channels:
 #endif                                 // measured, spills), 5 with l2 = 3, 4 (80 columns)
-#ifndef TPF_BRANCH_FREE_STEPS
-#define TPF_BRANCH_FREE_STEPS 0
-#endif
-#ifndef TPF_EXACT_Y
-#define TPF_EXACT_Y 0
-#endif
-#ifndef TPF_PUBLISH_EARLY
-#define TPF_PUBLISH_EARLY 0
-#endif
 __host__ __device__ constexpr int cap_channels(int l1, int nc) {
     int cap = 64;
     while (cap > 1 && cap * nc > (l1 == 0 ? TPF_MAX_COLS_L0 : l1 == 1 ? TPF_MAX_COLS_L1 : TPF_MAX_COLS)) cap /= 2;
@@ -169,6 +166,47 @@ struct Args {
 #endif
 };
 
+
+// the destination nodes of a unit: node group r of its tile -> (node of this lane, does the lane contract, its CSR segment,
+// the longest segment of the wave).  Every lane of a node (idle channel lanes too) knows the segment: the MFMA role needs it.
+struct UnitNodes {
+    int node, beg, deg, maxdeg;
+    bool valid;
+};
+struct RawNodes {   // the same before its two row-pointer loads are consumed (a persistent unit requests its NEXT group's early)
+    int node, b0, b1;
+    bool valid;
+};
+__device__ __forceinline__ RawNodes unit_nodes_issue(const Args& a, const GroupEntry& ge, int tile_id, int r, int lane) {
+    const int cu_log2 = ge.cu_log2;
+    const int nodes_per_wave = 64 >> cu_log2;
+    const int g_in_tile = r * nodes_per_wave + (lane >> cu_log2);
+    const int u = lane & ((1 << cu_log2) - 1);
+    RawNodes n;
+    n.node = tile_id * TILE_NODES + g_in_tile;
+    const bool in_range = (g_in_tile < TILE_NODES) && (n.node < a.n_nodes);
+    n.valid = in_range && (u < ge.mul);
+    n.b0 = 0, n.b1 = 0;
+    if (in_range) {
+        n.b0 = a.rowptr[n.node];
+        n.b1 = a.rowptr[n.node + 1];
+    }
+    return n;
+}
+__device__ __forceinline__ UnitNodes unit_nodes_finish(const RawNodes& raw) {
+    UnitNodes n;
+    n.node = raw.node, n.valid = raw.valid, n.beg = raw.b0, n.deg = raw.b1 - raw.b0;
+    int maxdeg = n.deg;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+    if constexpr (TPF_LAB_NO_LOOP) maxdeg = 0;  // timing build: prologue (segment, gather, fragment and stage set-up) + epilogue only
+    n.maxdeg = maxdeg;
+    return n;
+}
+__device__ __forceinline__ UnitNodes unit_nodes(const Args& a, const GroupEntry& ge, int tile_id, int r, int lane) {
+    return unit_nodes_finish(unit_nodes_issue(a, ge, tile_id, r, lane));
+}
+
 // ---- workgroup-shared staging (units flagged by the host, plan.fused_unit_map) --------------------------------------
 // When the four waves of a workgroup contract four entries of the SAME destination nodes (equal lanes per node, one or
 // two 16-edge MFMA tiles per chunk) they need the same hidden-feature and harmonics rows.  Each of the 256 threads then
@@ -199,40 +237,6 @@ __device__ __forceinline__ void mfma_tiles(const f16x8* __restrict__ ah, const f
     for (int mt = 0; mt < MTC; ++mt) *reinterpret_cast<f32x4*>(trow + mt * 16) = dh[mt] + SPLIT_LO_INV * dx[mt];
 }
 
-
-// y[0..NY) = the staged row's harmonics [Y0, Y0 + NY): 16-byte reads over the aligned middle, 4- / 8-byte reads at the ragged
-// ends -- exactly NY registers.  (Whole quads over the covering range left 3-4 dead registers per step that the allocator
-// reused for the weights: a write-after-read on a load still in flight, i.e. a second LDS round trip per edge step.)
-template <int Y0, int NY>
-__device__ __forceinline__ void read_harmonics(const float* __restrict__ row, float (&y)[NY]) {
-    constexpr int A = (Y0 + 3) / 4 * 4;                 // first 16-byte aligned column at or after Y0
-    constexpr int B = (Y0 + NY) / 4 * 4;                // end of the aligned middle
-    if constexpr (A >= B) {
-#pragma unroll
-        for (int j = 0; j < NY; ++j) y[j] = row[Y0 + j];
-    } else {
-        constexpr int HEAD = A - Y0, TAIL = Y0 + NY - B;
-        if constexpr (HEAD == 1) y[0] = row[Y0];
-        if constexpr (HEAD == 2) { const float2 v = *reinterpret_cast<const float2*>(row + Y0); y[0] = v.x, y[1] = v.y; }
-        if constexpr (HEAD == 3) {
-            y[0] = row[Y0];
-            const float2 v = *reinterpret_cast<const float2*>(row + Y0 + 1);
-            y[1] = v.x, y[2] = v.y;
-        }
-#pragma unroll
-        for (int q = A; q < B; q += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(row + q);
-            y[q - Y0] = v[0], y[q - Y0 + 1] = v[1], y[q - Y0 + 2] = v[2], y[q - Y0 + 3] = v[3];
-        }
-        if constexpr (TAIL == 1) y[NY - 1] = row[B];
-        if constexpr (TAIL == 2) { const float2 v = *reinterpret_cast<const float2*>(row + B); y[NY - 2] = v.x, y[NY - 1] = v.y; }
-        if constexpr (TAIL == 3) {
-            const float2 v = *reinterpret_cast<const float2*>(row + B);
-            y[NY - 3] = v.x, y[NY - 2] = v.y;
-            y[NY - 1] = row[B + 2];
-        }
-    }
-}
 
 // loader role of a thread: (edge row of the chunk, 16-byte piece of the row) per MFMA tile; fixed for the whole walk
 template <int TT>  // MFMA tiles (16 edge rows) per chunk: a compile-time count keeps every load of the loop unconditional
@@ -338,42 +342,48 @@ struct PairLoader {
     }
 };
 
-// loader-only unit of a paired workgroup
-__device__ __forceinline__ void run_loader_only_paired(const Args& a, int cu_log2, float* __restrict__ stage, int beg,
-                                                       int deg_node, int maxdeg) {
-    PairLoader ld;
-    ld.init(a, stage, reinterpret_cast<int*>(stage + STAGE_TOTAL_FLOATS), cu_log2, beg, deg_node, maxdeg);
-    ld.issue(0);
-    ld.publish(0);
-    __syncthreads();
-    int buf = 0;
-    for (int s0 = 0; s0 < ld.maxdeg; s0 += ld.CH, buf ^= 1) {
-        ld.issue(s0 + ld.CH);
-        ld.publish(buf ^ 1);
+// loader-only unit of a paired workgroup (same barrier sequence as run_group_shared<PAIRED>, node group after node group)
+__device__ __forceinline__ void run_loader_only_paired(const Args& a, const GroupEntry& ge, float* __restrict__ stage,
+                                                       int tile_id, int r0, int reps, int lane) {
+    for (int rep = 0; rep < reps; ++rep) {
+        const UnitNodes un = unit_nodes(a, ge, tile_id, r0 + 2 * rep, lane);
+        PairLoader ld;
+        ld.init(a, stage, reinterpret_cast<int*>(stage + STAGE_TOTAL_FLOATS), ge.cu_log2, un.beg, un.deg, un.maxdeg);
+        ld.issue(0);
+        ld.publish(0);
         __syncthreads();
+        int buf = 0;
+        for (int s0 = 0; s0 < ld.maxdeg; s0 += ld.CH, buf ^= 1) {
+            ld.issue(s0 + ld.CH);
+            ld.publish(buf ^ 1);
+            __syncthreads();
+        }
     }
 }
 
 // a unit that only feeds the stage (same barrier sequence as run_group_shared)
 template <int TT>
-__device__ __forceinline__ void run_loader_only_t(const Args& a, int cu_log2, float* __restrict__ stage, int beg,
-                                                  int deg_node, int maxdeg) {
-    StageLoader<TT> ld;
-    ld.init(a, stage, cu_log2, beg, deg_node);
-    ld.issue(0);
-    ld.publish(0);
-    __syncthreads();
-    int buf = 0;
-    for (int s0 = 0; s0 < maxdeg; s0 += ld.CH, buf ^= 1) {
-        ld.issue(s0 + ld.CH);
-        ld.publish(buf ^ 1);
+__device__ __forceinline__ void run_loader_only_t(const Args& a, const GroupEntry& ge, float* __restrict__ stage, int tile_id,
+                                                  int r0, int reps, int lane) {
+    for (int rep = 0; rep < reps; ++rep) {
+        const UnitNodes un = unit_nodes(a, ge, tile_id, r0 + rep, lane);
+        StageLoader<TT> ld;
+        ld.init(a, stage, ge.cu_log2, un.beg, un.deg);
+        ld.issue(0);
+        ld.publish(0);
         __syncthreads();
+        int buf = 0;
+        for (int s0 = 0; s0 < un.maxdeg; s0 += ld.CH, buf ^= 1) {
+            ld.issue(s0 + ld.CH);
+            ld.publish(buf ^ 1);
+            __syncthreads();
+        }
     }
 }
-__device__ __forceinline__ void run_loader_only(const Args& a, int cu_log2, float* __restrict__ stage, int beg, int deg_node,
-                                                int maxdeg) {
-    if ((64 >> cu_log2) > 16) run_loader_only_t<2>(a, cu_log2, stage, beg, deg_node, maxdeg);
-    else run_loader_only_t<1>(a, cu_log2, stage, beg, deg_node, maxdeg);
+__device__ __forceinline__ void run_loader_only(const Args& a, const GroupEntry& ge, float* __restrict__ stage, int tile_id,
+                                                int r0, int reps, int lane) {
+    if ((64 >> ge.cu_log2) > 16) run_loader_only_t<2>(a, ge, stage, tile_id, r0, reps, lane);
+    else run_loader_only_t<1>(a, ge, stage, tile_id, r0, reps, lane);
 }
 
 // the kinds with registers to spare for a second neighbour row in flight (two-slot chunks: 8 lanes per node)
@@ -384,23 +394,23 @@ struct TwoDeepOk { static constexpr bool value = L1 == 0 || (L1 == 1 && GI == 0)
 // reconciled their register assignments with 50-90 v_mov per CHUNK (60 % of the l1 = 0 kind's vector instructions).
 // CMASK != 0: the entry's coupling mask as a compile-time constant (HotMask below); the couplings of a step then form
 // one basic block instead of NC uniformly-branched ones
+// PERSISTENT units: a wave walks `reps` node groups of its tile one after the other (r0, r0 + 1, ...; paired workgroups:
+// r0, r0 + 2, ...) -- the A fragments are fetched once, and the agg stores of one node group drain behind the walk of the
+// next instead of holding the wave's slot until they are acknowledged (s_endpgm waits for them: 9-13 % of a wave's life,
+// tools/tp_trace.py).  The host picks reps per lanes-per-node class (plan.fused_unit_map).
 template <int L1, int GI, int TT, bool TWO_DEEP, bool PAIRED, unsigned CMASK, class Epilogue>
 __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry& ge, float* __restrict__ tile,
-                                                 float* __restrict__ stage, int entry, int node, int lane, bool valid,
-                                                 int beg, int deg_node, int maxdeg, const Epilogue& epi) {
+                                                 float* __restrict__ stage, int entry, int tile_id, int r0, int reps, int lane,
+                                                 const Epilogue& epi) {
     static_assert(!PAIRED || TT == 1, "paired workgroups stage 2 x 16 rows");
 #if TPF_TRACING
-    const unsigned long long tr_in = tpf_stamp();
-    unsigned tr_mfma = 0, tr_con = 0, tr_pub = 0, tr_bar = 0, tr_chunks = 0;
+    const unsigned long long tr_in = tpf_stamp();     // (covers every node group of a persistent unit)
+    unsigned tr_mfma = 0, tr_con = 0, tr_pub = 0, tr_bar = 0, tr_chunks = 0, tr_pro = 0, tr_epi = 0;
 #endif
     const int row0 = PAIRED ? 16 * (int)(threadIdx.x >> 7) : 0;       // this wave's half of a paired stage
     constexpr int STAGE_BUF = (PAIRED ? 32 : 16 * TT) * STAGE_ROW;    // floats per stage buffer
-    const int deg = valid ? deg_node : 0;
     using G = matten::Group<L1, GI>;
     constexpr int NC = G::NC;
-    float acc[G::NACC];
-#pragma unroll
-    for (int k = 0; k < G::NACC; ++k) acc[k] = 0.0f;
 
     const unsigned mask = ge.mask;
     const int cu_log2 = ge.cu_log2;              // >= 1 here: at most 32 nodes per wave
@@ -463,27 +473,35 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         }
     }
 
+    // Per node group: (i) start_group -- everything of the group's prologue that is a LOAD (segment bounds, the first chunk's
+    // stage rows, the first neighbour rows) -- and (ii) the walk + the agg stores.  A persistent unit runs (i) of group
+    // rep + 1 BEFORE the stores of group rep: vector-memory operations retire in order, so loads issued behind ~100 stores
+    // would wait for every store's acknowledgement, while loads issued in front of them land under the stores' shadow.
+    // The row pointers of group rep + 1 are requested at the top of group rep's walk.
     typename std::conditional<PAIRED, PairLoader, StageLoader<TT>>::type ld;
-    if constexpr (PAIRED) {
-        ld.init(a, stage, reinterpret_cast<int*>(stage + STAGE_TOTAL_FLOATS), cu_log2, beg, deg_node, maxdeg);
-        maxdeg = ld.maxdeg;   // both node groups walk the same number of chunks (one barrier sequence)
-    } else {
-        ld.init(a, stage, cu_log2, beg, deg_node);
-    }
-    ld.issue(0);
-
-    // Neighbour gather.  Two-slot chunks (8 nodes per wave: short steps) keep TWO rows in flight, one per slot of the
-    // chunk: a row is refilled right after its contraction with the edge two steps on, so a gather has a whole step,
-    // the stage hand-over and the next MFMA phase to land, and nothing is copied.  Other chunk shapes (long steps) keep
-    // the one-step-ahead pipeline: source index two edges ahead, row one edge ahead.  All loads are unconditional on a
-    // clamped edge index.
-    const int e_last = deg > 0 ? beg + deg - 1 : 0;
-    // (compiled in only for the kinds with registers to spare: the second row buffer costs the heavy kinds spills)
     static_assert(!TWO_DEEP || TwoDeepOk<L1, GI>::value, "two rows in flight only for the light kinds");
     constexpr bool two_deep = TWO_DEEP;   // the caller guarantees CH == 2 (8 lanes per node)
+    int node, beg, deg, maxdeg, e_last;
+    bool valid;
     float xn[G::D1], xb[G::D1];
     int src_nn, src_b = 0;
-    {
+    auto start_group = [&](const UnitNodes& un) {
+        node = un.node, beg = un.beg, valid = un.valid, maxdeg = un.maxdeg;
+        deg = valid ? un.deg : 0;
+        if constexpr (PAIRED) {
+            ld.init(a, stage, reinterpret_cast<int*>(stage + STAGE_TOTAL_FLOATS), cu_log2, un.beg, un.deg, un.maxdeg);
+            maxdeg = ld.maxdeg;   // both node groups walk the same number of chunks (one barrier sequence)
+        } else {
+            ld.init(a, stage, cu_log2, un.beg, un.deg);
+        }
+        ld.issue(0);
+        // Neighbour gather.  Two-slot chunks (8 nodes per wave: short steps) keep TWO rows in flight, one per slot of the
+        // chunk: a row is refilled right after its contraction with the edge two steps on, so a gather has a whole step,
+        // the stage hand-over and the next MFMA phase to land, and nothing is copied.  Other chunk shapes (long steps) keep
+        // the one-step-ahead pipeline: source index two edges ahead, row one edge ahead.  All loads are unconditional on a
+        // clamped edge index.
+        // (the second row buffer is compiled in only for the kinds with registers to spare: it costs the heavy kinds spills)
+        e_last = deg > 0 ? beg + deg - 1 : 0;
         const int src0 = a.src_sorted[min(beg, e_last)];
         const int src1 = a.src_sorted[min(beg + 1, e_last)];
         const float* xp0 = a.x + (int64_t)src0 * a.d_in + xcol;
@@ -497,12 +515,24 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             src_nn = a.src_sorted[min(beg + 2, e_last)];
             src_b = a.src_sorted[min(beg + 3, e_last)];
         }
-    }
+    };
+    constexpr int RSTEP = PAIRED ? 2 : 1;
+    start_group(unit_nodes(a, ge, tile_id, r0, lane));
+    for (int rep = 0; rep < reps; ++rep) {
+#if TPF_TRACING
+    const unsigned long long tr_rep = rep == 0 ? tr_in : tpf_stamp();
+#endif
+    const bool more = rep + 1 < reps;
+    const RawNodes raw_next = unit_nodes_issue(a, ge, tile_id, r0 + RSTEP * (rep + (more ? 1 : 0)), lane);
+    float acc[G::NACC];
+#pragma unroll
+    for (int k = 0; k < G::NACC; ++k) acc[k] = 0.0f;
     ld.publish(0);
     __syncthreads();
 #if TPF_TRACING
     const unsigned long long tr_loop = tpf_stamp();
     unsigned long long tr_a = tr_loop;
+    tr_pro += (unsigned)(tr_loop - tr_rep);
 #endif
     int buf = 0;
     for (int s0 = 0; s0 < maxdeg; s0 += CH, buf ^= 1) {
@@ -539,11 +569,19 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 #endif
         auto contract = [&](int so, const float* __restrict__ x) {
             const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
+            const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
             float y[G::NY], w[NC];
-            if constexpr (TPF_EXACT_Y) {
-                read_harmonics<G::Y0, G::NY>(sb + ((j << ch_log2) + so) * STAGE_ROW + 32, y);
-            } else {   // the harmonics of a staged row are 16-byte aligned: whole ds_read_b128 over [Y0, Y0 + NY)
-                const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
+            if constexpr (TPF_EXACT_Y0 && L1 == 0 && G::Y0 == 0 && G::NY % 4 == 1) {
+                // scalar blocks: NY = 25 = six quads + one float read on its own -- whole quads leave three dead registers
+                // that the allocator reuses for the weights: a write-after-read on a load in flight, a second LDS round trip
+                y[G::NY - 1] = yp[G::NY - 1];
+#pragma unroll
+                for (int q = 0; q < G::NY / 4; ++q) {
+                    const f32x4 v = reinterpret_cast<const f32x4*>(yp)[q];
+                    y[4 * q] = v[0], y[4 * q + 1] = v[1], y[4 * q + 2] = v[2], y[4 * q + 3] = v[3];
+                }
+            } else
+            {   // the harmonics of a staged row are 16-byte aligned: whole ds_read_b128 over [Y0, Y0 + NY)
                 constexpr int Q0 = G::Y0 / 4 * 4, NQ = (G::Y0 + G::NY - Q0 + 3) / 4;
                 float yq[4 * NQ];
                 const f32x4* y4 = reinterpret_cast<const f32x4*>(yp - (G::Y0 - Q0));
@@ -560,84 +598,23 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             G::apply(CMASK ? CMASK : mask, x, y, w, acc);
         };
         if constexpr (TPF_LAB_NO_VALU) {
-        } else if (two_deep && TPF_BRANCH_FREE_STEPS) {
-            // Branch-free slot pairs.  A step of a light kind is ~30-200 vector instructions behind ~8 LDS reads (harmonics
-            // row, weights): inside `if (s < deg)` regions the reads of step s + 1 cannot start before step s has finished
-            // and every step pays the LDS round trip (the l1 = 0 kind: 735 cycles per step for 30 instructions,
-            // tools/tp_trace.py).  Here the reads are unconditional (every slot of a chunk has a staged row: past the end of
-            // a segment its last edge again) and double-buffered one slot ahead; a slot past the segment's end contracts
-            // x = 0 instead of being skipped (w, Y finite: + 0 to every accumulator).
-            auto fetch = [&](int so, float (&y)[G::NY], float (&w)[NC]) {
-                const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
-                const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
-                constexpr int Q0 = G::Y0 / 4 * 4, NQ = (G::Y0 + G::NY - Q0 + 3) / 4;
-                float yq[4 * NQ];
-                const f32x4* y4 = reinterpret_cast<const f32x4*>(yp - (G::Y0 - Q0));
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const f32x4 v = y4[q];
-                    yq[4 * q] = v[0], yq[4 * q + 1] = v[1], yq[4 * q + 2] = v[2], yq[4 * q + 3] = v[3];
-                }
-#pragma unroll
-                for (int jj = 0; jj < G::NY; ++jj) y[jj] = yq[G::Y0 - Q0 + jj];
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
-            };
-            auto step = [&](bool on, const float (&x)[G::D1], const float (&y)[G::NY], const float (&w)[NC]) {
-                float xe[G::D1];
-#pragma unroll
-                for (int i = 0; i < G::D1; ++i) xe[i] = on ? x[i] : 0.0f;
-                G::apply(CMASK ? CMASK : mask, xe, y, w, acc);
-            };
-            float ya[G::NY], wa[NC], yb[G::NY], wb[NC];
-            fetch(0, ya, wa);
+        } else if (two_deep) {
             for (int so = 0; so < CH; so += 2) {   // CH is 2, 4 or 8 here: slot pairs, one row buffer per parity
                 const int s = s0 + so;
-                fetch(so + 1, yb, wb);
-                step(s < deg, xn, ya, wa);
+                if (s < deg) contract(so, xn);
                 {
                     const float* xp = a.x + (int64_t)TPF_SRC(src_nn) * a.d_in + xcol;
 #pragma unroll
                     for (int i = 0; i < G::D1; ++i) xn[i] = TPF_XLD(xp, i, src_nn);
                     src_nn = a.src_sorted[min(beg + s + 4, e_last)];
                 }
-                fetch(min(so + 2, CH - 1), ya, wa);     // (the last pair re-reads its own slot: never used)
-                step(s + 1 < deg, xb, yb, wb);
+                if (s + 1 < deg) contract(so + 1, xb);
                 {
                     const float* xp = a.x + (int64_t)TPF_SRC(src_b) * a.d_in + xcol;
 #pragma unroll
                     for (int i = 0; i < G::D1; ++i) xb[i] = TPF_XLD(xp, i, src_b);
                     src_b = a.src_sorted[min(beg + s + 5, e_last)];
                 }
-            }
-        } else if (two_deep) {
-            auto refill_n = [&](int s) {
-                const float* xp = a.x + (int64_t)TPF_SRC(src_nn) * a.d_in + xcol;
-#pragma unroll
-                for (int i = 0; i < G::D1; ++i) xn[i] = TPF_XLD(xp, i, src_nn);
-                src_nn = a.src_sorted[min(beg + s + 4, e_last)];
-            };
-            auto refill_b = [&](int s) {
-                const float* xp = a.x + (int64_t)TPF_SRC(src_b) * a.d_in + xcol;
-#pragma unroll
-                for (int i = 0; i < G::D1; ++i) xb[i] = TPF_XLD(xp, i, src_b);
-                src_b = a.src_sorted[min(beg + s + 5, e_last)];
-            };
-            for (int so = 0; so < CH; so += 2) {   // CH is 2, 4 or 8 here: slot pairs, one row buffer per parity
-                const int s = s0 + so;
-                const bool last = TPF_PUBLISH_EARLY && so + 2 >= CH;
-                if (s < deg) contract(so, xn);
-                if (!last) refill_n(s);
-                if (s + 1 < deg) contract(so + 1, xb);
-                if (!last) refill_b(s);
-            }
-            if (TPF_PUBLISH_EARLY) {
-                // the stage rows requested at the top of the chunk go to LDS BEFORE the chunk's last gathers are issued: the
-                // publish waits on the vector-memory counter, which retires in order -- behind freshly issued gathers it
-                // waited for THEIR round trip too (400-500 cycles per chunk of the l1 <= 1 kinds, tools/tp_trace.py)
-                ld.publish(buf ^ 1);
-                refill_n(s0 + CH - 2);
-                refill_b(s0 + CH - 2);
             }
         } else {
             for (int so = 0; so < CH; ++so) {
@@ -658,7 +635,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 #if TPF_TRACING
         const unsigned long long tr_c = tpf_stamp_after(acc);
 #endif
-        if (!(two_deep && TPF_PUBLISH_EARLY && !TPF_BRANCH_FREE_STEPS)) ld.publish(buf ^ 1);
+        ld.publish(buf ^ 1);
 #if TPF_TRACING
         const unsigned long long tr_d = tpf_stamp();
 #endif
@@ -678,18 +655,27 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 #if TPF_TRACING
     const unsigned long long tr_end = tpf_stamp();
 #endif
-    epi.template store<G>(a, ge, acc, a_scale_inv, node, j, u, valid);
+    const int node_done = node;
+    const bool valid_done = valid;
+    if (TPF_REP_PREFETCH && more) start_group(unit_nodes_finish(raw_next));
+    epi.template store<G>(a, ge, acc, a_scale_inv, node_done, j, u, valid_done);
+    if (!TPF_REP_PREFETCH && more) start_group(unit_nodes_finish(raw_next));
 #if TPF_TRACING
     if (a.trace && lane == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the LAST node group's stores are waited for (as s_endpgm does); the earlier ones drain behind the next group's walk
+        if (rep + 1 == reps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long tr_out = tpf_stamp();
-        unsigned* tr = a.trace + ((size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 16;
-        tr[0] = 1u, tr[1] = (unsigned)ge.kind, tr[2] = (unsigned)cu_log2 | (PAIRED ? 256u : 0u) | ((unsigned)TT << 12) | ((unsigned)MT << 16);
-        tr[3] = tr_chunks, tr[4] = (unsigned)(tr_loop - tr_in), tr[5] = tr_mfma, tr[6] = tr_con, tr[7] = tr_pub, tr[8] = tr_bar;
-        tr[9] = (unsigned)(tr_out - tr_end), tr[10] = (unsigned)(tr_out - tr_in), tr[11] = (unsigned)ge.mask;
-        tr[12] = (unsigned)(tr_in & 0xffffffffu), tr[13] = (unsigned)(tr_in >> 32);
+        tr_epi += (unsigned)(tr_out - tr_end);
+        if (rep + 1 == reps) {
+            unsigned* tr = a.trace + ((size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 16;
+            tr[0] = 1u, tr[1] = (unsigned)ge.kind, tr[2] = (unsigned)cu_log2 | (PAIRED ? 256u : 0u) | ((unsigned)reps << 9) | ((unsigned)TT << 12) | ((unsigned)MT << 16);
+            tr[3] = tr_chunks, tr[4] = tr_pro, tr[5] = tr_mfma, tr[6] = tr_con, tr[7] = tr_pub, tr[8] = tr_bar;
+            tr[9] = tr_epi, tr[10] = (unsigned)(tr_out - tr_in), tr[11] = (unsigned)ge.mask;
+            tr[12] = (unsigned)(tr_in & 0xffffffffu), tr[13] = (unsigned)(tr_in >> 32);
+        }
     }
 #endif
+    }   // rep
 }
 
 // Coupling masks worth a specialisation: only the scalar-block kind (all five couplings, or l2 <= 3 when the target has

@@ -53,6 +53,27 @@ TP_MERGE = os.environ.get("MATTEN_TP_MERGE", "1") != "0"
 FUSED_UNIT_SHARED = 1 << 24       # the unit's workgroup stages hidden features / harmonics once for its four waves
 FUSED_UNIT_LOADER_ONLY = 1 << 25  # padding unit of a shared workgroup: feeds the stage, contracts nothing
 FUSED_UNIT_PAIRED = 1 << 26       # shared workgroup of TWO entries on TWO consecutive node groups (waves 0,1 | 2,3)
+FUSED_UNIT_REPS_SHIFT = 27        # bits 27-28: log2 of the node groups a PERSISTENT unit walks one after the other
+
+
+def fused_persist(cu_log2: int, groups: int, mode: str) -> int:
+    """node groups a unit of this lanes-per-node class walks in turn (a power of two dividing its groups per tile; paired
+    workgroups advance two groups at a time).  MATTEN_TP_PERSIST = "lanes:reps,..." (lanes per node: 2, 4, 8, 16, 32)
+    overrides the defaults."""
+    spec = os.environ.get("MATTEN_TP_PERSIST", TP_PERSIST_DEFAULT)
+    want = 1
+    for item in filter(None, spec.split(",")):
+        lanes, reps = item.split(":")
+        if int(lanes) == (1 << cu_log2):
+            want = int(reps)
+    avail = groups // 2 if mode == "paired" else groups
+    reps = 1
+    while reps * 2 <= min(want, 8) and avail % (reps * 2) == 0:
+        reps *= 2
+    return reps
+
+
+TP_PERSIST_DEFAULT = "16:4,8:2"   # measured (tools/ab_env.sh, round 5): -2.3 % per forward; 4- and 2-lane classes: no gain
 
 
 def fused_workgroups(group_entries, order: Optional[str] = None):
@@ -103,14 +124,16 @@ def fused_unit_map(group_entries, order: Optional[str] = None) -> np.ndarray:
     for cu_log2, blk, mode in fused_workgroups(ent, order):
         groups = -(-TP_TILE_NODES // max(1, 64 >> cu_log2))
         assert groups < 256
+        reps = fused_persist(cu_log2, groups, mode) if mode in ("shared", "paired") else 1
+        rbits = (reps.bit_length() - 1) << FUSED_UNIT_REPS_SHIFT
         if mode == "shared":
-            for r in range(groups):
-                shared_units += [FUSED_UNIT_SHARED | (e << 8) | r for e in blk]
-                shared_units += [FUSED_UNIT_SHARED | FUSED_UNIT_LOADER_ONLY | (blk[-1] << 8) | r] * (4 - len(blk))
+            for r in range(0, groups, reps):
+                shared_units += [FUSED_UNIT_SHARED | rbits | (e << 8) | r for e in blk]
+                shared_units += [FUSED_UNIT_SHARED | FUSED_UNIT_LOADER_ONLY | rbits | (blk[-1] << 8) | r] * (4 - len(blk))
         elif mode == "paired":
             assert groups % 2 == 0 and 1 <= len(blk) <= 2
-            flags = FUSED_UNIT_SHARED | FUSED_UNIT_PAIRED
-            for r in range(0, groups, 2):
+            flags = FUSED_UNIT_SHARED | FUSED_UNIT_PAIRED | rbits
+            for r in range(0, groups, 2 * reps):
                 for rr in (r, r + 1):
                     shared_units += [flags | (e << 8) | rr for e in blk]
                     shared_units += [flags | FUSED_UNIT_LOADER_ONLY | (blk[-1] << 8) | rr] * (2 - len(blk))

@@ -361,11 +361,19 @@ def test_fused_unit_map_covers_every_entry_and_node_group_once():
     from matten_amd import plan as mp
     from matten_amd.o3 import Irreps
 
-    for irr in ("32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e", "16x0e", "3x0e+5x1o+1x2e", "64x0e+1x1o+7x2e+2x4e"):
+    cases = [(irr, spec) for irr in ("32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e", "16x0e", "3x0e+5x1o+1x2e",
+                                     "64x0e+1x1o+7x2e+2x4e") for spec in ("", "16:4,8:2,4:2,2:2", "16:8,8:8,4:8,2:8")]
+    for irr, spec in cases:
+        os.environ["MATTEN_TP_PERSIST"] = spec
         p = mp.plan_uvu(irr, Irreps.spherical_harmonics(4), irr)
+        os.environ.pop("MATTEN_TP_PERSIST")
         for order in ("node", "entry"):
+            os.environ["MATTEN_TP_PERSIST"] = spec
             m = mp.fused_unit_map(p.group_entries, order)
-            work = [(int(v) >> 8 & 0xFFFF, int(v) & 255) for v in m if not int(v) & mp.FUSED_UNIT_LOADER_ONLY]
+            work = []
+            for v in (int(v) for v in m if not int(v) & mp.FUSED_UNIT_LOADER_ONLY):
+                reps, step = 1 << ((v >> mp.FUSED_UNIT_REPS_SHIFT) & 3), 2 if v & mp.FUSED_UNIT_PAIRED else 1
+                work += [((v >> 8) & 0xFFFF, (v & 255) + step * k) for k in range(reps)]   # a persistent unit: its groups in turn
             want = set()
             for e, row in enumerate(p.group_entries):
                 if int(row[0]) < 0:
@@ -390,6 +398,8 @@ def test_fused_unit_map_covers_every_entry_and_node_group_once():
                 assert len({int(p.group_entries[v >> 8 & 0xFFFF][3]) for v in blk}) == 1
                 assert int(p.group_entries[blk[0] >> 8 & 0xFFFF][3]) >= 1
                 assert not blk[0] & mp.FUSED_UNIT_LOADER_ONLY
+                assert len({(v >> mp.FUSED_UNIT_REPS_SHIFT) & 3 for v in blk}) == 1   # one barrier sequence per workgroup
+    os.environ.pop("MATTEN_TP_PERSIST", None)
 
 
 def test_split_a_tiles_reconstructs_the_last_radial_layer():

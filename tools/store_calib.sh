@@ -30,7 +30,7 @@ for d in sorted(glob.glob(O + "/pmc_*/")):
         extra = ""
         if base and c in ("WRITE_SIZE", "FETCH_SIZE"):
             extra = f"  = {val * 1024 / base:6.3f} x known bytes (counter in KB)"
-        elif base:
+        elif base and val:
             extra = f"  -> {base / val:8.1f} known bytes per count"
         print(f"{name:24s} {c:26s} {val:16.0f}{extra}")
 PY
