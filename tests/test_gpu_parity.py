@@ -805,7 +805,6 @@ def test_predict_packs_in_slabs_behind_the_device(monkeypatch):
         W.simplefilter("always")
         one = P.predict(structs, model=model, config=cfg, batch_size=2)
     monkeypatch.setattr(P, "PREDICT_SLAB", 3)
-    monkeypatch.setattr(P, "PREDICT_SLAB_GROWTH", 1)     # (slabs of exactly 3: the ramp from a small first slab is switched off)
     with W.catch_warnings(record=True) as w3:
         W.simplefilter("always")
         three = P.predict(structs, model=model, config=cfg, batch_size=2)
@@ -820,13 +819,6 @@ def test_predict_packs_in_slabs_behind_the_device(monkeypatch):
         for i in holes:
             assert f"structure {i}," in text, (i, text)
         assert f"{holes}" in text
-    monkeypatch.setattr(P, "PREDICT_SLAB_GROWTH", 4)     # slabs of 3, 12: the default ramp
-    with W.catch_warnings(record=True):
-        W.simplefilter("always")
-        ramped = P.predict(structs, model=model, config=cfg, batch_size=2)
-    assert [i for i, t in enumerate(ramped) if t is None] == holes
-    assert all(np.abs(np.asarray(ramped[i]) - np.asarray(one[i])).max() <= 2e-6 * np.abs(np.asarray(one[i])).max()
-               for i in range(len(structs)) if i not in holes)
     bad_species = dict(good[0], atomic_numbers=np.full(64, 8))
     with pytest.raises(RuntimeError, match="structure 4. It contains species 8 not supported"):
         P.predict(structs[:4] + [bad_species], model=model, config=cfg)

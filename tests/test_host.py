@@ -256,6 +256,33 @@ def test_predict_coalesces_user_batches_within_the_node_budget():
     assert (np.concatenate(ch) == np.arange(1000)).all() and max(len(c) for c in ch) <= 21
 
 
+def test_pack_structures_fast_path_equals_the_careful_one(monkeypatch):
+    """predict.pack_structures: well-formed dicts of numpy arrays take a vectorised path (no per-structure Python body);
+    anything else -- malformed, non-finite, singular, pymatgen-like objects -- goes through the per-structure path that
+    warns and skips like the reference's dataset loop (dataset/structure_scalar_tensor.py:296-362).  Same arrays either way."""
+    from matten_amd import predict as P
+    from matten_amd.data import synthetic
+
+    st = synthetic.fcc64_structures(7)
+    fast = P._pack_fast(st)
+    assert fast is not None
+    monkeypatch.setattr(P, "_pack_fast", lambda s: None)
+    slow = P.pack_structures(st)
+    monkeypatch.undo()
+    assert all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(fast[:4], slow[:4])) and fast[4:] == slow[4:]
+    malformed = {"lattice": np.eye(3), "cart_coords": np.zeros((2, 3)), "atomic_numbers": np.array([29])}
+    singular = dict(st[0], lattice=np.zeros((3, 3)))
+    nonfinite = dict(st[0], cart_coords=np.full((64, 3), np.nan))
+    lists = dict(st[0], cart_coords=st[0]["cart_coords"].tolist())
+    for bad in (malformed, singular, nonfinite, lists):
+        assert P._pack_fast(st[:2] + [bad]) is None
+    with pytest.warns(UserWarning, match="structure 2"):
+        pos, cell, Z, ptr, keep, failed = P.pack_structures(st[:2] + [malformed] + st[2:4])
+    assert keep == [0, 1, 3, 4] and failed == [2] and len(ptr) == 5
+    pos2, _, _, ptr2, keep2, failed2 = P.pack_structures(st[:2] + [lists])     # lists are fine for the careful path
+    assert keep2 == [0, 1, 2] and not failed2 and ptr2[-1] == 192
+
+
 def test_predict_api_surface():
     import inspect
 
