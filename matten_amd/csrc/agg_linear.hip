@@ -34,6 +34,9 @@ constexpr int AL_ROWS = 16;      // rows per wave (the N dimension of the matrix
 #ifndef AL_MIN_BLOCKS
 #define AL_MIN_BLOCKS 3
 #endif
+#ifndef AL_GATE_PREFETCH
+#define AL_GATE_PREFETCH 1   // the Gate's column records are requested when a table row opens, not when it is flushed
+#endif
 constexpr int AL_BLK = AL_BLK_CHUNKS;  // chunks per block = 16-byte loads per lane issued together; two blocks in flight
 constexpr int AL_MAX_MT = 2;     // 16-channel output tiles per table row: wider irreps are split by the host into rows
                                  // of <= 32 output channels that re-read the same chunks (few: wide irreps are the
@@ -187,13 +190,24 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
 #pragma unroll
         for (int mt = 0; mt < AL_MAX_MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // a table row opens: request its slice of the addend rows (used by flush_row, many blocks later)
+    // a table row opens: request its slice of the addend rows and -- GATE -- this lane's column record with the constants it
+    // points at (used by flush_row, many blocks later: requested there they were two dependent global loads in front of
+    // every flush)
+    int4 cm_row = {0, 0, 0, 0};
+    float cst_row = 1.0f, bsc_row = 1.0f, bsh_row = 0.0f;
     auto open_row = [&]() {
         const int w = mo * d3;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int rid = max(rowid[2 * p + frow], 0);
             addv[p] = has_add ? a.add[(int64_t)rid * a.add_ld + out_off + min(fcol, w - 1)] : 0.0f;
+        }
+        if constexpr (GATE && AL_GATE_PREFETCH) {
+            cm_row = a.cmeta[out_off + min(fcol, w - 1)];
+            const int type = cm_row.x & 255, code = (cm_row.x >> 8) & 255;
+            cst_row = code ? a.act_cst[code] : 1.0f;
+            bsc_row = 1.0f, bsh_row = 0.0f;
+            if (a.bn_scale && (type == 1 || type == 3)) bsc_row = a.bn_scale[cm_row.y], bsh_row = a.bn_shift[cm_row.y];
         }
     };
     // a unit (component k) is complete: park its 16 x mo values
@@ -217,11 +231,13 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
         if constexpr (GATE) {
             // per column of the conv output: what happens to it.  type 0: dropped (an irrep the Gate does not take), 1:
             // activated scalar, 2: gate scalar (kept in gate_reg[set] of THIS lane), 3: gated component
-            const int4 cm = a.cmeta[out_off + min(fcol, w - 1)];
+            const int4 cm = AL_GATE_PREFETCH ? cm_row : a.cmeta[out_off + min(fcol, w - 1)];
             const int type = cm.x & 255, code = (cm.x >> 8) & 255;
-            const float cst = code ? a.act_cst[code] : 1.0f;
-            float bsc = 1.0f, bsh = 0.0f;
-            if (a.bn_scale && (type == 1 || type == 3)) bsc = a.bn_scale[cm.y], bsh = a.bn_shift[cm.y];
+            float cst = cst_row, bsc = bsc_row, bsh = bsh_row;
+            if (!AL_GATE_PREFETCH) {
+                cst = code ? a.act_cst[code] : 1.0f;
+                if (a.bn_scale && (type == 1 || type == 3)) bsc = a.bn_scale[cm.y], bsh = a.bn_shift[cm.y];
+            }
             const int src_lane = (cm.z & 31) | (frow << 5);
 #pragma unroll
             for (int p = 0; p < 8; ++p) {

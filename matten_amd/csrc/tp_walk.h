@@ -72,17 +72,24 @@ constexpr bool TPF_LAB_NO_LOOP = false;
 namespace matten_walk {
 
 #if TPF_TRACING
-__device__ __forceinline__ unsigned long long tpf_stamp() {
+// low word of s_memtime (phase lengths are differences of nearby stamps; 64-bit stamps that get spilled trip a gfx950 backend
+// check: "Subtarget requires even aligned vector registers" on the scratch reload of an odd register pair)
+__device__ __forceinline__ unsigned tpf_stamp() {
     unsigned long long t;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
-    return t;
+    return (unsigned)t;
+}
+__device__ __forceinline__ unsigned tpf_stamp_hi() {
+    unsigned long long t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return (unsigned)(t >> 32);
 }
 template <int N>
-__device__ __forceinline__ unsigned long long tpf_stamp_after(float (&acc)[N]) {   // ... once the accumulators exist
+__device__ __forceinline__ unsigned tpf_stamp_after(float (&acc)[N]) {   // ... once the accumulators exist
     unsigned long long t;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)"
                  : "=s"(t), "+v"(acc[0]), "+v"(acc[N / 2]), "+v"(acc[N - 1]) : : "memory");
-    return t;
+    return (unsigned)t;
 }
 #endif
 
@@ -404,7 +411,8 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                                                  const Epilogue& epi) {
     static_assert(!PAIRED || TT == 1, "paired workgroups stage 2 x 16 rows");
 #if TPF_TRACING
-    const unsigned long long tr_in = tpf_stamp();     // (covers every node group of a persistent unit)
+    const unsigned tr_in_hi = tpf_stamp_hi();
+    const unsigned tr_in = tpf_stamp();     // (covers every node group of a persistent unit)
     unsigned tr_mfma = 0, tr_con = 0, tr_pub = 0, tr_bar = 0, tr_chunks = 0, tr_pro = 0, tr_epi = 0;
 #endif
     const int row0 = PAIRED ? 16 * (int)(threadIdx.x >> 7) : 0;       // this wave's half of a paired stage
@@ -520,7 +528,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     start_group(unit_nodes(a, ge, tile_id, r0, lane));
     for (int rep = 0; rep < reps; ++rep) {
 #if TPF_TRACING
-    const unsigned long long tr_rep = rep == 0 ? tr_in : tpf_stamp();
+    const unsigned tr_rep = rep == 0 ? tr_in : tpf_stamp();
 #endif
     const bool more = rep + 1 < reps;
     const RawNodes raw_next = unit_nodes_issue(a, ge, tile_id, r0 + RSTEP * (rep + (more ? 1 : 0)), lane);
@@ -530,8 +538,8 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     ld.publish(0);
     __syncthreads();
 #if TPF_TRACING
-    const unsigned long long tr_loop = tpf_stamp();
-    unsigned long long tr_a = tr_loop;
+    const unsigned tr_loop = tpf_stamp();
+    unsigned tr_a = tr_loop;
     tr_pro += (unsigned)(tr_loop - tr_rep);
 #endif
     int buf = 0;
@@ -565,7 +573,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_setprio(0);
 #if TPF_TRACING
-        const unsigned long long tr_b = tpf_stamp();
+        const unsigned tr_b = tpf_stamp();
 #endif
         auto contract = [&](int so, const float* __restrict__ x) {
             const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
@@ -633,11 +641,11 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             }
         }
 #if TPF_TRACING
-        const unsigned long long tr_c = tpf_stamp_after(acc);
+        const unsigned tr_c = tpf_stamp_after(acc);
 #endif
         ld.publish(buf ^ 1);
 #if TPF_TRACING
-        const unsigned long long tr_d = tpf_stamp();
+        const unsigned tr_d = tpf_stamp();
 #endif
         if constexpr (TPF_LAB_NO_BARRIER) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -646,14 +654,14 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             __syncthreads();  // the next stage is published; every wave is done with this chunk's rows
         }
 #if TPF_TRACING
-        const unsigned long long tr_e = tpf_stamp();
+        const unsigned tr_e = tpf_stamp();
         tr_mfma += (unsigned)(tr_b - tr_a), tr_con += (unsigned)(tr_c - tr_b), tr_pub += (unsigned)(tr_d - tr_c);
         tr_bar += (unsigned)(tr_e - tr_d), tr_chunks += 1;
         tr_a = tr_e;
 #endif
     }
 #if TPF_TRACING
-    const unsigned long long tr_end = tpf_stamp();
+    const unsigned tr_end = tpf_stamp();
 #endif
     const int node_done = node;
     const bool valid_done = valid;
@@ -664,14 +672,14 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     if (a.trace && lane == 0) {
         // the LAST node group's stores are waited for (as s_endpgm does); the earlier ones drain behind the next group's walk
         if (rep + 1 == reps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long tr_out = tpf_stamp();
+        const unsigned tr_out = tpf_stamp();
         tr_epi += (unsigned)(tr_out - tr_end);
         if (rep + 1 == reps) {
             unsigned* tr = a.trace + ((size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 16;
             tr[0] = 1u, tr[1] = (unsigned)ge.kind, tr[2] = (unsigned)cu_log2 | (PAIRED ? 256u : 0u) | ((unsigned)reps << 9) | ((unsigned)TT << 12) | ((unsigned)MT << 16);
             tr[3] = tr_chunks, tr[4] = tr_pro, tr[5] = tr_mfma, tr[6] = tr_con, tr[7] = tr_pub, tr[8] = tr_bar;
             tr[9] = tr_epi, tr[10] = (unsigned)(tr_out - tr_in), tr[11] = (unsigned)ge.mask;
-            tr[12] = (unsigned)(tr_in & 0xffffffffu), tr[13] = (unsigned)(tr_in >> 32);
+            tr[12] = tr_in, tr[13] = tr_in_hi;
         }
     }
 #endif

@@ -1,16 +1,16 @@
 #!/bin/bash
 # round-5 A/B harness: REPS alternating runs per flag set of the bench forward (no extras / CPU baseline / calibration),
 # printing the step time and the per-layer tp_fused / agg_linear times; KINDS=1 adds the per-kind launch times once.
-#   FLAGSETS="|-DTPF_X=1" REPS=2 KINDS=1 bash tools/ab5.sh
+#   FLAGSETS="|-DTPF_X=1" REPS=2 KINDS=1 [SRC=agg_linear] bash tools/ab5.sh   (SRC: the source file the flag sets rebuild)
 cd "$GRAFT_REPO_ROOT/matten_amd/csrc" || exit 1
 make -j8 > /dev/null 2>&1
 IFS='|' read -ra SETS <<< "${FLAGSETS:-|}"
 i=0
 for fl in "${SETS[@]}"; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I../../include -I. $fl -c tp_fused.hip -o build/tp_fused_$i.o 2>&1 | grep -i "error" 
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I../../include -I. $fl -c ${SRC:-tp_fused}.hip -o build/${SRC:-tp_fused}_$i.o 2>&1 | grep -i "error" 
   i=$((i+1))
 done
-link() { cp build/tp_fused_$1.o build/tp_fused.o; hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v 'tp_fused_') -o ../libmatten_hip.so; }
+link() { cp build/${SRC:-tp_fused}_$1.o build/${SRC:-tp_fused}.o; hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v "${SRC:-tp_fused}_" | grep -v calib) -o ../libmatten_hip.so; }
 for rep in $(seq 1 ${REPS:-2}); do
   i=0
   for fl in "${SETS[@]}"; do
@@ -32,4 +32,4 @@ if [ -n "$KINDS" ]; then
     i=$((i+1))
   done
 fi
-rm -f build/tp_fused_*.o; touch tp_fused.hip; make -j8 > /dev/null 2>&1
+rm -f build/${SRC:-tp_fused}_*.o; touch ${SRC:-tp_fused}.hip; make -j8 > /dev/null 2>&1
