@@ -671,7 +671,7 @@ def test_cpu_tensors_are_rejected_loudly():
 
 
 @pytest.mark.parametrize("per_node_norm", [False, True])
-def test_tp_kernels_agree_and_match_oracle(per_node_norm):
+def test_tp_kernels_agree_and_match_oracle(per_node_norm, monkeypatch):
     """The block-fused and per-path kernels (literal CG) and the table-driven kernel are three
     implementations of the same operator: all must match the oracle's TensorProduct + scatter on ragged
     n100 crystals."""
@@ -740,6 +740,15 @@ def test_tp_kernels_agree_and_match_oracle(per_node_norm):
     f_plain = ops.tp_fused(x.to(DEV), h2p, w2f, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV), umap_plain,
                            umap_plain.numel(), p.fused_lds_floats_per_wave, p.d_mid, avg, nn_)
     assert torch.equal(f, f_plain)
+    # persistent units (a wave walks 1, 2, 4 or 8 node groups of its tile in turn; plan.fused_persist) change which wave
+    # visits a node, never the order in which a node's edges are summed: bit-identical for every repeat count
+    for spec in ("", "16:2,8:2,4:2,2:2", "16:8,8:8,4:4,2:2"):
+        monkeypatch.setenv("MATTEN_TP_PERSIST", spec)
+        um = torch.from_numpy(mplan.fused_unit_map(p.group_entries)).to(DEV)
+        monkeypatch.delenv("MATTEN_TP_PERSIST")
+        f_rep = ops.tp_fused(x.to(DEV), h2p, w2f, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV), um, um.numel(),
+                             p.fused_lds_floats_per_wave, p.d_mid, avg, nn_)
+        assert torch.equal(f, f_rep), f"persistent units {spec!r} changed the result"
     close(a, want, 2e-5, "tp_paths vs oracle")
 
 

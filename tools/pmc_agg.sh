@@ -9,7 +9,7 @@ P5="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_6
 P6="TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5" "$P6"; do i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmca_$i -o p -- python3 $R/tools/agg_bench.py > $R/gpurun_out/pmca_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmca_$i -o p -- python3 $R/tools/agg_bench.py > $R/gpurun_out/pmca_$i.log 2>&1
 done
 python3 - <<PY
 import csv, collections

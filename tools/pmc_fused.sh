@@ -5,7 +5,7 @@ P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WA
 P3="SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_WAVES_EQ_64"
 i=0
 for P in "$P1" "$P2" "$P3"; do i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmcf_$i -o p -- python3 $R/tools/tp_bench.py > $R/gpurun_out/pmcf_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmcf_$i -o p -- python3 $R/tools/tp_bench.py > $R/gpurun_out/pmcf_$i.log 2>&1
 done
 python3 - <<PY
 import csv, collections

@@ -11,7 +11,7 @@ P4="TA_BUSY_avr TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
 P5="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum TCP_TA_TCP_STATE_READ_sum TCP_TCC_WRITE_REQ_sum"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmck_${TAG}_$i -o p -- python3 $R/tools/fused_kind_bench.py > $R/gpurun_out/pmck_${TAG}_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmck_${TAG}_$i -o p -- python3 $R/tools/fused_kind_bench.py > $R/gpurun_out/pmck_${TAG}_$i.log 2>&1
 done
 python3 - <<PY
 import csv, collections

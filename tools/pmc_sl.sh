@@ -7,7 +7,7 @@ P3="SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCL
 P4="TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TA_TA_BUSY_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmcs_$i -o p -- python3 $R/tools/sl_bench.py > $R/gpurun_out/pmcs_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmcs_$i -o p -- python3 $R/tools/sl_bench.py > $R/gpurun_out/pmcs_$i.log 2>&1
 done
 python3 - <<PY
 import csv, collections

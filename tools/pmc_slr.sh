@@ -6,7 +6,7 @@ P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WA
 P3="GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_IFETCH SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_SCA"
 i=0
 for P in "$P1" "$P2" "$P3"; do i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmcr_$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmcr_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmcr_$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmcr_$i.log 2>&1
 done
 python3 - <<PY
 import csv, collections
