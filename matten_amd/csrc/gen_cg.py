@@ -89,6 +89,39 @@ def emit_triple(l1, l2, l3, out):
     return min(cost_pair, cost_m), len(nz)
 
 
+# ---- two edges at a time (vector input blocks, l1 = 1) ----------------------------------------------------------------
+# The coupling coefficients do not depend on the edge, so the pair products of TWO edges of the same (node, channel) can be
+# added before they meet them:  p = xw0[i] y0[j] + xw1[i] y1[j];  acc[k] += C p  -- 2 pairs + nnz operations for two edges
+# instead of 2 (pairs + nnz): -22 % / -25 % vector instructions for the two l1 = 1 kinds, whose edge steps run at the issue
+# rate of a single wave (docs/LAB_NOTES.md round 5).  Emitted for l1 = 1 only (the kinds that walk two edge slots per chunk).
+PAIR_SUM_L1 = (1,)
+
+
+def emit_triple2(l1, l2, l3, out):
+    C = wigner_3j(l1, l2, l3) * math.sqrt(2 * l3 + 1)
+    d1, d2, d3 = 2 * l1 + 1, 2 * l2 + 1, 2 * l3 + 1
+    nz = [(i, j, k, float(C[i, j, k])) for i in range(d1) for j in range(d2) for k in range(d3) if abs(C[i, j, k]) > 1e-12]
+    pairs = sorted({(i, j) for i, j, _, _ in nz})
+    out.append(f"// ({l1},{l2},{l3}) for two edges: 2 x {len(pairs)} pair operations + {len(nz)} coefficient operations")
+    out.append(f"template <> struct CG2<{l1}, {l2}, {l3}> {{")
+    out.append("    static __device__ __forceinline__ void apply(const float* __restrict__ xa, const float* __restrict__ ya, "
+               "const float* __restrict__ xb, const float* __restrict__ yb, float* __restrict__ acc) {")
+    for (i, j) in pairs:
+        terms = [(k, c) for (ii, jj, k, c) in nz if ii == i and jj == j]
+        if len(terms) == 1 and abs(abs(terms[0][1]) - 1.0) < 1e-12:
+            k, c = terms[0]
+            sign = "" if c > 0 else "-"
+            out.append(f"        acc[{k}] = fmaf({sign}xa[{i}], ya[{j}], acc[{k}]);")
+            out.append(f"        acc[{k}] = fmaf({sign}xb[{i}], yb[{j}], acc[{k}]);")
+            continue
+        out.append(f"        {{ const float p = fmaf(xb[{i}], yb[{j}], xa[{i}] * ya[{j}]);")
+        for k, c in terms:
+            out.append(f"          acc[{k}] = fmaf({lit(c)}, p, acc[{k}]);")
+        out.append("        }")
+    out.append("    }")
+    out.append("};")
+
+
 # l2 ranges fused into one "group" per input block: single source of truth is matten_amd/plan.py
 from matten_amd.plan import TP_GROUPS as GROUPS, TP_MAX_COMBOS as MAX_COMBOS  # noqa: E402
 
@@ -129,6 +162,21 @@ def emit_group(l1, gi, lo, hi, out):
             out.append(f"            CG<{l1}, {l2}, {l3}>::apply(xw, y + {l2 * l2 - y0}, acc + {off});")
             out.append("        }")
     out.append("    }")
+    if l1 in PAIR_SUM_L1:
+        out.append("    // two edges (a, b) of the same (node, channel) in one pass: see CG2")
+        out.append("    static constexpr bool HAS_APPLY2 = true;")
+        out.append("    static __device__ __forceinline__ void apply2(unsigned mask, const float* __restrict__ xa, "
+                   "const float* __restrict__ ya, const float* __restrict__ wa, const float* __restrict__ xb, "
+                   "const float* __restrict__ yb, const float* __restrict__ wb, float* __restrict__ acc) {")
+        for c, ((l2, l3), off) in enumerate(zip(combos, offs)):
+            out.append(f"        if (mask & {1 << c}u) {{")
+            out.append(f"            float xwa[{d1}], xwb[{d1}];")
+            out.append(f"            _Pragma(\"unroll\") for (int i = 0; i < {d1}; ++i) xwa[i] = wa[{c}] * xa[i], xwb[i] = wb[{c}] * xb[i];")
+            out.append(f"            CG2<{l1}, {l2}, {l3}>::apply(xwa, ya + {l2 * l2 - y0}, xwb, yb + {l2 * l2 - y0}, acc + {off});")
+            out.append("        }")
+        out.append("    }")
+    else:
+        out.append("    static constexpr bool HAS_APPLY2 = false;")
     out.append("};")
 
 
@@ -215,6 +263,7 @@ def main():
         "",
         f"constexpr int CG_LMAX = {LMAX};",
         "template <int L1, int L2, int L3> struct CG;",
+        "template <int L1, int L2, int L3> struct CG2;   // the same contraction for two edges at once (l1 = 1 only)",
         "",
     ]
     tot_ops = tot_nnz = 0
@@ -223,6 +272,9 @@ def main():
         tot_ops += ops
         tot_nnz += nnz
         out.append("")
+        if t[0] in PAIR_SUM_L1:
+            emit_triple2(*t, out)
+            out.append("")
     out.append(f"// total: {tot_nnz} non-zeros, {tot_ops} VALU ops over all triples")
     out.append("")
     out.append(f"constexpr int GROUP_MAX_COMBOS = {MAX_COMBOS};")

@@ -112,6 +112,9 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_SETPRIO
 #define TPF_SETPRIO 3
 #endif
+#ifndef TPF_PAIR_SUM
+#define TPF_PAIR_SUM 1   // vector input blocks (l1 = 1): two edge slots per pass, pair products summed before the coefficients
+#endif
 #ifndef TPF_EXACT_Y0
 #define TPF_EXACT_Y0 0
 #endif
@@ -395,7 +398,7 @@ __device__ __forceinline__ void run_loader_only(const Args& a, const GroupEntry&
 
 // the kinds with registers to spare for a second neighbour row in flight (two-slot chunks: 8 lanes per node)
 template <int L1, int GI>
-struct TwoDeepOk { static constexpr bool value = L1 == 0 || (L1 == 1 && GI == 0); };
+struct TwoDeepOk { static constexpr bool value = L1 == 0 || (L1 == 1 && (GI == 0 || TPF_PAIR_SUM)); };
 
 // TWO_DEEP is a template parameter, not a run-time flag: with both gather schedules in one instantiation the compiler
 // reconciled their register assignments with 50-90 v_mov per CHUNK (60 % of the l1 = 0 kind's vector instructions).
@@ -606,6 +609,48 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             G::apply(CMASK ? CMASK : mask, x, y, w, acc);
         };
         if constexpr (TPF_LAB_NO_VALU) {
+        } else if constexpr (TWO_DEEP && TPF_PAIR_SUM && G::HAS_APPLY2) {
+            // Vector input blocks: the two edge slots of a pair in ONE pass (cg_gen.h CG2: the pair products of both edges
+            // are added before they meet the coupling coefficients, -22 / -25 % vector instructions per pair).  The harmonics
+            // and weights of both slots are read unconditionally (every slot of a chunk has a staged row: past a segment's
+            // end its last edge again); a slot past the end contracts x = 0 -- an exact + 0 to every accumulator.
+            auto fetch = [&](int so, float (&y)[G::NY], float (&w)[NC]) {
+                const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
+                const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
+                constexpr int Q0 = G::Y0 / 4 * 4, NQ = (G::Y0 + G::NY - Q0 + 3) / 4;
+                float yq[4 * NQ];
+                const f32x4* y4 = reinterpret_cast<const f32x4*>(yp - (G::Y0 - Q0));
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 v = y4[q];
+                    yq[4 * q] = v[0], yq[4 * q + 1] = v[1], yq[4 * q + 2] = v[2], yq[4 * q + 3] = v[3];
+                }
+#pragma unroll
+                for (int jj = 0; jj < G::NY; ++jj) y[jj] = yq[G::Y0 - Q0 + jj];
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+            };
+            for (int so = 0; so < CH; so += 2) {
+                const int s = s0 + so;
+                float ya[G::NY], wa[NC], yb[G::NY], wb[NC], xa[G::D1], xc[G::D1];
+                fetch(so, ya, wa);
+                fetch(so + 1, yb, wb);
+#pragma unroll
+                for (int i = 0; i < G::D1; ++i) xa[i] = s < deg ? xn[i] : 0.0f, xc[i] = s + 1 < deg ? xb[i] : 0.0f;
+                {
+                    const float* xp = a.x + (int64_t)TPF_SRC(src_nn) * a.d_in + xcol;
+#pragma unroll
+                    for (int i = 0; i < G::D1; ++i) xn[i] = TPF_XLD(xp, i, src_nn);
+                    src_nn = a.src_sorted[min(beg + s + 4, e_last)];
+                }
+                {
+                    const float* xp = a.x + (int64_t)TPF_SRC(src_b) * a.d_in + xcol;
+#pragma unroll
+                    for (int i = 0; i < G::D1; ++i) xb[i] = TPF_XLD(xp, i, src_b);
+                    src_b = a.src_sorted[min(beg + s + 5, e_last)];
+                }
+                G::apply2(CMASK ? CMASK : mask, xa, ya, wa, xc, yb, wb, acc);
+            }
         } else if (two_deep) {
             for (int so = 0; so < CH; so += 2) {   // CH is 2, 4 or 8 here: slot pairs, one row buffer per parity
                 const int s = s0 + so;

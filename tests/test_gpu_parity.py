@@ -739,7 +739,15 @@ def test_tp_kernels_agree_and_match_oracle(per_node_norm, monkeypatch):
     umap_plain = torch.from_numpy(mplan.fused_unit_map(p.group_entries, "entry")).to(DEV)
     f_plain = ops.tp_fused(x.to(DEV), h2p, w2f, geo["sh_sorted"], rowptr, src, t.get("gentries", DEV), umap_plain,
                            umap_plain.numel(), p.fused_lds_floats_per_wave, p.d_mid, avg, nn_)
-    assert torch.equal(f, f_plain)
+    # ... except for the vector (l1 = 1) input blocks, whose shared walk contracts the two edge slots of a pair in one pass
+    # (the pair products of both edges are added before the coupling coefficients: cg_gen.h CG2): same sum, another association
+    l1_cols = torch.zeros(p.d_mid, dtype=torch.bool)
+    for pth in p.paths:
+        if pth.l1 == 1:
+            l1_cols[pth.out_off: pth.out_off + pth.mul * (2 * pth.l3 + 1)] = True
+    assert l1_cols.any() and not l1_cols.all()
+    assert torch.equal(f[:, ~l1_cols.to(DEV)], f_plain[:, ~l1_cols.to(DEV)])
+    close(f[:, l1_cols.to(DEV)], f_plain[:, l1_cols.to(DEV)].cpu(), 2e-6, "pair-summed l1 = 1 blocks vs the edge-by-edge walk")
     # persistent units (a wave walks 1, 2, 4 or 8 node groups of its tile in turn; plan.fused_persist) change which wave
     # visits a node, never the order in which a node's edges are summed: bit-identical for every repeat count
     for spec in ("", "16:2,8:2,4:2,2:2", "16:8,8:8,4:4,2:2"):
