@@ -126,13 +126,10 @@ def emit_triple2(l1, l2, l3, out):
 from matten_amd.plan import TP_GROUPS as GROUPS, TP_MAX_COMBOS as MAX_COMBOS  # noqa: E402
 
 
-def group_combos(l1, lo, hi):
-    return [(l2, l3) for l2 in range(lo, hi + 1) for l3 in range(abs(l1 - l2), min(LMAX, l1 + l2) + 1)]
-
-
-def emit_group(l1, gi, lo, hi, out):
-    combos = group_combos(l1, lo, hi)
-    assert len(combos) <= MAX_COMBOS, (l1, lo, hi, len(combos))
+def emit_group(l1, gi, combos, out):
+    combos = list(combos)
+    lo, hi = min(l2 for l2, _ in combos), max(l2 for l2, _ in combos)   # the harmonics a lane keeps: the hull of its l2
+    assert len(combos) <= MAX_COMBOS, (l1, gi, len(combos))
     d1 = 2 * l1 + 1
     offs, o = [], 0
     for (_, l3) in combos:
@@ -140,7 +137,8 @@ def emit_group(l1, gi, lo, hi, out):
         o += 2 * l3 + 1
     y0 = lo * lo
     ny = (hi + 1) ** 2 - y0
-    out.append(f"// in1 l={l1}, edge harmonics l2={lo}..{hi}: {len(combos)} couplings, {o} accumulators")
+    out.append(f"// in1 l={l1}, edge harmonics l2={lo}..{hi}: {len(combos)} couplings "
+               f"{' '.join('(%d,%d)' % c for c in combos)}, {o} accumulators")
     out.append(f"template <> struct Group<{l1}, {gi}> {{")
     out.append(f"    static constexpr int NC = {len(combos)}, NACC = {o}, D1 = {d1}, Y0 = {y0}, NY = {ny};")
     out.append("    static constexpr int L2[NC] = {" + ", ".join(str(c[0]) for c in combos) + "};")
@@ -151,7 +149,9 @@ def emit_group(l1, gi, lo, hi, out):
                "const float* __restrict__ y, const float* __restrict__ w, float* __restrict__ acc) {")
     for l2 in range(lo, hi + 1):
         members = [(c, l3, off) for c, ((l2_, l3), off) in enumerate(zip(combos, offs)) if l2_ == l2]
-        rows = shared_rows(l1, l2)
+        if not members:
+            continue
+        rows = shared_rows(l1, l2) if len(members) == len(range(abs(l1 - l2), min(LMAX, l1 + l2) + 1)) else 0
         if rows:
             emit_shared_products(l1, l2, members, rows, l2 * l2 - y0, out)
             continue
@@ -283,9 +283,9 @@ def main():
     out.append("#define MATTEN_FOR_EACH_GROUP(X) " + " ".join(
         f"X({l1}, {gi})" for l1, ranges in GROUPS.items() for gi in range(len(ranges))))
     out.append("")
-    for l1, ranges in GROUPS.items():
-        for gi, (lo, hi) in enumerate(ranges):
-            emit_group(l1, gi, lo, hi, out)
+    for l1, groups in GROUPS.items():
+        for gi, combos in enumerate(groups):
+            emit_group(l1, gi, combos, out)
             out.append("")
     out.append("}  // namespace matten")
     print("\n".join(out))

@@ -112,6 +112,12 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_SETPRIO
 #define TPF_SETPRIO 3
 #endif
+#ifndef TPF_W_FIRST
+#define TPF_W_FIRST 1    // a step's weights are requested before its harmonics (one LDS round trip per step instead of two: -0.4 %)
+#endif
+#ifndef TPF_W_FIRST2
+#define TPF_W_FIRST2 1   // the same in the two-slot pass of the vector input blocks (-0.7 %)
+#endif
 #ifndef TPF_PAIR_SUM
 #define TPF_PAIR_SUM 1   // vector input blocks (l1 = 1): two edge slots per pass, pair products summed before the coefficients
 #endif
@@ -246,6 +252,7 @@ __device__ __forceinline__ void mfma_tiles(const f16x8* __restrict__ ah, const f
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) *reinterpret_cast<f32x4*>(trow + mt * 16) = dh[mt] + SPLIT_LO_INV * dx[mt];
 }
+
 
 
 // loader role of a thread: (edge row of the chunk, 16-byte piece of the row) per MFMA tile; fixed for the whole walk
@@ -582,6 +589,14 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
             const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
             float y[G::NY], w[NC];
+            if constexpr (TPF_W_FIRST) {
+                // the weights are requested BEFORE the harmonics: whole quads over [Y0, Y0 + NY) leave up to four dead registers,
+                // and weights requested afterwards land IN them -- a write-after-read on a load in flight, i.e. a second LDS
+                // round trip per edge step (seen in the ISA of the l1 = 0 kind, docs/LAB_NOTES.md round 5)
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+                asm volatile("" ::: "memory");
+            }
             if constexpr (TPF_EXACT_Y0 && L1 == 0 && G::Y0 == 0 && G::NY % 4 == 1) {
                 // scalar blocks: NY = 25 = six quads + one float read on its own -- whole quads leave three dead registers
                 // that the allocator reuses for the weights: a write-after-read on a load in flight, a second LDS round trip
@@ -604,8 +619,10 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 #pragma unroll
                 for (int jj = 0; jj < G::NY; ++jj) y[jj] = yq[G::Y0 - Q0 + jj];
             }
+            if constexpr (!TPF_W_FIRST) {
 #pragma unroll
-            for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+                for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+            }
             G::apply(CMASK ? CMASK : mask, x, y, w, acc);
         };
         if constexpr (TPF_LAB_NO_VALU) {
@@ -617,6 +634,11 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             auto fetch = [&](int so, float (&y)[G::NY], float (&w)[NC]) {
                 const float* wp = tile + ((j << ch_log2) + so) * stride + u * NC;
                 const float* yp = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
+                if constexpr (TPF_W_FIRST2) {   // weights before harmonics: see `contract` below
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+                    asm volatile("" ::: "memory");
+                }
                 constexpr int Q0 = G::Y0 / 4 * 4, NQ = (G::Y0 + G::NY - Q0 + 3) / 4;
                 float yq[4 * NQ];
                 const f32x4* y4 = reinterpret_cast<const f32x4*>(yp - (G::Y0 - Q0));
@@ -627,8 +649,10 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                 }
 #pragma unroll
                 for (int jj = 0; jj < G::NY; ++jj) y[jj] = yq[G::Y0 - Q0 + jj];
+                if constexpr (!TPF_W_FIRST2) {
 #pragma unroll
-                for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+                    for (int cc = 0; cc < NC; ++cc) w[cc] = wp[cc];
+                }
             };
             for (int so = 0; so < CH; so += 2) {
                 const int s = s0 + so;

@@ -23,14 +23,34 @@ from .o3 import Irrep, Irreps, wigner_3j
 
 TP_TILE_NODES = 64  # must equal matten_tp_tile_nodes() of the library (checked at first use)
 
-# l2 ranges fused per input-block degree l1; must match GROUPS in matten_amd/csrc/gen_cg.py
+# Couplings (l2, l3) of one input-block degree l1 contracted by one wave = a "group".  Schemes A-C cut by l2 RANGES; scheme D
+# moves two or three couplings of l2 = 3 from the heavy second group of the l1 >= 2 blocks into the light first one: the two
+# partners of a block sit in ONE workgroup and meet at a barrier every chunk, and with the range cut they are 296 / 492,
+# 402 / 716 and 404 / 902 coupling operations per edge step (the lighter wave waits 12-41 % of its life, tools/tp_trace.py);
+# with D 380 / 408, 462 / 656, 550 / 756: -0.75 % per forward (same-box A/B, round 5; balancing further -- 534 / 584 and 674 / 632
+# at 61 accumulators in the first groups of l1 = 3, 4 -- is 1.3 % SLOWER than D).  gen_cg.py emits Group<l1, g> from the same lists (cg_gen.h is generated for ONE
+# scheme; tests/test_host.py checks the committed header against the default).
+def _range_groups(ranges, l1, lmax=4):
+    return [[(l2, l3) for l2 in range(lo, hi + 1) for l3 in range(abs(l1 - l2), min(lmax, l1 + l2) + 1)] for lo, hi in ranges]
+
+
+def _moved(l1, to_first, lmax=4):
+    """scheme A's two groups of l1 with the couplings `to_first` (of l2 = 3) moved from the second into the first"""
+    g0, g1 = _range_groups([(0, 2), (3, 4)], l1, lmax)
+    assert all(c in g1 for c in to_first)
+    return [g0 + list(to_first), [c for c in g1 if c not in to_first]]
+
+
 _GROUP_SCHEMES = {
-    "A": {0: [(0, 4)], 1: [(0, 2), (3, 4)], 2: [(0, 2), (3, 4)], 3: [(0, 2), (3, 4)], 4: [(0, 2), (3, 4)]},
-    "B": {0: [(0, 4)], 1: [(0, 2), (3, 4)], 2: [(0, 1), (2, 2), (3, 3), (4, 4)], 3: [(0, 1), (2, 2), (3, 3), (4, 4)],
-          4: [(0, 1), (2, 2), (3, 3), (4, 4)]},
-    "C": {l1: [(l2, l2) for l2 in range(5)] for l1 in range(5)},
+    "A": {l1: _range_groups([(0, 4)] if l1 == 0 else [(0, 2), (3, 4)], l1) for l1 in range(5)},
+    "B": {l1: _range_groups([(0, 4)] if l1 == 0 else [(0, 2), (3, 4)] if l1 == 1 else [(0, 1), (2, 2), (3, 3), (4, 4)], l1)
+          for l1 in range(5)},
+    "C": {l1: _range_groups([(l2, l2) for l2 in range(5)], l1) for l1 in range(5)},
+    "D": {0: _range_groups([(0, 4)], 0), 1: _range_groups([(0, 2), (3, 4)], 1),
+          2: _moved(2, [(3, 1), (3, 2)]), 3: _moved(3, [(3, 0), (3, 1)]), 4: _moved(4, [(3, 1), (3, 2)])},
 }
-TP_GROUPS = _GROUP_SCHEMES[os.environ.get("MATTEN_TP_GROUPS", "A")]
+TP_GROUPS_SCHEME = os.environ.get("MATTEN_TP_GROUPS", "D")
+TP_GROUPS = _GROUP_SCHEMES[TP_GROUPS_SCHEME]   # l1 -> [group: [(l2, l3), ...]]
 TP_MAX_COMBOS = 12
 TP_MAX_COLS = int(os.environ.get("MATTEN_TP_MAX_COLS", "64"))  # == matten_tp_max_cols() of the library (-DTPF_MAX_COLS)
 TP_MAX_COLS_L0 = int(os.environ.get("MATTEN_TP_MAX_COLS_L0", "96"))  # scalar input blocks (see plan_uvu); -DTPF_MAX_COLS_L0
@@ -330,9 +350,8 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         per_class: Dict[int, int] = {}
         for plist in by_block.values():
             l1_, mul_ = plist[0].l1, plist[0].mul
-            for lo, hi in TP_GROUPS[l1_]:
-                combos_ = [(l2, l3) for l2 in range(lo, hi + 1) for l3 in range(abs(l1_ - l2), min(4, l1_ + l2) + 1)]
-                if not any(lo <= p_.l2 <= hi for p_ in plist):
+            for combos_ in TP_GROUPS[l1_]:
+                if not any((p_.l2, p_.l3) in combos_ for p_ in plist):
                     continue
                 cap_ = _cap(l1_, len(combos_), cols0, cols1)
                 for u0 in range(0, mul_, cap_):
@@ -421,13 +440,12 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
             continue
         plist = by_block[i_in1]
         l1, mul = plist[0].l1, plist[0].mul
-        for gi, (lo, hi) in enumerate(TP_GROUPS[l1]):
-            combos = [(l2, l3) for l2 in range(lo, hi + 1) for l3 in range(abs(l1 - l2), min(4, l1 + l2) + 1)]
-            present = {(p.l2, p.l3): p for p in plist if lo <= p.l2 <= hi}
+        for gi, combos in enumerate(TP_GROUPS[l1]):
+            present = {(p.l2, p.l3): p for p in plist if (p.l2, p.l3) in combos}
             todo = [(plist, present)]
             if i_in1 in partner:
                 plist_b = by_block[partner[i_in1]]
-                present_b = {(p.l2, p.l3): p for p in plist_b if lo <= p.l2 <= hi}
+                present_b = {(p.l2, p.l3): p for p in plist_b if (p.l2, p.l3) in combos}
                 if present and present_b and _cap(l1, len(combos), cols_l0, cols_l1) >= 4:
                     add_entry(l1, gi, combos, plist[0].x_off, 0, 4, 2, [(2, present), (2, present_b)])
                     continue
