@@ -115,12 +115,6 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_W_FIRST
 #define TPF_W_FIRST 1    // a step's weights are requested before its harmonics (one LDS round trip per step instead of two: -0.4 %)
 #endif
-#ifndef TPF_SINGLE_SLOT
-#define TPF_SINGLE_SLOT 0
-#endif
-#ifndef TPF_PAIR_ADDR_FIRST
-#define TPF_PAIR_ADDR_FIRST 0
-#endif
 #ifndef TPF_W_FIRST2
 #define TPF_W_FIRST2 1   // the same in the two-slot pass of the vector input blocks (-0.7 %)
 #endif
@@ -663,37 +657,8 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             for (int so = 0; so < CH; so += 2) {
                 const int s = s0 + so;
                 float ya[G::NY], wa[NC], yb[G::NY], wb[NC], xa[G::D1], xc[G::D1];
-                if constexpr (TPF_PAIR_ADDR_FIRST) {
-                    // both slots' LDS addresses exist before the first read goes out: an address computed between the two slots'
-                    // reads lands in a dead register of the first slot's last quad and forces lgkmcnt(0) there
-                    const float* wpa = tile + ((j << ch_log2) + so) * stride + u * NC;
-                    const float* ypa = sb + ((j << ch_log2) + so) * STAGE_ROW + 32 + G::Y0;
-                    const float* wpb = wpa + stride;
-                    const float* ypb = ypa + STAGE_ROW;
-                    asm volatile("" : "+v"(wpa), "+v"(ypa), "+v"(wpb), "+v"(ypb));
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) wa[cc] = wpa[cc];
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) wb[cc] = wpb[cc];
-                    asm volatile("" ::: "memory");
-                    constexpr int Q0 = G::Y0 / 4 * 4, NQ = (G::Y0 + G::NY - Q0 + 3) / 4;
-                    float qa[4 * NQ], qb[4 * NQ];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const f32x4 v = reinterpret_cast<const f32x4*>(ypa - (G::Y0 - Q0))[q];
-                        qa[4 * q] = v[0], qa[4 * q + 1] = v[1], qa[4 * q + 2] = v[2], qa[4 * q + 3] = v[3];
-                    }
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const f32x4 v = reinterpret_cast<const f32x4*>(ypb - (G::Y0 - Q0))[q];
-                        qb[4 * q] = v[0], qb[4 * q + 1] = v[1], qb[4 * q + 2] = v[2], qb[4 * q + 3] = v[3];
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < G::NY; ++jj) ya[jj] = qa[G::Y0 - Q0 + jj], yb[jj] = qb[G::Y0 - Q0 + jj];
-                } else {
-                    fetch(so, ya, wa);
-                    fetch(so + 1, yb, wb);
-                }
+                fetch(so, ya, wa);
+                fetch(so + 1, yb, wb);
 #pragma unroll
                 for (int i = 0; i < G::D1; ++i) xa[i] = s < deg ? xn[i] : 0.0f, xc[i] = s + 1 < deg ? xb[i] : 0.0f;
                 {
@@ -728,21 +693,6 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                     src_b = a.src_sorted[min(beg + s + 5, e_last)];
                 }
             }
-        } else if (TPF_SINGLE_SLOT && (TT == 2 || npw == 16)) {
-            // one edge slot per chunk (16 or 32 nodes per wave): the step as straight-line code -- inside a slot loop of unknown
-            // trip count the compiler cannot count the vector-memory operations in flight and drains them all (vmcnt(0)),
-            // the next chunk's stage rows included
-            const int s = s0;
-            float x[G::D1];
-#pragma unroll
-            for (int i = 0; i < G::D1; ++i) x[i] = xn[i];
-            {
-                const float* xp = a.x + (int64_t)TPF_SRC(src_nn) * a.d_in + xcol;
-#pragma unroll
-                for (int i = 0; i < G::D1; ++i) xn[i] = TPF_XLD(xp, i, src_nn);
-                src_nn = a.src_sorted[min(beg + s + 2, e_last)];
-            }
-            if (s < deg) contract(0, x);
         } else {
             for (int so = 0; so < CH; ++so) {
                 const int s = s0 + so;
