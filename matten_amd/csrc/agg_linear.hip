@@ -40,13 +40,14 @@ constexpr int AL_ROWS = 16;      // rows per wave (the N dimension of the matrix
 constexpr int AL_BLK = AL_BLK_CHUNKS;  // chunks per block = 16-byte loads per lane issued together; two blocks in flight
 constexpr int AL_MAX_MT = 2;     // 16-channel output tiles per table row: wider irreps are split by the host into rows
                                  // of <= 32 output channels that re-read the same chunks (few: wide irreps are the
-                                 // scalars, a few chunks per row).  Small on purpose: accumulators + addend = 16 registers,
+                                 // scalars, a few chunks per row); rows of <= 32 channels whose channels x components
+                                 // exceed the 32-float stage are cut by component range instead: nothing is re-read.  Small on purpose: accumulators + addend = 16 registers,
                                  // ~80 in all, six waves per SIMD -- the stream is hidden by occupancy, not by depth
 
 constexpr int AL_STAGE_RS = 33;   // row stride of the wave's output stage (odd: the 16 rows hit 16 banks)
 
-struct AggIo {   // plan.AggLinearPlan.io_table
-    int chunk0, T, K, packed, a_off, out_off, mo, pad;
+struct AggIo {   // plan.AggLinearPlan.io_table: a table row = channels [v0, v0 + mo) x components [k0, k0 + kk) of one output irrep
+    int chunk0, T, K, packed, a_off, out_off, mo, k0;   // packed = d3 | n_mt << 8 | cw << 16 | kk << 24; out_off = column of (v0, k = 0)
 };
 struct AggBlk {  // plan.AggLinearPlan.blocks: <= AL_BLK consecutive chunks of one (io, k) unit
     int chunk;   // first chunk of the block in the row
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
     const int fcol = lane & 31, frow = lane >> 5;   // flush role: column of the table row's slice, row parity
 
     // (io, k) unit state, wave-uniform
-    int K = 0, d3 = 0, n_mt = 0, cw = 0, a_off = 0, out_off = 0, mo = 0;
+    int K = 0, d3 = 0, n_mt = 0, cw = 0, a_off = 0, out_off = 0, mo = 0, k0 = 0, kk = 1;
     auto load_io = [&](int ii) {
         const AggIo r = io_l[ii];
         K = __builtin_amdgcn_readfirstlane(r.K);
@@ -183,6 +184,8 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
         a_off = __builtin_amdgcn_readfirstlane(r.a_off);
         out_off = __builtin_amdgcn_readfirstlane(r.out_off);
         mo = __builtin_amdgcn_readfirstlane(r.mo);
+        k0 = __builtin_amdgcn_readfirstlane(r.k0);
+        kk = __builtin_amdgcn_readfirstlane((r.packed >> 24) & 255);
     };
     f32x4 acc[AL_MAX_MT];
     float addv[8];
@@ -195,15 +198,18 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
     // every flush)
     int4 cm_row = {0, 0, 0, 0};
     float cst_row = 1.0f, bsc_row = 1.0f, bsh_row = 0.0f;
+    int ocol = 0;   // the conv-output column this lane flushes: stage position v * kk + (k - k0) -> out_off + v * d3 + k
     auto open_row = [&]() {
-        const int w = mo * d3;
+        const int w = mo * kk;
+        const int fc = min(fcol, w - 1), fv = fc / kk;
+        ocol = out_off + fv * d3 + k0 + (fc - fv * kk);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int rid = max(rowid[2 * p + frow], 0);
-            addv[p] = has_add ? a.add[(int64_t)rid * a.add_ld + out_off + min(fcol, w - 1)] : 0.0f;
+            addv[p] = has_add ? a.add[(int64_t)rid * a.add_ld + ocol] : 0.0f;
         }
         if constexpr (GATE && AL_GATE_PREFETCH) {
-            cm_row = a.cmeta[out_off + min(fcol, w - 1)];
+            cm_row = a.cmeta[ocol];
             const int type = cm_row.x & 255, code = (cm_row.x >> 8) & 255;
             cst_row = code ? a.act_cst[code] : 1.0f;
             bsc_row = 1.0f, bsh_row = 0.0f;
@@ -218,20 +224,20 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int v = 16 * mt + 4 * g + i;
-                    if (v < mo) stage[c * AL_STAGE_RS + v * d3 + k] = acc[mt][i];
+                    if (v < mo) stage[c * AL_STAGE_RS + v * kk + (k - k0)] = acc[mt][i];
                 }
             }
         }
     };
     float gate_reg[GATE ? AL_GATE_SETS : 1][8];
     auto flush_row = [&]() {
-        const int w = mo * d3;
+        const int w = mo * kk;
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the stage is written (LDS is in order per wave)
         __builtin_amdgcn_wave_barrier();
         if constexpr (GATE) {
             // per column of the conv output: what happens to it.  type 0: dropped (an irrep the Gate does not take), 1:
             // activated scalar, 2: gate scalar (kept in gate_reg[set] of THIS lane), 3: gated component
-            const int4 cm = AL_GATE_PREFETCH ? cm_row : a.cmeta[out_off + min(fcol, w - 1)];
+            const int4 cm = AL_GATE_PREFETCH ? cm_row : a.cmeta[ocol];
             const int type = cm.x & 255, code = (cm.x >> 8) & 255;
             float cst = cst_row, bsc = bsc_row, bsh = bsh_row;
             if (!AL_GATE_PREFETCH) {
@@ -272,12 +278,12 @@ __global__ __launch_bounds__(AL_WAVES * 64, AL_MIN_BLOCKS) AL_OCC void agg_linea
 #ifdef AL_ABL_NO_STORE
             if (fcol < w && rid >= 0 && addv[p] == 12345.678f)
 #elif defined(AL_ABL_SMALL_OUT)   // timing experiment: same store instructions, all into 64 cache-resident rows
-            if (fcol < w && rid >= 0) a.out[(int64_t)(rid & 63) * a.d_out + out_off + fcol] = stage[r * AL_STAGE_RS + fcol] + addv[p];
+            if (fcol < w && rid >= 0) a.out[(int64_t)(rid & 63) * a.d_out + ocol] = stage[r * AL_STAGE_RS + fcol] + addv[p];
             if (false)
 #else
             if (fcol < w && rid >= 0)
 #endif
-                a.out[(int64_t)rid * a.d_out + out_off + fcol] = stage[r * AL_STAGE_RS + fcol] + addv[p];
+                a.out[(int64_t)rid * a.d_out + ocol] = stage[r * AL_STAGE_RS + fcol] + addv[p];
         }
         __builtin_amdgcn_wave_barrier();      // the next table row's units overwrite the stage after these reads
     };

@@ -811,6 +811,7 @@ def plan_batchnorm(irreps, odd_scalars_too: bool = False) -> Tuple[np.ndarray, n
 AGG_CHUNK = 16  # floats per streamed piece of a row (one 16-byte load per lane group g = 0..3)
 AGG_BLOCK = int(os.environ.get("MATTEN_AGG_BLOCK", "4"))   # chunks per block of matten_agg_linear (-DAL_BLK_CHUNKS; checked by ops.agg_linear)
 AGG_STAGE_W = 32  # output floats per node of one io_table row (AL_STAGE_W)
+AGG_ROW_CUT = os.environ.get("MATTEN_AGG_ROW_CUT", "component")   # "channel": the round-4 rows (A/B only; re-reads chunks)
 AGG_MAX_MT = 2  # 16-channel output tiles per io_table row (AL_MAX_MT): wider irreps become several rows
 
 
@@ -850,12 +851,14 @@ def plan_agg_gate(ap: "AggLinearPlan", gate: "GatePlan") -> Optional[np.ndarray]
     not fit: more table rows with gates than the kernel has register sets, or a gate produced after a row that needs it."""
     meta = np.asarray(gate.meta).reshape(-1, 4)
     d_conv = int(ap.d_out)
-    rows = [(int(r[5]), int(r[6]) * int(r[3] & 255)) for r in np.asarray(ap.io_table).reshape(-1, 8)]   # (out_off, width)
+    # table row = columns out_off + v * d3 + k of (v < mo, k0 <= k < k0 + kk); position in the row's stage = v * kk + (k - k0)
+    rows = [(int(r[5]), int(r[6]), int(r[3] & 255), int(r[7]), int((r[3] >> 24) & 255))
+            for r in np.asarray(ap.io_table).reshape(-1, 8)]
 
     def row_of(col):
-        for ii, (o, w) in enumerate(rows):
-            if o <= col < o + w:
-                return ii, col - o
+        for ii, (o, mo, d3, k0, kk) in enumerate(rows):
+            if o <= col < o + mo * d3 and k0 <= (col - o) % d3 < k0 + kk:
+                return ii, (col - o) // d3 * kk + (col - o) % d3 - k0
         return None
 
     cm = np.zeros((d_conv, 4), dtype=np.int64)
@@ -959,9 +962,12 @@ def plan_agg_linear(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[AggLin
             ent[e][8 + 12 + c] = chunk0 * AGG_CHUNK + piece_off[(e, c)]   # out_off[c]: first float of channel 0, k = 0
             ent[e][8 + c] = Kpad                                          # t_off[c]: floats between components
         # table rows of this irrep: <= AGG_STAGE_W output floats per node each (the kernel's output stage: one 128-byte
-        # line per row), a power-of-two channel count; all rows of an irrep read the same region
+        # line per row).  <= 16 * AGG_MAX_MT channels per row; an irrep whose channels x components exceed the stage is cut
+        # by COMPONENT range [k0, k0 + kk): the (io, k) units of different components are different chunks, so no chunk is
+        # read twice and the rows share one set of A tiles (cutting by channel made every row re-read the whole region:
+        # +18 % of the stream for 16x1o + 16x1e outputs).  Only irreps wider than a row's channels re-read (the scalars).
         step = 16 * AGG_MAX_MT
-        while step * d3 > AGG_STAGE_W and step > 1:
+        while AGG_ROW_CUT == "channel" and step * d3 > AGG_STAGE_W and step > 1:
             step //= 2
         for v0 in range(0, mo, step):
             mo_p = min(step, mo - v0)
@@ -979,19 +985,23 @@ def plan_agg_linear(uvu: UVUPlan, n_species: int, irreps_out) -> Optional[AggLin
             valid = (ib_ >= 0) & (v < mo)
             gather_parts.append(np.where(valid[None, :], g0[None, :] + np.arange(S)[:, None] * mo, -1))
             scale_parts.append(np.full(slot.size, fan[io] ** -0.5, dtype=np.float32))
-            io_rows.append((chunk0, T, K, d3 | (n_mt << 8) | (cw << 16), a_off, o_offs[io] + v0 * d3, mo_p, 0))
+            kmax = max(1, AGG_STAGE_W // mo_p)
+            for k0 in range(0, d3, kmax):
+                kk = min(kmax, d3 - k0)
+                io_rows.append((chunk0, T, K, d3 | (n_mt << 8) | (cw << 16) | (kk << 24), a_off, o_offs[io] + v0 * d3, mo_p, k0))
             a_off += slot.size
         chunk0 += d3 * T
     ld = -(-(chunk0 * AGG_CHUNK) // 32) * 32
     # the row as the reader walks it: blocks of <= AGG_BLOCK chunks of one (io, k) unit
     blocks = []
-    for ii, (c0, T, K, packed, *_rest) in enumerate(io_rows):
-        for k in range(packed & 255):
+    for ii, (c0, T, K, packed, _a, _o, _m, k0) in enumerate(io_rows):
+        kk = (packed >> 24) & 255
+        for k in range(k0, k0 + kk):
             for t0 in range(0, T, AGG_BLOCK):
                 n = min(AGG_BLOCK, T - t0)
                 last = t0 + n == T
                 blocks.append((c0 + k * T + t0, n | (int(t0 == 0) << 8) | (int(last) << 9)
-                               | (int(last and k == (packed & 255) - 1) << 10) | (k << 12) | (ii << 20), t0, 0))
+                               | (int(last and k == k0 + kk - 1) << 10) | (k << 12) | (ii << 20), t0, 0))
     gather = np.concatenate(gather_parts, axis=1).astype(np.int64)
     assert gather.max() < flat
     return AggLinearPlan(entries=ent.astype(np.int32), ld=ld, n_chunks=chunk0,

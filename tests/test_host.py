@@ -712,9 +712,10 @@ def test_agg_linear_plan_reproduces_lin2_on_the_host():
         seen_chunks = 0
         for (chunk, info, t0, _) in ap.blocks.tolist():
             n, k, ii = info & 255, (info >> 12) & 255, (info >> 20) & 4095
-            c0, T, K, packed, a_off, out_off, mo, _z = ap.io_table[ii].tolist()
-            d3, n_mt, cw = packed & 255, (packed >> 8) & 255, (packed >> 16) & 255
-            assert mo * d3 <= mplan.AGG_STAGE_W and n_mt <= mplan.AGG_MAX_MT and 1 <= n <= mplan.AGG_BLOCK
+            c0, T, K, packed, a_off, out_off, mo, k0 = ap.io_table[ii].tolist()
+            d3, n_mt, cw, kk = packed & 255, (packed >> 8) & 255, (packed >> 16) & 255, (packed >> 24) & 255
+            assert mo * kk <= mplan.AGG_STAGE_W and n_mt <= mplan.AGG_MAX_MT and 1 <= n <= mplan.AGG_BLOCK
+            assert k0 <= k < k0 + kk <= d3   # the row's component range (a wide irrep is cut by component: no chunk read twice)
             assert chunk == c0 + k * T + t0
             for i in range(n):
                 t = t0 + i
