@@ -450,7 +450,9 @@ def evaluate_atomic(model, graphs: List, batch_size: int = 200, tensor_target_na
 PREDICT_SLAB = int(__import__("os").environ.get("MATTEN_PREDICT_SLAB", "1024"))   # structures packed per slab
 # (a small first slab with 4x growth -- device started after 0.3 ms of packing -- was measured in round 5 and dropped: every
 # forward costs the host ~1 ms (graph-build read-back + ~45 launches), so three forwards instead of one gave back what the
-# earlier start gained on 1000 fcc-64 structures, 8.1 ms either way, and small structures lost: 3.4 -> 5.3 ms per 1000)
+# earlier start gained on 1000 fcc-64 structures, 8.1 ms either way, and small structures lost: 3.4 -> 5.3 ms per 1000; with the
+# vectorised packer a HALF first slab for large cells only was measured again: 6.3-6.4 vs 6.3-6.6 ms per 1000 fcc-64
+# structures, 5.1-5.3 either way at 4000 -- inside the run-to-run spread, not kept)
 
 
 def _predict_slabs(model, structures, r_cut, batch_size, tensor_target_name, tensor_target_formula, node_budget=None):
