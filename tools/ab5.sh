@@ -17,7 +17,7 @@ for rep in $(seq 1 ${REPS:-2}); do
     link $i
     env ${ENVS:-A=1} python3 ../../bench.py --steps ${STEPS:-30} --warmup 5 --no-cpu-baseline --no-extras --no-calibration 2>/dev/null | tail -1 | python3 -c "
 import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_launch']
-print('rep $rep [$fl]: step %.3f ms  full-layers %.3f' % (d['ms_per_step'], d.get('ms_per_step_full_layers', 0)), 'tp', ' '.join('%.3f'%v for n,v in k.items() if n.startswith('tp')), ' agg', ' '.join('%.3f'%v for n,v in k.items() if n.startswith('agg')))"
+print('rep $rep [$fl]: step %.3f ms  full-layers %.3f' % (d['ms_per_step'], d.get('ms_per_step_full_layers', 0)), 'tp', ' '.join('%.3f'%v for n,v in k.items() if n.startswith('tp')), ' agg', ' '.join('%.3f'%v for n,v in k.items() if n.startswith('agg')), ' radial %.3f' % k.get('radial_hidden_multi', 0))"
     i=$((i+1))
   done
 done
