@@ -716,6 +716,17 @@ def test_training_on_the_production_tensor_product_kernel(golden_dir, monkeypatc
         grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters()}
     for k in grads["fused"]:
         _close(grads["fused"][k], grads["paths"][k], 2e-3, f"fused vs default grad {k}")
+    # the default ("auto") takes the fused forward from nn.utils.TRAIN_FUSED_MIN_EDGES edges on, the path kernels below
+    from matten_amd.nn import utils as nnu
+
+    monkeypatch.delenv("MATTEN_TRAIN_TP")
+    for min_edges, like in ((0, "fused"), (1 << 40, "paths")):
+        monkeypatch.setattr(nnu, "TRAIN_FUSED_MIN_EDGES", min_edges)
+        _, model = build_pair(LMAX2, ds, randomize_bn=True)
+        model.train()
+        out = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+        torch.nn.functional.mse_loss(out, target.to(DEV)).backward()
+        assert all(torch.equal(p.grad, grads[like][k]) for k, p in model.named_parameters()), like
     # capturable: the kernel's operands are derived by kernels, nothing is read on the host
     from matten_amd.graphs import GraphedTrainStep
 
