@@ -393,6 +393,20 @@ int matten_tp_backward_lit(const float* x, int64_t d_in, const void* w_edge, int
                            int64_t d_mid, float avg_num_neighbors, const float* num_neigh, int64_t n_edges, float* dx,
                            void* dw, int64_t dw_ld, int edge_is_bf16, int64_t n_nodes, const int32_t* out_ptr,
                            const int32_t* out_perm, float* dx_edges, matten_stream_t stream);
+/* matten_tp_backward_lit for training on the fused forward: w[E, W] is never read -- every workgroup re-evaluates the weights of
+ * its (edges, input block) on the matrix cores from h2s[E, 2, 32] (matten_radial_hidden: the rows the forward used) and the
+ * A fragments of the last radial layer in REFERENCE column order: frag / w_inv = matten_split_a_tiles over one pseudo-entry per
+ * path (int32 [n_paths, 32], words 5 / 6 / 7 = w_off, first tile, ceil(mul / 16); plan.bw_w_entries), paths[p][3] = that first
+ * tile.  Same dw / dx contract as matten_tp_backward_lit (fixed-order sums with out_ptr / out_perm / dx_edges). */
+int matten_tp_backward_lit_wfree(const float* x, int64_t d_in, const uint16_t* h2s, const uint16_t* frag, const float* w_inv,
+                                 const float* sh_sorted, int64_t sh_stride, const int32_t* src_sorted,
+                                 const int32_t* dst_sorted, const int32_t* blocks, int64_t n_blocks, int64_t sum_lanes,
+                                 const int32_t* paths, int64_t n_paths, const float* g_agg, int64_t d_mid,
+                                 float avg_num_neighbors, const float* num_neigh, int64_t n_edges, float* dx, void* dw,
+                                 int64_t dw_ld, int edge_is_bf16, int64_t n_nodes, const int32_t* out_ptr,
+                                 const int32_t* out_perm, float* dx_edges, int64_t lds_floats, matten_stream_t stream);
+/* lds_floats (512 .. 15360): floats of LDS per workgroup for its [edge][path][column] weight tile; a block whose paths do not
+ * fit takes them in rounds (plan.bw_wfree_lds_floats = what the widest block needs in one round, capped at 4096). */
 
 /* adjoint of matten_species_linear w.r.t. the packed weights (the adjoint w.r.t. x is matten_species_linear
  * itself with the transposed segment table and transposed packed weights):

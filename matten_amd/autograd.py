@@ -172,6 +172,11 @@ class TensorProductScatterFn(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+# training on the fused forward: the adjoint re-evaluates w inside its workgroups (0 = matten_radial_mlp writes it for one layer
+# at a time inside the backward, the round-3 form)
+W_FREE_ADJOINT = os.environ.get("MATTEN_TP_BWD_WFREE", "1") != "0"
+
+
 class FusedTensorProductFn(torch.autograd.Function):
     """The training tensor product on the PRODUCTION kernel (MATTEN_TRAIN_TP=fused): forward = matten_tp_fused -- the last
     radial layer on the matrix cores inside the kernel, the per-edge weights w[E, W] never reach memory -- and nothing
@@ -200,6 +205,8 @@ class FusedTensorProductFn(torch.autograd.Function):
         w0p, w1p, w2p, hs, frag, inv = ops.fused_operands(w0, w1, w2, mlp.pack_scales(), mod._tables.get("fused_cols", dev),
                                                           gent, p.fused_a_tiles, r0, r1, mlp.act_cst)
         h2p = ops.radial_hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, w0p, w1p, hs)
+        if W_FREE_ADJOINT:   # the hidden features (128 B per edge) are what the backward re-evaluates w from
+            ctx.h2p, ctx.hs = h2p, hs
         return ops.tp_fused(x, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC], gent,
                             mod._tables.get("gumap", dev), len(p.fused_unit_map), p.fused_lds_floats_per_wave, p.d_mid, avg,
                             num_neigh, a_split=(frag, inv))
@@ -212,14 +219,25 @@ class FusedTensorProductFn(torch.autograd.Function):
         geom, sh, src, dst = ctx.graph
         scales = mlp.pack_scales()
         w0p, w1p, w2p = ops.radial_pack(w0, w1, w2, scales)                       # reference column order
-        w_edge = ops.radial_mlp(geom, *ctx.rbf, w0p, w1p, w2p, out_dtype=EDGE_STORAGE_DTYPE)   # transient
         out_csr = ctx.out_csr if os.environ.get("MATTEN_TP_BWD_DX", "ordered") != "atomic" else None
-        dx, dw = ops.tp_backward_lit(x, w_edge, sh, src, dst, mod._tables.get("bw_blocks", dev),
-                                     mod._tables.get("bw_paths", dev), mod.plan.bw_sum_lanes, g.contiguous(), ctx.avg,
-                                     ctx.num_neigh, out_csr=out_csr,
-                                     blocks_cover_input=int(mod.plan.bw_blocks[:, 1].dot(2 * mod.plan.bw_blocks[:, 2] + 1))
-                                     == mod.plan.d_in)
-        del w_edge
+        covered = int(mod.plan.bw_blocks[:, 1].dot(2 * mod.plan.bw_blocks[:, 2] + 1)) == mod.plan.d_in
+        h2p = getattr(ctx, "h2p", None)
+        if h2p is not None:
+            # w-free: every workgroup of the adjoint re-evaluates its weights on the matrix cores from the forward's hidden
+            # features and the last layer's A fragments in reference column order (one small launch); w never exists
+            frag, inv = ops.split_a_tiles_dev(w2p, mod._tables.get("bw_w_entries", dev), mod.plan.bw_a_tiles, ctx.hs)
+            dx, dw = ops.tp_backward_lit(x, None, sh, src, dst, mod._tables.get("bw_blocks", dev),
+                                         mod._tables.get("bw_paths", dev), mod.plan.bw_sum_lanes, g.contiguous(), ctx.avg,
+                                         ctx.num_neigh, out_csr=out_csr, blocks_cover_input=covered, wfree=(h2p, frag, inv),
+                                         dw_shape=((geom.shape[0], w2p.shape[1]), EDGE_STORAGE_DTYPE),
+                                         lds_floats=mod.plan.bw_wfree_lds_floats)
+            ctx.h2p = None
+        else:
+            w_edge = ops.radial_mlp(geom, *ctx.rbf, w0p, w1p, w2p, out_dtype=EDGE_STORAGE_DTYPE)   # transient
+            dx, dw = ops.tp_backward_lit(x, w_edge, sh, src, dst, mod._tables.get("bw_blocks", dev),
+                                         mod._tables.get("bw_paths", dev), mod.plan.bw_sum_lanes, g.contiguous(), ctx.avg,
+                                         ctx.num_neigh, out_csr=out_csr, blocks_cover_input=covered)
+            del w_edge
         nb, W = mlp.hs[0], mlp.hs[3]
         d0, d1, d2 = ops.radial_mlp_bwd(geom, *ctx.rbf, w0p, w1p, w2p, W, dw, scales=scales)
         return dx, d0[:nb], d1, d2[:, :W], None, None, None, None

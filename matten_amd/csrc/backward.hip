@@ -1092,9 +1092,9 @@ struct LitArgs {
 };
 
 template <int L1, int L2, int L3>
-__device__ __forceinline__ void lit_path(const LitArgs& a, const int4 pth, int64_t e, int u, const float* __restrict__ x,
-                                         const float* __restrict__ grow, const float* __restrict__ yrow, float norm,
-                                         float* __restrict__ dxi) {
+__device__ __forceinline__ void lit_path(const LitArgs& a, const int4 pth, float wv, int64_t e, int u,
+                                         const float* __restrict__ x, const float* __restrict__ grow,
+                                         const float* __restrict__ yrow, float norm, float* __restrict__ dxi) {
     constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
     float g[D3], y[D2], t[D1];
     const float* gp = grow + pth.z + u * D3;
@@ -1105,7 +1105,6 @@ __device__ __forceinline__ void lit_path(const LitArgs& a, const int4 pth, int64
 #pragma unroll
     for (int i = 0; i < D1; ++i) t[i] = 0.0f;
     matten::CG<L1, L2, L3>::adjoint(y, g, t);
-    const float wv = matten_ld_edge(a.w_edge, e * a.w_ld + pth.y + u, a.edge_bf16);
     float dwv = 0.0f;
 #pragma unroll
     for (int i = 0; i < D1; ++i) {
@@ -1116,10 +1115,31 @@ __device__ __forceinline__ void lit_path(const LitArgs& a, const int4 pth, int64
 }
 
 #define MATTEN_LIT_CASE(L1, L2, L3) \
-    case (L1 * 25 + L2 * 5 + L3): lit_path<L1, L2, L3>(a, pth, e, u, x, grow, yrow, norm, dxi); break;
+    case (L1 * 25 + L2 * 5 + L3): lit_path<L1, L2, L3>(a, pth, wv, e, u, x, grow, yrow, norm, dxi); break;
 
-__device__ __forceinline__ void lit_block_0(const LitArgs& a, const int4 blk, const int4* __restrict__ paths, int64_t e, int u) {
-    constexpr int D1 = 1;
+// the case lists per input-block degree (paths[].x = l1 * 25 + l2 * 5 + l3)
+#define MATTEN_LIT_LIST_0 MATTEN_LIT_CASE(0, 0, 0) MATTEN_LIT_CASE(0, 1, 1) MATTEN_LIT_CASE(0, 2, 2) MATTEN_LIT_CASE(0, 3, 3) MATTEN_LIT_CASE(0, 4, 4)
+#define MATTEN_LIT_LIST_1 MATTEN_LIT_CASE(1, 0, 1) MATTEN_LIT_CASE(1, 1, 0) MATTEN_LIT_CASE(1, 1, 1) MATTEN_LIT_CASE(1, 1, 2) MATTEN_LIT_CASE(1, 2, 1) MATTEN_LIT_CASE(1, 2, 2) MATTEN_LIT_CASE(1, 2, 3) MATTEN_LIT_CASE(1, 3, 2) MATTEN_LIT_CASE(1, 3, 3) MATTEN_LIT_CASE(1, 3, 4) MATTEN_LIT_CASE(1, 4, 3) MATTEN_LIT_CASE(1, 4, 4)
+#define MATTEN_LIT_LIST_2 MATTEN_LIT_CASE(2, 0, 2) MATTEN_LIT_CASE(2, 1, 1) MATTEN_LIT_CASE(2, 1, 2) MATTEN_LIT_CASE(2, 1, 3) MATTEN_LIT_CASE(2, 2, 0) MATTEN_LIT_CASE(2, 2, 1) MATTEN_LIT_CASE(2, 2, 2) MATTEN_LIT_CASE(2, 2, 3) MATTEN_LIT_CASE(2, 2, 4) MATTEN_LIT_CASE(2, 3, 1) MATTEN_LIT_CASE(2, 3, 2) MATTEN_LIT_CASE(2, 3, 3) MATTEN_LIT_CASE(2, 3, 4) MATTEN_LIT_CASE(2, 4, 2) MATTEN_LIT_CASE(2, 4, 3) MATTEN_LIT_CASE(2, 4, 4)
+#define MATTEN_LIT_LIST_3 MATTEN_LIT_CASE(3, 0, 3) MATTEN_LIT_CASE(3, 1, 2) MATTEN_LIT_CASE(3, 1, 3) MATTEN_LIT_CASE(3, 1, 4) MATTEN_LIT_CASE(3, 2, 1) MATTEN_LIT_CASE(3, 2, 2) MATTEN_LIT_CASE(3, 2, 3) MATTEN_LIT_CASE(3, 2, 4) MATTEN_LIT_CASE(3, 3, 0) MATTEN_LIT_CASE(3, 3, 1) MATTEN_LIT_CASE(3, 3, 2) MATTEN_LIT_CASE(3, 3, 3) MATTEN_LIT_CASE(3, 3, 4) MATTEN_LIT_CASE(3, 4, 1) MATTEN_LIT_CASE(3, 4, 2) MATTEN_LIT_CASE(3, 4, 3) MATTEN_LIT_CASE(3, 4, 4)
+#define MATTEN_LIT_LIST_4 MATTEN_LIT_CASE(4, 0, 4) MATTEN_LIT_CASE(4, 1, 3) MATTEN_LIT_CASE(4, 1, 4) MATTEN_LIT_CASE(4, 2, 2) MATTEN_LIT_CASE(4, 2, 3) MATTEN_LIT_CASE(4, 2, 4) MATTEN_LIT_CASE(4, 3, 1) MATTEN_LIT_CASE(4, 3, 2) MATTEN_LIT_CASE(4, 3, 3) MATTEN_LIT_CASE(4, 3, 4) MATTEN_LIT_CASE(4, 4, 0) MATTEN_LIT_CASE(4, 4, 1) MATTEN_LIT_CASE(4, 4, 2) MATTEN_LIT_CASE(4, 4, 3) MATTEN_LIT_CASE(4, 4, 4)
+
+// one path of an input block for one (edge, channel): dw written, the edge's dx contribution added into dxi
+template <int L1>
+__device__ __forceinline__ void lit_one_path(const LitArgs& a, const int4 pth, float wv, int64_t e, int u,
+                                             const float* __restrict__ x, const float* __restrict__ grow,
+                                             const float* __restrict__ yrow, float norm, float* __restrict__ dxi) {
+    // the code is uniform over the block: every thread of the launch row walks the same list
+    if constexpr (L1 == 0) { switch (pth.x) { MATTEN_LIT_LIST_0 default: break; } }
+    if constexpr (L1 == 1) { switch (pth.x) { MATTEN_LIT_LIST_1 default: break; } }
+    if constexpr (L1 == 2) { switch (pth.x) { MATTEN_LIT_LIST_2 default: break; } }
+    if constexpr (L1 == 3) { switch (pth.x) { MATTEN_LIT_LIST_3 default: break; } }
+    if constexpr (L1 == 4) { switch (pth.x) { MATTEN_LIT_LIST_4 default: break; } }
+}
+
+template <int L1>
+__device__ __forceinline__ void lit_block(const LitArgs& a, const int4 blk, const int4* __restrict__ paths, int64_t e, int u) {
+    constexpr int D1 = 2 * L1 + 1;
     const int src = a.src[e], dst = a.dst[e];
     const float norm = 1.0f / sqrtf(a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[dst]);
     const float* xp = a.x + (int64_t)src * a.d_in + blk.x + u * D1;
@@ -1134,11 +1154,8 @@ __device__ __forceinline__ void lit_block_0(const LitArgs& a, const int4 blk, co
     const int p0 = blk.w & 0xffff, np = blk.w >> 16;
     for (int p = p0; p < p0 + np; ++p) {
         const int4 pth = paths[p];
-        switch (pth.x) {   // uniform over the block: every thread of the launch row walks the same list
-            case -1: break;
-            MATTEN_LIT_CASE(0, 0, 0) MATTEN_LIT_CASE(0, 1, 1) MATTEN_LIT_CASE(0, 2, 2) MATTEN_LIT_CASE(0, 3, 3) MATTEN_LIT_CASE(0, 4, 4)
-            default: break;
-        }
+        const float wv = matten_ld_edge(a.w_edge, e * a.w_ld + pth.y + u, a.edge_bf16);
+        lit_one_path<L1>(a, pth, wv, e, u, x, grow, yrow, norm, dxi);
     }
     float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
 #pragma unroll
@@ -1148,127 +1165,109 @@ __device__ __forceinline__ void lit_block_0(const LitArgs& a, const int4 blk, co
     }
 }
 
+// ---- the same adjoint WITHOUT w[E, W] in memory (training on the fused forward) --------------------------------------------
+// The workgroup (256 / cu edges x cu channel lanes of one input block) first evaluates the weights it is about to use,
+//      w[e, w_off_p + u] = sum_k h2[e, k] W2p[k, w_off_p + u],
+// on the matrix cores exactly as the forward does (split fp16: hi hi + 2^-11 (lo hi + hi lo), tp_fused.hip header): per path
+// ceil(mul / 16) column tiles of ready-made A fragments (matten_split_a_tiles over pseudo-entries, one per path, REFERENCE
+// column order), the edges of the workgroup as the N dimension in tiles of 16, B = the hidden-feature rows h2s[E, 2, 32] the
+// forward used.  The D fragments (4 columns of one edge per lane) go to an LDS tile [edge][path][column]; after a barrier
+// the (edge, channel) threads run the literal coupling code with w read from there.  Paths are taken in rounds so that
+// the tile stays within the launch's LDS (lds_floats); dx accumulates in registers across rounds.  What it saves: matten_radial_mlp in the
+// backward (0.36 ms at 293 k edges) and the 4 W bytes per edge of w written and read back; w never exists.
+typedef _Float16 wf_f16x8 __attribute__((ext_vector_type(8)));
+typedef float wf_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int WF_BATCH = 3;            // matrix jobs of a wave whose operand loads are in flight together
+struct WFreeArgs {
+    const _Float16* h2s;      // [E, 2, 32]
+    const _Float16* frag;     // [n_tiles, 64, 16]: hi(kk 0..7) | lo(kk 0..7) per lane
+    const float* w_inv;       // [n_paths] 1 / (the path's fragment scale x the hidden-feature scale)
+    int lds_floats;           // capacity of the workgroup's tile (plan.bw_wfree_lds_floats: what the widest block needs, capped)
+};
 
-__device__ __forceinline__ void lit_block_1(const LitArgs& a, const int4 blk, const int4* __restrict__ paths, int64_t e, int u) {
-    constexpr int D1 = 3;
-    const int src = a.src[e], dst = a.dst[e];
-    const float norm = 1.0f / sqrtf(a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[dst]);
-    const float* xp = a.x + (int64_t)src * a.d_in + blk.x + u * D1;
+template <int L1>
+__device__ __forceinline__ void lit_block_wfree(const LitArgs& a, const WFreeArgs& wf, const int4 blk, const int4* __restrict__ paths,
+                                                int cu, int64_t e0, float* __restrict__ wt) {
+    constexpr int D1 = 2 * L1 + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int epw = 256 / cu;                       // edges of this workgroup
+    const int n_et = (epw + 15) >> 4;               // 16-edge MFMA tiles
+    const int n_mt = (blk.y + 15) >> 4;             // 16-column tiles per path
+    const int tw = (blk.y + 3) & ~3;                // floats of the LDS tile per (edge, path)
+    const int p0 = blk.w & 0xffff, np = blk.w >> 16;
+    const int per_round = max(1, (wf.lds_floats / epw - 4) / tw);
+    const int row = min(np, per_round) * tw + 4;    // floats per edge row of the tile (+4: rows start on different banks)
+    // phase-2 role
+    const int el = tid / cu, u = tid - el * cu;
+    const int64_t e = e0 + el;
+    const bool active = e < a.E && u < blk.y;
+    int src = 0, dst = 0;
+    float norm = 0.0f;
     float x[D1], dxi[D1];
 #pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        x[i] = xp[i];
-        dxi[i] = 0.0f;
+    for (int i = 0; i < D1; ++i) x[i] = 0.0f, dxi[i] = 0.0f;
+    if (active) {
+        src = a.src[e], dst = a.dst[e];
+        norm = 1.0f / sqrtf(a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[dst]);
+        const float* xp = a.x + (int64_t)src * a.d_in + blk.x + u * D1;
+#pragma unroll
+        for (int i = 0; i < D1; ++i) x[i] = xp[i];
     }
     const float* grow = a.g_agg + (int64_t)dst * a.d_mid;
-    const float* yrow = a.sh + e * a.sh_stride;
-    const int p0 = blk.w & 0xffff, np = blk.w >> 16;
-    for (int p = p0; p < p0 + np; ++p) {
-        const int4 pth = paths[p];
-        switch (pth.x) {   // uniform over the block: every thread of the launch row walks the same list
-            case -1: break;
-            MATTEN_LIT_CASE(1, 0, 1) MATTEN_LIT_CASE(1, 1, 0) MATTEN_LIT_CASE(1, 1, 1) MATTEN_LIT_CASE(1, 1, 2) MATTEN_LIT_CASE(1, 2, 1) MATTEN_LIT_CASE(1, 2, 2) MATTEN_LIT_CASE(1, 2, 3) MATTEN_LIT_CASE(1, 3, 2) MATTEN_LIT_CASE(1, 3, 3) MATTEN_LIT_CASE(1, 3, 4) MATTEN_LIT_CASE(1, 4, 3) MATTEN_LIT_CASE(1, 4, 4)
-            default: break;
+    const float* yrow = a.sh + (active ? e : 0) * a.sh_stride;
+    const wf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < np; r0 += per_round) {
+        const int nr = min(per_round, np - r0);
+        // ---- phase 1: jobs (edge tile, path, column tile) dealt to the four waves in batches of WF_BATCH: all of a batch's
+        // operand loads (two 16-byte A pieces per job, the edge tile's two B pieces) go out before the first matrix instruction
+        const int jobs_per_et = nr * n_mt, n_jobs = n_et * jobs_per_et;
+        for (int j0 = wave * WF_BATCH; j0 < n_jobs; j0 += 4 * WF_BATCH) {
+            wf_f16x8 ah[WF_BATCH], al[WF_BATCH], bh[WF_BATCH], bl[WF_BATCH];
+            float inv[WF_BATCH];
+            int dst_off[WF_BATCH];
+#pragma unroll
+            for (int q = 0; q < WF_BATCH; ++q) {
+                const int j = min(j0 + q, n_jobs - 1);
+                const int et = j / jobs_per_et, jj = j - et * jobs_per_et;
+                const int pl = jj / n_mt, mt = jj - pl * n_mt;
+                const int4 pth = paths[p0 + r0 + pl];
+                const int64_t er = min(e0 + 16 * et + c, a.E - 1);
+                const _Float16* fr = wf.frag + ((int64_t)(pth.w + mt) * 64 + lane) * 16;
+                ah[q] = *reinterpret_cast<const wf_f16x8*>(fr);
+                al[q] = *reinterpret_cast<const wf_f16x8*>(fr + 8);
+                bh[q] = *reinterpret_cast<const wf_f16x8*>(wf.h2s + er * 64 + g * 8);
+                bl[q] = *reinterpret_cast<const wf_f16x8*>(wf.h2s + er * 64 + 32 + g * 8);
+                inv[q] = wf.w_inv[p0 + r0 + pl];
+                const int col = 16 * mt + 4 * g;
+                dst_off[q] = (j0 + q < n_jobs && 16 * et + c < epw && col < tw) ? (16 * et + c) * row + pl * tw + col : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < WF_BATCH; ++q) {
+                wf_f32x4 dl = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q], bh[q], zero, 0, 0, 0);
+                wf_f32x4 dh = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], bh[q], zero, 0, 0, 0);
+                dl = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q], bl[q], dl, 0, 0, 0);
+                const wf_f32x4 w4 = (dh + (1.0f / 2048.0f) * dl) * inv[q];
+                if (dst_off[q] >= 0) *reinterpret_cast<wf_f32x4*>(wt + dst_off[q]) = w4;
+            }
         }
-    }
-    float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
-#pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        if (a.dx_per_edge) dxp[i] = norm * dxi[i];   // summed per source node in a fixed order by rows_segment_sum_kernel
-        else if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
-    }
-}
-
-
-__device__ __forceinline__ void lit_block_2(const LitArgs& a, const int4 blk, const int4* __restrict__ paths, int64_t e, int u) {
-    constexpr int D1 = 5;
-    const int src = a.src[e], dst = a.dst[e];
-    const float norm = 1.0f / sqrtf(a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[dst]);
-    const float* xp = a.x + (int64_t)src * a.d_in + blk.x + u * D1;
-    float x[D1], dxi[D1];
-#pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        x[i] = xp[i];
-        dxi[i] = 0.0f;
-    }
-    const float* grow = a.g_agg + (int64_t)dst * a.d_mid;
-    const float* yrow = a.sh + e * a.sh_stride;
-    const int p0 = blk.w & 0xffff, np = blk.w >> 16;
-    for (int p = p0; p < p0 + np; ++p) {
-        const int4 pth = paths[p];
-        switch (pth.x) {   // uniform over the block: every thread of the launch row walks the same list
-            case -1: break;
-            MATTEN_LIT_CASE(2, 0, 2) MATTEN_LIT_CASE(2, 1, 1) MATTEN_LIT_CASE(2, 1, 2) MATTEN_LIT_CASE(2, 1, 3) MATTEN_LIT_CASE(2, 2, 0) MATTEN_LIT_CASE(2, 2, 1) MATTEN_LIT_CASE(2, 2, 2) MATTEN_LIT_CASE(2, 2, 3) MATTEN_LIT_CASE(2, 2, 4) MATTEN_LIT_CASE(2, 3, 1) MATTEN_LIT_CASE(2, 3, 2) MATTEN_LIT_CASE(2, 3, 3) MATTEN_LIT_CASE(2, 3, 4) MATTEN_LIT_CASE(2, 4, 2) MATTEN_LIT_CASE(2, 4, 3) MATTEN_LIT_CASE(2, 4, 4)
-            default: break;
+        __syncthreads();
+        // ---- phase 2: the literal adjoint with w from the tile
+        if (active) {
+            for (int pl = 0; pl < nr; ++pl) {
+                const int4 pth = paths[p0 + r0 + pl];
+                lit_one_path<L1>(a, pth, wt[el * row + pl * tw + u], e, u, x, grow, yrow, norm, dxi);
+            }
         }
+        __syncthreads();   // the next round overwrites the tile
     }
-    float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
+    if (active) {
+        float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
 #pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        if (a.dx_per_edge) dxp[i] = norm * dxi[i];   // summed per source node in a fixed order by rows_segment_sum_kernel
-        else if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
-    }
-}
-
-
-__device__ __forceinline__ void lit_block_3(const LitArgs& a, const int4 blk, const int4* __restrict__ paths, int64_t e, int u) {
-    constexpr int D1 = 7;
-    const int src = a.src[e], dst = a.dst[e];
-    const float norm = 1.0f / sqrtf(a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[dst]);
-    const float* xp = a.x + (int64_t)src * a.d_in + blk.x + u * D1;
-    float x[D1], dxi[D1];
-#pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        x[i] = xp[i];
-        dxi[i] = 0.0f;
-    }
-    const float* grow = a.g_agg + (int64_t)dst * a.d_mid;
-    const float* yrow = a.sh + e * a.sh_stride;
-    const int p0 = blk.w & 0xffff, np = blk.w >> 16;
-    for (int p = p0; p < p0 + np; ++p) {
-        const int4 pth = paths[p];
-        switch (pth.x) {   // uniform over the block: every thread of the launch row walks the same list
-            case -1: break;
-            MATTEN_LIT_CASE(3, 0, 3) MATTEN_LIT_CASE(3, 1, 2) MATTEN_LIT_CASE(3, 1, 3) MATTEN_LIT_CASE(3, 1, 4) MATTEN_LIT_CASE(3, 2, 1) MATTEN_LIT_CASE(3, 2, 2) MATTEN_LIT_CASE(3, 2, 3) MATTEN_LIT_CASE(3, 2, 4) MATTEN_LIT_CASE(3, 3, 0) MATTEN_LIT_CASE(3, 3, 1) MATTEN_LIT_CASE(3, 3, 2) MATTEN_LIT_CASE(3, 3, 3) MATTEN_LIT_CASE(3, 3, 4) MATTEN_LIT_CASE(3, 4, 1) MATTEN_LIT_CASE(3, 4, 2) MATTEN_LIT_CASE(3, 4, 3) MATTEN_LIT_CASE(3, 4, 4)
-            default: break;
+        for (int i = 0; i < D1; ++i) {
+            if (a.dx_per_edge) dxp[i] = norm * dxi[i];
+            else if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
         }
-    }
-    float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
-#pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        if (a.dx_per_edge) dxp[i] = norm * dxi[i];   // summed per source node in a fixed order by rows_segment_sum_kernel
-        else if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
-    }
-}
-
-
-__device__ __forceinline__ void lit_block_4(const LitArgs& a, const int4 blk, const int4* __restrict__ paths, int64_t e, int u) {
-    constexpr int D1 = 9;
-    const int src = a.src[e], dst = a.dst[e];
-    const float norm = 1.0f / sqrtf(a.avg_nn > 0.0f ? a.avg_nn : a.num_neigh[dst]);
-    const float* xp = a.x + (int64_t)src * a.d_in + blk.x + u * D1;
-    float x[D1], dxi[D1];
-#pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        x[i] = xp[i];
-        dxi[i] = 0.0f;
-    }
-    const float* grow = a.g_agg + (int64_t)dst * a.d_mid;
-    const float* yrow = a.sh + e * a.sh_stride;
-    const int p0 = blk.w & 0xffff, np = blk.w >> 16;
-    for (int p = p0; p < p0 + np; ++p) {
-        const int4 pth = paths[p];
-        switch (pth.x) {   // uniform over the block: every thread of the launch row walks the same list
-            case -1: break;
-            MATTEN_LIT_CASE(4, 0, 4) MATTEN_LIT_CASE(4, 1, 3) MATTEN_LIT_CASE(4, 1, 4) MATTEN_LIT_CASE(4, 2, 2) MATTEN_LIT_CASE(4, 2, 3) MATTEN_LIT_CASE(4, 2, 4) MATTEN_LIT_CASE(4, 3, 1) MATTEN_LIT_CASE(4, 3, 2) MATTEN_LIT_CASE(4, 3, 3) MATTEN_LIT_CASE(4, 3, 4) MATTEN_LIT_CASE(4, 4, 0) MATTEN_LIT_CASE(4, 4, 1) MATTEN_LIT_CASE(4, 4, 2) MATTEN_LIT_CASE(4, 4, 3) MATTEN_LIT_CASE(4, 4, 4)
-            default: break;
-        }
-    }
-    float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
-#pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        if (a.dx_per_edge) dxp[i] = norm * dxi[i];   // summed per source node in a fixed order by rows_segment_sum_kernel
-        else if (dxi[i] != 0.0f) atomicAdd(dxp + i, norm * dxi[i]);
     }
 }
 
@@ -1315,11 +1314,37 @@ __global__ __launch_bounds__(256) void tp_backward_lit_kernel(LitArgs a, const i
     const int u = (int)(idx - e * cu);
     if (e >= a.E || u >= blk.y) return;
     switch (blk.z) {
-        case 0: lit_block_0(a, blk, paths, e, u); break;
-        case 1: lit_block_1(a, blk, paths, e, u); break;
-        case 2: lit_block_2(a, blk, paths, e, u); break;
-        case 3: lit_block_3(a, blk, paths, e, u); break;
-        case 4: lit_block_4(a, blk, paths, e, u); break;
+        case 0: lit_block<0>(a, blk, paths, e, u); break;
+        case 1: lit_block<1>(a, blk, paths, e, u); break;
+        case 2: lit_block<2>(a, blk, paths, e, u); break;
+        case 3: lit_block<3>(a, blk, paths, e, u); break;
+        case 4: lit_block<4>(a, blk, paths, e, u); break;
+        default: break;
+    }
+}
+
+// the same grid; every thread of a workgroup stays to the end (barriers)
+__global__ __launch_bounds__(256) void tp_backward_lit_wfree_kernel(LitArgs a, WFreeArgs wf, const int4* __restrict__ blocks,
+                                                                    int n_blocks, const int4* __restrict__ paths) {
+    extern __shared__ __attribute__((aligned(16))) float wt[];
+    int b = 0, cu = 1;
+    int64_t first = 0;
+    for (;; ++b) {
+        cu = 1;
+        while (cu < blocks[b].y) cu <<= 1;
+        const int64_t n = (a.E * cu + 255) / 256;
+        if (b + 1 >= n_blocks || (int64_t)blockIdx.x < first + n) break;
+        first += n;
+    }
+    const int4 blk = blocks[b];
+    const int64_t e0 = ((int64_t)blockIdx.x - first) * (256 / cu);
+    if (e0 >= a.E) return;   // (workgroup-uniform: the excess workgroups behind the last block)
+    switch (blk.z) {
+        case 0: lit_block_wfree<0>(a, wf, blk, paths, cu, e0, wt); break;
+        case 1: lit_block_wfree<1>(a, wf, blk, paths, cu, e0, wt); break;
+        case 2: lit_block_wfree<2>(a, wf, blk, paths, cu, e0, wt); break;
+        case 3: lit_block_wfree<3>(a, wf, blk, paths, cu, e0, wt); break;
+        case 4: lit_block_wfree<4>(a, wf, blk, paths, cu, e0, wt); break;
         default: break;
     }
 }
@@ -1354,6 +1379,49 @@ extern "C" int matten_tp_backward_lit(const float* x, int64_t d_in, const void* 
     LitArgs a{x, w_edge, sh_sorted, src_sorted, dst_sorted, g_agg, num_neigh, dx_edges ? dx_edges : dx, dw, n_edges, (int)d_in,
               (int)w_ld, (int)sh_stride, (int)d_mid, (int)dw_ld, edge_is_bf16, avg_num_neighbors, dx_edges ? 1 : 0};
     tp_backward_lit_kernel<<<(unsigned)gx, 256, 0, stream>>>(a, (const int4*)blocks, (int)n_blocks, (const int4*)paths);
+    MATTEN_LAUNCH_CHECK();
+    if (dx_edges && n_nodes > 0) {
+        if (matten_cdiv(n_nodes * d_in, 256) >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+        rows_segment_sum_kernel<<<(unsigned)matten_cdiv(n_nodes * d_in, 256), 256, 0, stream>>>(dx_edges, (int)d_in, out_ptr,
+                                                                                              out_perm, n_nodes, dx);
+        MATTEN_LAUNCH_CHECK();
+    }
+    return MATTEN_OK;
+}
+
+// matten_tp_backward_lit without w[E, W]: the weights are re-evaluated per workgroup on the matrix cores from the hidden
+// features (see lit_block_wfree).  paths[p].w = first A-fragment tile of path p; frag / w_inv from matten_split_a_tiles over one
+// pseudo-entry per path (words 5, 6, 7 = w_off, first tile, ceil(mul / 16)) on the last radial layer in REFERENCE column order.
+extern "C" int matten_tp_backward_lit_wfree(const float* x, int64_t d_in, const uint16_t* h2s, const uint16_t* frag,
+                                            const float* w_inv, const float* sh_sorted, int64_t sh_stride,
+                                            const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* blocks,
+                                            int64_t n_blocks, int64_t sum_lanes, const int32_t* paths, int64_t n_paths,
+                                            const float* g_agg, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
+                                            int64_t n_edges, float* dx, void* dw, int64_t dw_ld, int edge_is_bf16,
+                                            int64_t n_nodes, const int32_t* out_ptr, const int32_t* out_perm, float* dx_edges,
+                                            int64_t lds_floats, matten_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_edges < 0 || d_in <= 0 || n_blocks <= 0 || n_blocks > 65535 || n_paths <= 0 || d_mid <= 0 || sum_lanes <= 0 ||
+        sum_lanes > 256 * n_blocks || dw_ld <= 0 || lds_floats < 512 || lds_floats > 15 * 1024)
+        return MATTEN_EINVAL;
+    if (dx_edges && (!out_ptr || !out_perm || n_nodes < 0)) return MATTEN_EINVAL;
+    if (n_edges == 0) {
+        if (dx_edges && n_nodes > 0) {
+            if (!dx) return MATTEN_EINVAL;
+            if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n_nodes * (size_t)d_in, stream) != hipSuccess) return MATTEN_ELAUNCH;
+        }
+        return MATTEN_OK;
+    }
+    if (!x || !h2s || !frag || !w_inv || !sh_sorted || !src_sorted || !dst_sorted || !blocks || !paths || !g_agg || !dx || !dw)
+        return MATTEN_EINVAL;
+    if (!(avg_num_neighbors > 0.0f) && !num_neigh) return MATTEN_EINVAL;
+    const int64_t gx = matten_cdiv(n_edges * sum_lanes, 256) + n_blocks;
+    if (gx >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
+    LitArgs a{x, nullptr, sh_sorted, src_sorted, dst_sorted, g_agg, num_neigh, dx_edges ? dx_edges : dx, dw, n_edges, (int)d_in,
+              0, (int)sh_stride, (int)d_mid, (int)dw_ld, edge_is_bf16, avg_num_neighbors, dx_edges ? 1 : 0};
+    WFreeArgs wf{(const _Float16*)h2s, (const _Float16*)frag, w_inv, (int)lds_floats};
+    tp_backward_lit_wfree_kernel<<<(unsigned)gx, 256, sizeof(float) * (size_t)lds_floats, stream>>>(
+        a, wf, (const int4*)blocks, (int)n_blocks, (const int4*)paths);
     MATTEN_LAUNCH_CHECK();
     if (dx_edges && n_nodes > 0) {
         if (matten_cdiv(n_nodes * d_in, 256) >= ((int64_t)1 << 31)) return MATTEN_EINVAL;

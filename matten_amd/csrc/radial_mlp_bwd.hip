@@ -715,7 +715,7 @@ __global__ void split_a_tiles_kernel(const float* __restrict__ w2p, int w_pad, c
     float amax = 0.0f;
     for (int i = threadIdx.x; i < HID * ncol; i += blockDim.x) {
         const int k = i / ncol, q = i - k * ncol;
-        amax = fmaxf(amax, fabsf(w2p[(int64_t)k * w_pad + w_base + q]));
+        if (w_base + q < w_pad) amax = fmaxf(amax, fabsf(w2p[(int64_t)k * w_pad + w_base + q]));   // (a tile may reach past the last column)
     }
     red[threadIdx.x] = amax;
     __syncthreads();
@@ -735,7 +735,8 @@ __global__ void split_a_tiles_kernel(const float* __restrict__ w2p, int w_pad, c
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
-            const float v = w2p[(int64_t)k * w_pad + w_base + 16 * mt + c] * sc;
+            const int col = w_base + 16 * mt + c;
+            const float v = col < w_pad ? w2p[(int64_t)k * w_pad + col] * sc : 0.0f;
             const float hi = fabsf(v) < tiny ? 0.0f : (float)(_Float16)v;
             float lo = (v - hi) * 2048.0f;
             lo = fabsf(lo) < tiny ? 0.0f : lo;

@@ -295,7 +295,7 @@ class UVUTensorProduct(torch.nn.Module):
             gentries=self.plan.group_entries, gumap=self.plan.fused_unit_map,
             bw_col_meta=self.plan.bw_col_meta, bw_nnz_ijk=self.plan.bw_nnz_ijk, bw_nnz_c=self.plan.bw_nnz_c,
             bw_in_ptr=self.plan.bw_in_ptr, bw_in_cols=self.plan.bw_in_cols,
-            bw_blocks=self.plan.bw_blocks, bw_paths=self.plan.bw_paths,
+            bw_blocks=self.plan.bw_blocks, bw_paths=self.plan.bw_paths, bw_w_entries=self.plan.bw_w_entries,
             fused_cols=self.plan.fused_cols,
         )
 

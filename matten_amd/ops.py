@@ -670,18 +670,43 @@ def tp_backward(x, w_edge, sh_sorted, src_sorted, dst_sorted, col_meta, nnz_ijk,
     return dx, dw
 
 
+def split_a_tiles_dev(w2p, entries, n_tiles: int, h_scale=None):
+    """-> (frag [n_tiles, 64, 16] fp16, scale_inv [n_entries]): matten_split_a_tiles on the device, no host read (the values of
+    split_a_tiles; h_scale = the [s, 1/s] pair of matten_radial_h_scale folds 1/s into scale_inv)"""
+    lib = _lib.load()
+    w2p = _need(w2p, torch.float32, "w2p")
+    entries = _need(entries, torch.int32, "entries")
+    frag = torch.empty(n_tiles, 64, 16, dtype=torch.float16, device=w2p.device)
+    inv = torch.empty(entries.shape[0], dtype=torch.float32, device=w2p.device)
+    _lib.check(lib.matten_split_a_tiles(_ptr(w2p), w2p.shape[1], _ptr(entries), entries.shape[0], _ptr(h_scale), _ptr(frag),
+                                        _ptr(inv), _stream()), "matten_split_a_tiles")
+    return frag, inv
+
+
 def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths, sum_lanes: int, g_agg,
-                    avg_num_neighbors: float, num_neigh=None, out_csr=None, blocks_cover_input: bool = True):
+                    avg_num_neighbors: float, num_neigh=None, out_csr=None, blocks_cover_input: bool = True, wfree=None,
+                    dw_shape=None, lds_floats: int = 4096):
     """the adjoint of tp_backward with literal-coefficient coupling code (include/matten_hip.h matten_tp_backward_lit;
     tables plan.bw_blocks / bw_paths) -> (dx [N,d_in], dw [E, ld of w_edge]).
     out_csr = (out_ptr [N+1] i32, out_perm [E] i32): sorted-edge indices grouped by SOURCE node -- dx is then summed per
-    node in that fixed order (bitwise reproducible) instead of through atomics."""
+    node in that fixed order (bitwise reproducible) instead of through atomics.
+    wfree = (h2s [E, 2, 32] fp16, frag, w_inv) with w_edge None: the weights are re-evaluated inside the kernel on the matrix
+    cores (matten_tp_backward_lit_wfree; frag / w_inv from split_a_tiles_dev over plan.bw_w_entries); dw_shape = ((E, ld), dtype)."""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
-    w_edge = _edge_dtype(w_edge, "w_edge")
     g_agg = _need(g_agg, torch.float32, "grad agg")
     N, d_in = x.shape
-    E = w_edge.shape[0]
+    if wfree is not None:
+        if w_edge is not None or dw_shape is None:
+            raise ValueError("wfree: pass w_edge=None and dw_shape=((E, ld), dtype)")
+        h2s, frag, w_inv = (_need(t, dt, n) for t, dt, n in zip(wfree, (torch.float16, torch.float16, torch.float32),
+                                                                ("h2s", "frag", "w_inv")))
+        (E, dw_ld), dw_dtype = dw_shape
+        if h2s.shape != (E, 2, 32) or w_inv.numel() != paths.shape[0]:
+            raise ValueError("wfree: h2s must be [E, 2, 32] and w_inv hold one value per path")
+    else:
+        w_edge = _edge_dtype(w_edge, "w_edge")
+        E, dw_ld, dw_dtype = w_edge.shape[0], w_edge.shape[1], w_edge.dtype
     if out_csr is not None:
         out_ptr, out_perm = (_need(t, torch.int32, n) for t, n in zip(out_csr, ("out_ptr", "out_perm")))
         dx = torch.empty(N, d_in, dtype=torch.float32, device=x.device)
@@ -691,9 +716,19 @@ def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths,
         dx = torch.zeros(N, d_in, dtype=torch.float32, device=x.device)
     # columns no path writes (the pad up to the row stride) must not hold NaN for the MLP adjoint's masked reads: they are
     # masked by a select there, so plain empty storage is fine
-    dw = torch.empty(E, w_edge.shape[1], dtype=w_edge.dtype, device=x.device)
+    dw = torch.empty(E, dw_ld, dtype=dw_dtype, device=x.device)
     if num_neigh is not None:
         num_neigh = _need(num_neigh, torch.float32, "num_neigh")
+    if wfree is not None:
+        with _timed(f"tp_backward/d_mid={g_agg.shape[1]}/d_in={d_in}"):
+            rc = lib.matten_tp_backward_lit_wfree(_ptr(x), d_in, _ptr(h2s), _ptr(frag), _ptr(w_inv), _ptr(sh_sorted),
+                                                  sh_sorted.shape[1], _ptr(src_sorted), _ptr(dst_sorted), _ptr(blocks),
+                                                  blocks.shape[0], int(sum_lanes), _ptr(paths), paths.shape[0], _ptr(g_agg),
+                                                  g_agg.shape[1], float(avg_num_neighbors or 0.0), _ptr(num_neigh), E, _ptr(dx),
+                                                  _ptr(dw), dw_ld, int(dw_dtype == torch.bfloat16), N, _ptr(out_ptr),
+                                                  _ptr(out_perm), _ptr(dx_edges), int(lds_floats), _stream())
+        _lib.check(rc, "matten_tp_backward_lit_wfree")
+        return dx, dw
     with _timed(f"tp_backward/d_mid={g_agg.shape[1]}/d_in={d_in}"):
         rc = lib.matten_tp_backward_lit(_ptr(x), d_in, _ptr(w_edge), w_edge.shape[1], _ptr(sh_sorted), sh_sorted.shape[1],
                                         _ptr(src_sorted), _ptr(dst_sorted), _ptr(blocks), blocks.shape[0], int(sum_lanes),

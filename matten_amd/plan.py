@@ -233,7 +233,11 @@ class UVUPlan:
     # literal-coefficient adjoint (matten_tp_backward_lit): input blocks and their path lists
     bw_blocks: np.ndarray = None      # int32 [n_blocks, 4] {x_off, mul, l1, first path | n_paths << 16}
     bw_sum_lanes: int = 0             # sum of the blocks' mul rounded up to a power of two (matten_tp_backward_lit's launch)
-    bw_paths: np.ndarray = None       # int32 [n_paths, 4] {l1*25 + l2*5 + l3, w_off, out_off, 0}
+    bw_paths: np.ndarray = None       # int32 [n_paths, 4] {l1*25 + l2*5 + l3, w_off, out_off, first A tile (bw_w_entries)}
+    bw_w_entries: np.ndarray = None   # int32 [n_paths, 32]: one pseudo group entry per path for matten_split_a_tiles (words 5, 6, 7 =
+                                      # w_off, first tile, ceil(mul / 16)): the w-free adjoint's A fragments in reference column order
+    bw_a_tiles: int = 0               # tiles in all of them
+    bw_wfree_lds_floats: int = 4096   # LDS floats per workgroup of matten_tp_backward_lit_wfree (its widest block in one round, capped)
     bw_max_mul: int = 0
 
 
@@ -483,12 +487,17 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         for u in range(p.mul):
             col_meta[p.w_off + u] = (p.x_off + u * d1, p.out_off + u * d3, b0, cnt | (sh_offs[p.l2] << 16))
     # literal adjoint: per input block its paths (the path list is generated block by block already)
-    bw_blocks, bw_paths = [], []
+    bw_blocks, bw_paths, bw_w_entries, bw_a_tiles = [], [], [], 0
     for i_in1, plist in by_block.items():
         bw_blocks.append((plist[0].x_off, plist[0].mul, plist[0].l1, len(bw_paths) | (len(plist) << 16)))
         assert len(plist) < 32768 and len(bw_paths) < 65536
         for pth in plist:
-            bw_paths.append((pth.l1 * 25 + pth.l2 * 5 + pth.l3, pth.w_off, pth.out_off, 0))
+            n_mt = -(-pth.mul // 16)
+            bw_paths.append((pth.l1 * 25 + pth.l2 * 5 + pth.l3, pth.w_off, pth.out_off, bw_a_tiles))
+            ent = [0] * 32
+            ent[5], ent[6], ent[7] = pth.w_off, bw_a_tiles, n_mt
+            bw_w_entries.append(ent)
+            bw_a_tiles += n_mt
     # weight columns grouped by the input channel they read (stable: reference column order inside a group)
     in_order = np.argsort(col_meta[:, 0], kind="stable")
     xb_sorted = col_meta[in_order, 0]
@@ -497,6 +506,8 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
     return UVUPlan(
         bw_blocks=np.array(bw_blocks, dtype=np.int32).reshape(-1, 4), bw_paths=np.array(bw_paths, dtype=np.int32).reshape(-1, 4),
         bw_max_mul=max(b[1] for b in bw_blocks),
+        bw_w_entries=np.array(bw_w_entries, dtype=np.int32).reshape(-1, 32), bw_a_tiles=bw_a_tiles,
+        bw_wfree_lds_floats=_bw_wfree_lds(bw_blocks),
         bw_sum_lanes=sum(1 << max(0, (int(b[1]) - 1).bit_length()) for b in bw_blocks),
         bw_in_ptr=bw_in_ptr, bw_in_cols=in_order.astype(np.int32),
         bw_col_meta=col_meta.astype(np.int32), bw_nnz_ijk=np.array(nnz_ijk, dtype=np.uint8).reshape(-1, 4),
@@ -841,6 +852,16 @@ class AggLinearPlan:
 
 
 AGG_GATE_SETS = 3   # == matten_agg_linear_gate_sets(): table rows of lin2 that may hold gate scalars
+
+
+def _bw_wfree_lds(bw_blocks, cap: int = 4096) -> int:
+    """LDS floats per workgroup of the w-free adjoint: (256 / lanes per edge) edges x (paths x columns rounded to 4, + 4) for
+    the block that needs most, between 512 and `cap` (blocks that need more walk their paths in rounds)"""
+    need = 512
+    for _x, mul, _l, w in bw_blocks:
+        cu = 1 << max(0, (int(mul) - 1).bit_length())
+        need = max(need, (256 // cu) * ((int(w) >> 16) * ((int(mul) + 3) // 4 * 4) + 4))
+    return int(min(cap, -(-need // 64) * 64))
 
 
 def plan_agg_gate(ap: "AggLinearPlan", gate: "GatePlan") -> Optional[np.ndarray]:

@@ -716,6 +716,23 @@ def test_training_on_the_production_tensor_product_kernel(golden_dir, monkeypatc
         grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters()}
     for k in grads["fused"]:
         _close(grads["fused"][k], grads["paths"][k], 2e-3, f"fused vs default grad {k}")
+    # the fused mode's adjoint re-evaluates w on the matrix cores inside its workgroups (matten_tp_backward_lit_wfree, split
+    # fp16 like the forward); with autograd.W_FREE_ADJOINT off it reads a w[E, W] that matten_radial_mlp wrote on the fp32
+    # matrix instruction: same gradients to the split's rounding, and the w-free ones equal their own repeat bit for bit
+    from matten_amd import autograd as mag
+
+    monkeypatch.setenv("MATTEN_TRAIN_TP", "fused")
+    for flag in (False, True):
+        monkeypatch.setattr(mag, "W_FREE_ADJOINT", flag)
+        _, model = build_pair(LMAX2, ds, randomize_bn=True)
+        model.train()
+        out = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+        torch.nn.functional.mse_loss(out, target.to(DEV)).backward()
+        for k, p in model.named_parameters():
+            if flag:
+                assert torch.equal(p.grad, grads["fused"][k]), k
+            else:
+                _close(p.grad, grads["fused"][k], 1e-3, f"w-free vs materialised-w adjoint grad {k}")
     # the default ("auto") takes the fused forward from nn.utils.TRAIN_FUSED_MIN_EDGES edges on, the path kernels below
     from matten_amd.nn import utils as nnu
 
