@@ -369,12 +369,14 @@ def extras(dev):
     roof_l = None
     if bw_l:
         bm, mm = sum(b for b, _ in bw_l) / len(bw_l), sum(t for _, t in bw_l) / len(bw_l)
-        roof_l = {"kernel": "tp_backward (adjoint of the uvu tensor product: reads w, writes dw; mean over the conv layers)",
+        roof_l = {"kernel": "tp_backward (adjoint of the uvu tensor product, matten_tp_backward_lit_wfree since round 5: w re-evaluated per "
+                            "workgroup on the matrix cores, dw written; mean over the conv layers)",
                   "bound": "hbm", "achieved": bm / (mm * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                   "frac": bm / (mm * 1e-3) / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_launch": bm,
                   "avg_launch_ms": mm,
                   "contract": "ids 8 + vector 12 + w read 4 W + dw written 4 W + (x, dx rows: 2 d_in; grad rows: d_mid) / deg per "
-                              "(edge, layer)"}
+                              "(edge, layer): the two-kernel architecture's bytes (SURVEY 8d); the w-free kernel reads 128 B of hidden "
+                              "features per edge instead of the 4 W bytes of w"}
     kern_l = {k: v for k, v in ev_l.items() if k.startswith(("tp_backward", "tp_scatter", "radial_mlp", "species_linear_wgrad"))}
     del m_l, opt_l
     # the same large step replayed from a hipGraph with the flat-buffer Adam (no host time between its ~220 launches)
