@@ -392,7 +392,7 @@ int matten_tp_backward_lit(const float* x, int64_t d_in, const void* w_edge, int
                            int64_t n_blocks, int64_t max_mul, const int32_t* paths, int64_t n_paths, const float* g_agg,
                            int64_t d_mid, float avg_num_neighbors, const float* num_neigh, int64_t n_edges, float* dx,
                            void* dw, int64_t dw_ld, int edge_is_bf16, int64_t n_nodes, const int32_t* out_ptr,
-                           const int32_t* out_perm, float* dx_edges, matten_stream_t stream);
+                           const int32_t* out_perm, float* dx_edges, int max_l, matten_stream_t stream);
 /* matten_tp_backward_lit for training on the fused forward: w[E, W] is never read -- every workgroup re-evaluates the weights of
  * its (edges, input block) on the matrix cores from h2s[E, 2, 32] (matten_radial_hidden: the rows the forward used) and the
  * A fragments of the last radial layer in REFERENCE column order: frag / w_inv = matten_split_a_tiles over one pseudo-entry per
@@ -404,7 +404,9 @@ int matten_tp_backward_lit_wfree(const float* x, int64_t d_in, const uint16_t* h
                                  const int32_t* paths, int64_t n_paths, const float* g_agg, int64_t d_mid,
                                  float avg_num_neighbors, const float* num_neigh, int64_t n_edges, float* dx, void* dw,
                                  int64_t dw_ld, int edge_is_bf16, int64_t n_nodes, const int32_t* out_ptr,
-                                 const int32_t* out_perm, float* dx_edges, int64_t lds_floats, matten_stream_t stream);
+                                 const int32_t* out_perm, float* dx_edges, int64_t lds_floats, int max_l, matten_stream_t stream);
+/* max_l (both functions): the largest degree among the paths' (l1, l2, l3); <= 2 selects the instantiation without the l = 3, 4
+ * coupling code (about half the registers, twice the resident waves). */
 /* lds_floats (512 .. 15360): floats of LDS per workgroup for its [edge][path][column] weight tile; a block whose paths do not
  * fit takes them in rounds (plan.bw_wfree_lds_floats = what the widest block needs in one round, capped at 4096). */
 

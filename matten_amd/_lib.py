@@ -63,9 +63,9 @@ SIGNATURES = {
     "matten_tp_backward": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, P, c_int64, P, P, P, c_int64, c_float, P, c_int64, P, P, c_int64,
                                    P, P, c_int64, c_int, P]),
     "matten_tp_backward_lit": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, P, c_int64, c_int64, P, c_int64, P, c_int64, c_float,
-                                       P, c_int64, P, P, c_int64, c_int, c_int64, P, P, P, P]),
+                                       P, c_int64, P, P, c_int64, c_int, c_int64, P, P, P, c_int, P]),
     "matten_tp_backward_lit_wfree": (c_int, [P, c_int64, P, P, P, P, c_int64, P, P, P, c_int64, c_int64, P, c_int64, P, c_int64, c_float,
-                                             P, c_int64, P, P, c_int64, c_int, c_int64, P, P, P, c_int64, P]),
+                                             P, c_int64, P, P, c_int64, c_int, c_int64, P, P, P, c_int64, c_int, P]),
     "matten_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float, P]),
     "matten_species_linear_wgrad": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int64, P, c_int64, c_int64, P, P, P]),
     "matten_gate_bwd": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, P, P]),

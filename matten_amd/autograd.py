@@ -160,7 +160,7 @@ class TensorProductScatterFn(torch.autograd.Function):
             out_csr = ctx.out_csr if os.environ.get("MATTEN_TP_BWD_DX", "ordered") != "atomic" else None
             dx, dw = ops.tp_backward_lit(x, w_edge, sh, src, dst, mod._tables.get("bw_blocks", dev),
                                          mod._tables.get("bw_paths", dev), mod.plan.bw_sum_lanes, g.contiguous(), ctx.avg,
-                                         ctx.num_neigh, out_csr=out_csr,
+                                         ctx.num_neigh, out_csr=out_csr, max_l=mod.plan.bw_max_l,
                                          blocks_cover_input=int(mod.plan.bw_blocks[:, 1].dot(2 * mod.plan.bw_blocks[:, 2] + 1))
                                          == mod.plan.d_in)
             return dx, dw, None, None, None, None
@@ -230,13 +230,13 @@ class FusedTensorProductFn(torch.autograd.Function):
                                          mod._tables.get("bw_paths", dev), mod.plan.bw_sum_lanes, g.contiguous(), ctx.avg,
                                          ctx.num_neigh, out_csr=out_csr, blocks_cover_input=covered, wfree=(h2p, frag, inv),
                                          dw_shape=((geom.shape[0], w2p.shape[1]), EDGE_STORAGE_DTYPE),
-                                         lds_floats=mod.plan.bw_wfree_lds_floats)
+                                         lds_floats=mod.plan.bw_wfree_lds_floats, max_l=mod.plan.bw_max_l)
             ctx.h2p = None
         else:
             w_edge = ops.radial_mlp(geom, *ctx.rbf, w0p, w1p, w2p, out_dtype=EDGE_STORAGE_DTYPE)   # transient
             dx, dw = ops.tp_backward_lit(x, w_edge, sh, src, dst, mod._tables.get("bw_blocks", dev),
                                          mod._tables.get("bw_paths", dev), mod.plan.bw_sum_lanes, g.contiguous(), ctx.avg,
-                                         ctx.num_neigh, out_csr=out_csr, blocks_cover_input=covered)
+                                         ctx.num_neigh, out_csr=out_csr, blocks_cover_input=covered, max_l=mod.plan.bw_max_l)
             del w_edge
         nb, W = mlp.hs[0], mlp.hs[3]
         d0, d1, d2 = ops.radial_mlp_bwd(geom, *ctx.rbf, w0p, w1p, w2p, W, dw, scales=scales)

@@ -1124,20 +1124,32 @@ __device__ __forceinline__ void lit_path(const LitArgs& a, const int4 pth, float
 #define MATTEN_LIT_LIST_3 MATTEN_LIT_CASE(3, 0, 3) MATTEN_LIT_CASE(3, 1, 2) MATTEN_LIT_CASE(3, 1, 3) MATTEN_LIT_CASE(3, 1, 4) MATTEN_LIT_CASE(3, 2, 1) MATTEN_LIT_CASE(3, 2, 2) MATTEN_LIT_CASE(3, 2, 3) MATTEN_LIT_CASE(3, 2, 4) MATTEN_LIT_CASE(3, 3, 0) MATTEN_LIT_CASE(3, 3, 1) MATTEN_LIT_CASE(3, 3, 2) MATTEN_LIT_CASE(3, 3, 3) MATTEN_LIT_CASE(3, 3, 4) MATTEN_LIT_CASE(3, 4, 1) MATTEN_LIT_CASE(3, 4, 2) MATTEN_LIT_CASE(3, 4, 3) MATTEN_LIT_CASE(3, 4, 4)
 #define MATTEN_LIT_LIST_4 MATTEN_LIT_CASE(4, 0, 4) MATTEN_LIT_CASE(4, 1, 3) MATTEN_LIT_CASE(4, 1, 4) MATTEN_LIT_CASE(4, 2, 2) MATTEN_LIT_CASE(4, 2, 3) MATTEN_LIT_CASE(4, 2, 4) MATTEN_LIT_CASE(4, 3, 1) MATTEN_LIT_CASE(4, 3, 2) MATTEN_LIT_CASE(4, 3, 3) MATTEN_LIT_CASE(4, 3, 4) MATTEN_LIT_CASE(4, 4, 0) MATTEN_LIT_CASE(4, 4, 1) MATTEN_LIT_CASE(4, 4, 2) MATTEN_LIT_CASE(4, 4, 3) MATTEN_LIT_CASE(4, 4, 4)
 
+#define MATTEN_LIT_LIST2_0 MATTEN_LIT_CASE(0, 0, 0) MATTEN_LIT_CASE(0, 1, 1) MATTEN_LIT_CASE(0, 2, 2)
+#define MATTEN_LIT_LIST2_1 MATTEN_LIT_CASE(1, 0, 1) MATTEN_LIT_CASE(1, 1, 0) MATTEN_LIT_CASE(1, 1, 1) MATTEN_LIT_CASE(1, 1, 2) MATTEN_LIT_CASE(1, 2, 1) MATTEN_LIT_CASE(1, 2, 2)
+#define MATTEN_LIT_LIST2_2 MATTEN_LIT_CASE(2, 0, 2) MATTEN_LIT_CASE(2, 1, 1) MATTEN_LIT_CASE(2, 1, 2) MATTEN_LIT_CASE(2, 2, 0) MATTEN_LIT_CASE(2, 2, 1) MATTEN_LIT_CASE(2, 2, 2)
+
 // one path of an input block for one (edge, channel): dw written, the edge's dx contribution added into dxi
-template <int L1>
+// LMAX = 2: the instantiation for tensor products whose degrees all stay <= 2 (the kernel's registers are those of its widest
+// case: 60 instead of 108, twice the resident waves)
+template <int L1, int LMAX>
 __device__ __forceinline__ void lit_one_path(const LitArgs& a, const int4 pth, float wv, int64_t e, int u,
                                              const float* __restrict__ x, const float* __restrict__ grow,
                                              const float* __restrict__ yrow, float norm, float* __restrict__ dxi) {
     // the code is uniform over the block: every thread of the launch row walks the same list
-    if constexpr (L1 == 0) { switch (pth.x) { MATTEN_LIT_LIST_0 default: break; } }
-    if constexpr (L1 == 1) { switch (pth.x) { MATTEN_LIT_LIST_1 default: break; } }
-    if constexpr (L1 == 2) { switch (pth.x) { MATTEN_LIT_LIST_2 default: break; } }
-    if constexpr (L1 == 3) { switch (pth.x) { MATTEN_LIT_LIST_3 default: break; } }
-    if constexpr (L1 == 4) { switch (pth.x) { MATTEN_LIT_LIST_4 default: break; } }
+    if constexpr (LMAX <= 2) {
+        if constexpr (L1 == 0) { switch (pth.x) { MATTEN_LIT_LIST2_0 default: break; } }
+        if constexpr (L1 == 1) { switch (pth.x) { MATTEN_LIT_LIST2_1 default: break; } }
+        if constexpr (L1 == 2) { switch (pth.x) { MATTEN_LIT_LIST2_2 default: break; } }
+    } else {
+        if constexpr (L1 == 0) { switch (pth.x) { MATTEN_LIT_LIST_0 default: break; } }
+        if constexpr (L1 == 1) { switch (pth.x) { MATTEN_LIT_LIST_1 default: break; } }
+        if constexpr (L1 == 2) { switch (pth.x) { MATTEN_LIT_LIST_2 default: break; } }
+        if constexpr (L1 == 3) { switch (pth.x) { MATTEN_LIT_LIST_3 default: break; } }
+        if constexpr (L1 == 4) { switch (pth.x) { MATTEN_LIT_LIST_4 default: break; } }
+    }
 }
 
-template <int L1>
+template <int L1, int LMAX>
 __device__ __forceinline__ void lit_block(const LitArgs& a, const int4 blk, const int4* __restrict__ paths, int64_t e, int u) {
     constexpr int D1 = 2 * L1 + 1;
     const int src = a.src[e], dst = a.dst[e];
@@ -1155,7 +1167,7 @@ __device__ __forceinline__ void lit_block(const LitArgs& a, const int4 blk, cons
     for (int p = p0; p < p0 + np; ++p) {
         const int4 pth = paths[p];
         const float wv = matten_ld_edge(a.w_edge, e * a.w_ld + pth.y + u, a.edge_bf16);
-        lit_one_path<L1>(a, pth, wv, e, u, x, grow, yrow, norm, dxi);
+        lit_one_path<L1, LMAX>(a, pth, wv, e, u, x, grow, yrow, norm, dxi);
     }
     float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
 #pragma unroll
@@ -1177,7 +1189,10 @@ __device__ __forceinline__ void lit_block(const LitArgs& a, const int4 blk, cons
 // backward (0.36 ms at 293 k edges) and the 4 W bytes per edge of w written and read back; w never exists.
 typedef _Float16 wf_f16x8 __attribute__((ext_vector_type(8)));
 typedef float wf_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int WF_BATCH = 3;            // matrix jobs of a wave whose operand loads are in flight together
+#ifndef WF_BATCH_N
+#define WF_BATCH_N 2
+#endif
+constexpr int WF_BATCH = WF_BATCH_N;   // matrix jobs of a wave whose operand loads are in flight together
 struct WFreeArgs {
     const _Float16* h2s;      // [E, 2, 32]
     const _Float16* frag;     // [n_tiles, 64, 16]: hi(kk 0..7) | lo(kk 0..7) per lane
@@ -1185,7 +1200,7 @@ struct WFreeArgs {
     int lds_floats;           // capacity of the workgroup's tile (plan.bw_wfree_lds_floats: what the widest block needs, capped)
 };
 
-template <int L1>
+template <int L1, int LMAX>
 __device__ __forceinline__ void lit_block_wfree(const LitArgs& a, const WFreeArgs& wf, const int4 blk, const int4* __restrict__ paths,
                                                 int cu, int64_t e0, float* __restrict__ wt) {
     constexpr int D1 = 2 * L1 + 1;
@@ -1198,8 +1213,8 @@ __device__ __forceinline__ void lit_block_wfree(const LitArgs& a, const WFreeArg
     const int p0 = blk.w & 0xffff, np = blk.w >> 16;
     const int per_round = max(1, (wf.lds_floats / epw - 4) / tw);
     const int row = min(np, per_round) * tw + 4;    // floats per edge row of the tile (+4: rows start on different banks)
-    // phase-2 role
-    const int el = tid / cu, u = tid - el * cu;
+    // phase-2 role; its edge-invariant loads go out in front of phase 1
+    const int el = tid / cu, u = tid & (cu - 1);
     const int64_t e = e0 + el;
     const bool active = e < a.E && u < blk.y;
     int src = 0, dst = 0;
@@ -1219,9 +1234,9 @@ __device__ __forceinline__ void lit_block_wfree(const LitArgs& a, const WFreeArg
     const wf_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int r0 = 0; r0 < np; r0 += per_round) {
         const int nr = min(per_round, np - r0);
-        // ---- phase 1: jobs (edge tile, path, column tile) dealt to the four waves in batches of WF_BATCH: all of a batch's
+        // ---- phase 1: jobs (path, column tile, edge tile) dealt to the four waves in batches of WF_BATCH: all of a batch's
         // operand loads (two 16-byte A pieces per job, the edge tile's two B pieces) go out before the first matrix instruction
-        const int jobs_per_et = nr * n_mt, n_jobs = n_et * jobs_per_et;
+        const int n_jobs = nr * n_mt * n_et;
         for (int j0 = wave * WF_BATCH; j0 < n_jobs; j0 += 4 * WF_BATCH) {
             wf_f16x8 ah[WF_BATCH], al[WF_BATCH], bh[WF_BATCH], bl[WF_BATCH];
             float inv[WF_BATCH];
@@ -1229,7 +1244,7 @@ __device__ __forceinline__ void lit_block_wfree(const LitArgs& a, const WFreeArg
 #pragma unroll
             for (int q = 0; q < WF_BATCH; ++q) {
                 const int j = min(j0 + q, n_jobs - 1);
-                const int et = j / jobs_per_et, jj = j - et * jobs_per_et;
+                const int jj = j / n_et, et = j - jj * n_et;
                 const int pl = jj / n_mt, mt = jj - pl * n_mt;
                 const int4 pth = paths[p0 + r0 + pl];
                 const int64_t er = min(e0 + 16 * et + c, a.E - 1);
@@ -1256,10 +1271,10 @@ __device__ __forceinline__ void lit_block_wfree(const LitArgs& a, const WFreeArg
         if (active) {
             for (int pl = 0; pl < nr; ++pl) {
                 const int4 pth = paths[p0 + r0 + pl];
-                lit_one_path<L1>(a, pth, wt[el * row + pl * tw + u], e, u, x, grow, yrow, norm, dxi);
+                lit_one_path<L1, LMAX>(a, pth, wt[el * row + pl * tw + u], e, u, x, grow, yrow, norm, dxi);
             }
         }
-        __syncthreads();   // the next round overwrites the tile
+        if (r0 + per_round < np) __syncthreads();   // the next round overwrites the tile
     }
     if (active) {
         float* dxp = a.dx + (a.dx_per_edge ? e : (int64_t)src) * a.d_in + blk.x + u * D1;
@@ -1297,6 +1312,7 @@ __global__ void rows_segment_sum_kernel(const float* __restrict__ rows, int d, c
 // The grid is the input blocks' own workgroup ranges (cdiv(E * lanes per edge, 256) each) laid end to end: a 2-D grid sized
 // for the widest block left half of its workgroups without an edge (blocks of 4 channels beside blocks of 32: 100 k
 // empty workgroups per launch at 293 k edges).
+template <int LMAX>
 __global__ __launch_bounds__(256) void tp_backward_lit_kernel(LitArgs a, const int4* __restrict__ blocks, int n_blocks,
                                                               const int4* __restrict__ paths) {
     int b = 0, cu = 1;
@@ -1314,17 +1330,21 @@ __global__ __launch_bounds__(256) void tp_backward_lit_kernel(LitArgs a, const i
     const int u = (int)(idx - e * cu);
     if (e >= a.E || u >= blk.y) return;
     switch (blk.z) {
-        case 0: lit_block<0>(a, blk, paths, e, u); break;
-        case 1: lit_block<1>(a, blk, paths, e, u); break;
-        case 2: lit_block<2>(a, blk, paths, e, u); break;
-        case 3: lit_block<3>(a, blk, paths, e, u); break;
-        case 4: lit_block<4>(a, blk, paths, e, u); break;
+        case 0: lit_block<0, LMAX>(a, blk, paths, e, u); break;
+        case 1: lit_block<1, LMAX>(a, blk, paths, e, u); break;
+        case 2: lit_block<2, LMAX>(a, blk, paths, e, u); break;
+        case 3: if constexpr (LMAX > 2) lit_block<3, LMAX>(a, blk, paths, e, u); break;
+        case 4: if constexpr (LMAX > 2) lit_block<4, LMAX>(a, blk, paths, e, u); break;
         default: break;
     }
 }
 
-// the same grid; every thread of a workgroup stays to the end (barriers)
-__global__ __launch_bounds__(256) void tp_backward_lit_wfree_kernel(LitArgs a, WFreeArgs wf, const int4* __restrict__ blocks,
+// the same grid as tp_backward_lit_kernel; every thread of a workgroup stays to the end (barriers)
+#ifndef WF_MIN_WGS
+#define WF_MIN_WGS 6   // l <= 2 instantiation: six workgroups per CU (<= 80 registers; 7 and 8 spill: 1.82 / 2.68 vs 1.53 ms)
+#endif
+template <int LMAX>
+__global__ __launch_bounds__(256, (LMAX <= 2 ? WF_MIN_WGS : 1)) void tp_backward_lit_wfree_kernel(LitArgs a, WFreeArgs wf, const int4* __restrict__ blocks,
                                                                     int n_blocks, const int4* __restrict__ paths) {
     extern __shared__ __attribute__((aligned(16))) float wt[];
     int b = 0, cu = 1;
@@ -1340,11 +1360,11 @@ __global__ __launch_bounds__(256) void tp_backward_lit_wfree_kernel(LitArgs a, W
     const int64_t e0 = ((int64_t)blockIdx.x - first) * (256 / cu);
     if (e0 >= a.E) return;   // (workgroup-uniform: the excess workgroups behind the last block)
     switch (blk.z) {
-        case 0: lit_block_wfree<0>(a, wf, blk, paths, cu, e0, wt); break;
-        case 1: lit_block_wfree<1>(a, wf, blk, paths, cu, e0, wt); break;
-        case 2: lit_block_wfree<2>(a, wf, blk, paths, cu, e0, wt); break;
-        case 3: lit_block_wfree<3>(a, wf, blk, paths, cu, e0, wt); break;
-        case 4: lit_block_wfree<4>(a, wf, blk, paths, cu, e0, wt); break;
+        case 0: lit_block_wfree<0, LMAX>(a, wf, blk, paths, cu, e0, wt); break;
+        case 1: lit_block_wfree<1, LMAX>(a, wf, blk, paths, cu, e0, wt); break;
+        case 2: lit_block_wfree<2, LMAX>(a, wf, blk, paths, cu, e0, wt); break;
+        case 3: if constexpr (LMAX > 2) lit_block_wfree<3, LMAX>(a, wf, blk, paths, cu, e0, wt); break;
+        case 4: if constexpr (LMAX > 2) lit_block_wfree<4, LMAX>(a, wf, blk, paths, cu, e0, wt); break;
         default: break;
     }
 }
@@ -1356,7 +1376,7 @@ extern "C" int matten_tp_backward_lit(const float* x, int64_t d_in, const void* 
                                       int64_t n_paths, const float* g_agg, int64_t d_mid, float avg_num_neighbors,
                                       const float* num_neigh, int64_t n_edges, float* dx, void* dw, int64_t dw_ld,
                                       int edge_is_bf16, int64_t n_nodes, const int32_t* out_ptr, const int32_t* out_perm,
-                                      float* dx_edges, matten_stream_t stream_) {
+                                      float* dx_edges, int max_l, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || d_in <= 0 || n_blocks <= 0 || n_blocks > 65535 || n_paths <= 0 || d_mid <= 0 || sum_lanes <= 0 ||
         sum_lanes > 4096 * n_blocks || w_ld <= 0 || dw_ld <= 0)
@@ -1378,7 +1398,8 @@ extern "C" int matten_tp_backward_lit(const float* x, int64_t d_in, const void* 
     if (gx >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
     LitArgs a{x, w_edge, sh_sorted, src_sorted, dst_sorted, g_agg, num_neigh, dx_edges ? dx_edges : dx, dw, n_edges, (int)d_in,
               (int)w_ld, (int)sh_stride, (int)d_mid, (int)dw_ld, edge_is_bf16, avg_num_neighbors, dx_edges ? 1 : 0};
-    tp_backward_lit_kernel<<<(unsigned)gx, 256, 0, stream>>>(a, (const int4*)blocks, (int)n_blocks, (const int4*)paths);
+    if (max_l <= 2) tp_backward_lit_kernel<2><<<(unsigned)gx, 256, 0, stream>>>(a, (const int4*)blocks, (int)n_blocks, (const int4*)paths);
+    else tp_backward_lit_kernel<4><<<(unsigned)gx, 256, 0, stream>>>(a, (const int4*)blocks, (int)n_blocks, (const int4*)paths);
     MATTEN_LAUNCH_CHECK();
     if (dx_edges && n_nodes > 0) {
         if (matten_cdiv(n_nodes * d_in, 256) >= ((int64_t)1 << 31)) return MATTEN_EINVAL;
@@ -1399,7 +1420,7 @@ extern "C" int matten_tp_backward_lit_wfree(const float* x, int64_t d_in, const 
                                             const float* g_agg, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
                                             int64_t n_edges, float* dx, void* dw, int64_t dw_ld, int edge_is_bf16,
                                             int64_t n_nodes, const int32_t* out_ptr, const int32_t* out_perm, float* dx_edges,
-                                            int64_t lds_floats, matten_stream_t stream_) {
+                                            int64_t lds_floats, int max_l, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_edges < 0 || d_in <= 0 || n_blocks <= 0 || n_blocks > 65535 || n_paths <= 0 || d_mid <= 0 || sum_lanes <= 0 ||
         sum_lanes > 256 * n_blocks || dw_ld <= 0 || lds_floats < 512 || lds_floats > 15 * 1024)
@@ -1420,8 +1441,12 @@ extern "C" int matten_tp_backward_lit_wfree(const float* x, int64_t d_in, const 
     LitArgs a{x, nullptr, sh_sorted, src_sorted, dst_sorted, g_agg, num_neigh, dx_edges ? dx_edges : dx, dw, n_edges, (int)d_in,
               0, (int)sh_stride, (int)d_mid, (int)dw_ld, edge_is_bf16, avg_num_neighbors, dx_edges ? 1 : 0};
     WFreeArgs wf{(const _Float16*)h2s, (const _Float16*)frag, w_inv, (int)lds_floats};
-    tp_backward_lit_wfree_kernel<<<(unsigned)gx, 256, sizeof(float) * (size_t)lds_floats, stream>>>(
-        a, wf, (const int4*)blocks, (int)n_blocks, (const int4*)paths);
+    if (max_l <= 2)
+        tp_backward_lit_wfree_kernel<2><<<(unsigned)gx, 256, sizeof(float) * (size_t)lds_floats, stream>>>(
+            a, wf, (const int4*)blocks, (int)n_blocks, (const int4*)paths);
+    else
+        tp_backward_lit_wfree_kernel<4><<<(unsigned)gx, 256, sizeof(float) * (size_t)lds_floats, stream>>>(
+            a, wf, (const int4*)blocks, (int)n_blocks, (const int4*)paths);
     MATTEN_LAUNCH_CHECK();
     if (dx_edges && n_nodes > 0) {
         if (matten_cdiv(n_nodes * d_in, 256) >= ((int64_t)1 << 31)) return MATTEN_EINVAL;

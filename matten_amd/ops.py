@@ -685,7 +685,7 @@ def split_a_tiles_dev(w2p, entries, n_tiles: int, h_scale=None):
 
 def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths, sum_lanes: int, g_agg,
                     avg_num_neighbors: float, num_neigh=None, out_csr=None, blocks_cover_input: bool = True, wfree=None,
-                    dw_shape=None, lds_floats: int = 4096):
+                    dw_shape=None, lds_floats: int = 4096, max_l: int = 4):
     """the adjoint of tp_backward with literal-coefficient coupling code (include/matten_hip.h matten_tp_backward_lit;
     tables plan.bw_blocks / bw_paths) -> (dx [N,d_in], dw [E, ld of w_edge]).
     out_csr = (out_ptr [N+1] i32, out_perm [E] i32): sorted-edge indices grouped by SOURCE node -- dx is then summed per
@@ -726,7 +726,7 @@ def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths,
                                                   blocks.shape[0], int(sum_lanes), _ptr(paths), paths.shape[0], _ptr(g_agg),
                                                   g_agg.shape[1], float(avg_num_neighbors or 0.0), _ptr(num_neigh), E, _ptr(dx),
                                                   _ptr(dw), dw_ld, int(dw_dtype == torch.bfloat16), N, _ptr(out_ptr),
-                                                  _ptr(out_perm), _ptr(dx_edges), int(lds_floats), _stream())
+                                                  _ptr(out_perm), _ptr(dx_edges), int(lds_floats), int(max_l), _stream())
         _lib.check(rc, "matten_tp_backward_lit_wfree")
         return dx, dw
     with _timed(f"tp_backward/d_mid={g_agg.shape[1]}/d_in={d_in}"):
@@ -735,7 +735,7 @@ def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths,
                                         _ptr(paths), paths.shape[0], _ptr(g_agg), g_agg.shape[1],
                                         float(avg_num_neighbors or 0.0), _ptr(num_neigh), E, _ptr(dx), _ptr(dw),
                                         dw.shape[1], int(w_edge.dtype == torch.bfloat16), N, _ptr(out_ptr), _ptr(out_perm),
-                                        _ptr(dx_edges), _stream())
+                                        _ptr(dx_edges), int(max_l), _stream())
     _lib.check(rc, "matten_tp_backward_lit")
     return dx, dw
 

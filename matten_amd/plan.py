@@ -237,6 +237,7 @@ class UVUPlan:
     bw_w_entries: np.ndarray = None   # int32 [n_paths, 32]: one pseudo group entry per path for matten_split_a_tiles (words 5, 6, 7 =
                                       # w_off, first tile, ceil(mul / 16)): the w-free adjoint's A fragments in reference column order
     bw_a_tiles: int = 0               # tiles in all of them
+    bw_max_l: int = 4                 # largest degree among the paths' (l1, l2, l3): <= 2 selects the adjoint's small instantiation
     bw_wfree_lds_floats: int = 4096   # LDS floats per workgroup of matten_tp_backward_lit_wfree (its widest block in one round, capped)
     bw_max_mul: int = 0
 
@@ -507,7 +508,7 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         bw_blocks=np.array(bw_blocks, dtype=np.int32).reshape(-1, 4), bw_paths=np.array(bw_paths, dtype=np.int32).reshape(-1, 4),
         bw_max_mul=max(b[1] for b in bw_blocks),
         bw_w_entries=np.array(bw_w_entries, dtype=np.int32).reshape(-1, 32), bw_a_tiles=bw_a_tiles,
-        bw_wfree_lds_floats=_bw_wfree_lds(bw_blocks),
+        bw_wfree_lds_floats=_bw_wfree_lds(bw_blocks), bw_max_l=max(max(p.l1, p.l2, p.l3) for p in paths),
         bw_sum_lanes=sum(1 << max(0, (int(b[1]) - 1).bit_length()) for b in bw_blocks),
         bw_in_ptr=bw_in_ptr, bw_in_cols=in_order.astype(np.int32),
         bw_col_meta=col_meta.astype(np.int32), bw_nnz_ijk=np.array(nnz_ijk, dtype=np.uint8).reshape(-1, 4),
