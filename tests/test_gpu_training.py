@@ -693,6 +693,34 @@ def test_min_max_pooling_forward_and_gradients(golden_dir, reduce):
             _close(named[k].grad, p.grad, 3e-3, f"grad {k}")
 
 
+def test_fused_training_path_with_the_paper_model(golden_dir, monkeypatch):
+    """The l = 3, 4 instantiations of the fused training path (forward on matten_tp_fused, w-free adjoint
+    matten_tp_backward_lit_wfree<4>, blocks whose paths take the LDS tile in rounds) on the paper's lmax-4 model: every gradient
+    against the oracle's autograd and against the path kernels' (materialised w), and equal to its own repeat bit for bit."""
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _graphs(golden_dir, 8)
+    target = torch.randn(len(graphs), 21, generator=torch.Generator().manual_seed(11))
+    grads = {}
+    for mode in ("fused", "paths", "fused"):
+        monkeypatch.setenv("MATTEN_TRAIN_TP", mode)
+        ref, model = build_pair(PAPER, ds, randomize_bn=True)
+        ref.train(), model.train()
+        out = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+        torch.nn.functional.mse_loss(out, target.to(DEV)).backward()
+        g = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        if mode in grads:
+            assert all(torch.equal(g[k], grads[mode][k]) for k in g), "fused-path gradients differ between two evaluations"
+            continue
+        torch.nn.functional.mse_loss(ref.decode(collate(graphs)), target).backward()
+        for k, p in ref.named_parameters():
+            if p.grad is not None:
+                _close(g[k], p.grad, 3e-3, f"[{mode}] grad {k}")
+        grads[mode] = g
+    for k in grads["fused"]:
+        _close(grads["fused"][k], grads["paths"][k], 2e-3, f"fused vs path-kernel grad {k}")
+
+
 def test_training_on_the_production_tensor_product_kernel(golden_dir, monkeypatch):
     """MATTEN_TRAIN_TP=fused: the training forward runs matten_tp_fused (w[E, W] never materialised in the forward, nothing
     per-edge saved for the backward); the backward re-evaluates w per layer.  Forward, every gradient and the parameters
