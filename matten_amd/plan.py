@@ -50,7 +50,34 @@ _GROUP_SCHEMES = {
           2: _moved(2, [(3, 1), (3, 2)]), 3: _moved(3, [(3, 0), (3, 1)]), 4: _moved(4, [(3, 1), (3, 2)])},
 }
 TP_GROUPS_SCHEME = os.environ.get("MATTEN_TP_GROUPS", "D")
-TP_GROUPS = _GROUP_SCHEMES[TP_GROUPS_SCHEME]   # l1 -> [group: [(l2, l3), ...]]
+# ALTERNATIVE groups (generated code like any other; kinds after the regular ones of their l1): taken INSTEAD of the regular
+# groups by an input block all of whose couplings one of them holds.  They are the couplings into EVEN l3 of an odd- / even-
+# parity input block -- what is left of a block when a layer's output is cut down to 0e + 2e + 4e (the last conv layer behind
+# the elasticity read-out): one entry per block chunk instead of two, i.e. half the units (gathers, stage rows, matrix phase,
+# barriers), and no dead weight column in the entry (the regular groups keep zero columns for absent couplings).  Measured
+# and left out: l1 = 3 (its 2x3o + 2x3e blocks share merged four-lane entries, which need ONE list for both parities: nine
+# couplings, 57 accumulators: last layer 0.60 -> 0.635 ms) and l1 = 0 (three couplings instead of five: 0.604 vs 0.610 ms).
+_ALT_GROUPS = {
+    1: [[(1, 0), (1, 2), (3, 2), (3, 4)], [(2, 2), (4, 4)]],
+    2: [[(1, 2), (3, 2), (3, 4)], [(0, 2), (2, 0), (2, 2), (2, 4), (4, 2), (4, 4)]],
+    4: [[(1, 4), (3, 2), (3, 4)], [(0, 4), (2, 2), (2, 4), (4, 0), (4, 2), (4, 4)]],
+}
+TP_ALT_GROUPS = os.environ.get("MATTEN_TP_ALT_GROUPS", "1") != "0"
+TP_GROUPS_REGULAR = {l1: len(g) for l1, g in _GROUP_SCHEMES[TP_GROUPS_SCHEME].items()}   # l1 -> number of regular groups
+# l1 -> [group: [(l2, l3), ...]]: the regular groups, then the alternatives
+TP_GROUPS = {l1: list(g) + (_ALT_GROUPS.get(l1, []) if TP_GROUPS_SCHEME == "D" else [])
+             for l1, g in _GROUP_SCHEMES[TP_GROUPS_SCHEME].items()}
+
+
+def groups_for_block(l1: int, couplings) -> list:
+    """[(group index, couplings of the group)] an input block with these (l2, l3) couplings is contracted by"""
+    n_reg = TP_GROUPS_REGULAR[l1]
+    couplings = set(couplings)
+    if TP_ALT_GROUPS and couplings:
+        for gi in range(n_reg, len(TP_GROUPS[l1])):
+            if couplings <= set(TP_GROUPS[l1][gi]):
+                return [(gi, TP_GROUPS[l1][gi])]
+    return list(enumerate(TP_GROUPS[l1][:n_reg]))
 TP_MAX_COMBOS = 12
 TP_MAX_COLS = int(os.environ.get("MATTEN_TP_MAX_COLS", "64"))  # == matten_tp_max_cols() of the library (-DTPF_MAX_COLS)
 TP_MAX_COLS_L0 = int(os.environ.get("MATTEN_TP_MAX_COLS_L0", "96"))  # scalar input blocks (see plan_uvu); -DTPF_MAX_COLS_L0
@@ -348,14 +375,14 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
         cap = 64
         while cap > 1 and cap * n_combos > limit:
             cap //= 2
-        return cap
+        return min(cap, 16)   # (16 lanes per node at most: short alternative coupling lists would take 32)
 
     def _padding(cols0, cols1):
         """loader-only waves per node tile for this choice"""
         per_class: Dict[int, int] = {}
         for plist in by_block.values():
             l1_, mul_ = plist[0].l1, plist[0].mul
-            for combos_ in TP_GROUPS[l1_]:
+            for _gi, combos_ in groups_for_block(l1_, [(p_.l2, p_.l3) for p_ in plist]):
                 if not any((p_.l2, p_.l3) in combos_ for p_ in plist):
                     continue
                 cap_ = _cap(l1_, len(combos_), cols0, cols1)
@@ -445,7 +472,8 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
             continue
         plist = by_block[i_in1]
         l1, mul = plist[0].l1, plist[0].mul
-        for gi, combos in enumerate(TP_GROUPS[l1]):
+        both = list(plist) + (list(by_block[partner[i_in1]]) if i_in1 in partner else [])
+        for gi, combos in groups_for_block(l1, [(p.l2, p.l3) for p in both]):
             present = {(p.l2, p.l3): p for p in plist if (p.l2, p.l3) in combos}
             todo = [(plist, present)]
             if i_in1 in partner:

@@ -324,6 +324,17 @@ def test_dead_output_elimination_matches_the_full_layer(hp_name, monkeypatch):
         getattr(last.tp.weight_nn, f"layer{i}").weight.numel() for i in (0, 1))   # shared modules only
     kept = _kept_columns(last).to(DEV)
     assert 0 < kept.numel() < last.irreps_out["node_features"].dim
+    if hp_name == "paper":
+        # the view's vector / l = 2 / l = 4 input blocks keep even-l3 couplings only: they run on the ALTERNATIVE coupling groups
+        # (plan._ALT_GROUPS: one entry per block chunk, no dead weight columns), the full layer on the regular ones -- this test
+        # compares the two families of generated code column for column
+        from matten_amd import plan as mplan
+
+        def kinds(p):
+            e = np.asarray(p.group_entries).reshape(-1, 32)
+            return {((int(k) & 255) // mplan.TP_KIND_STRIDE, (int(k) & 255) % mplan.TP_KIND_STRIDE) for k in e[:, 0] if k >= 0}
+        alt = {(l1, gi) for (l1, gi) in kinds(last._view.tp.plan) if gi >= mplan.TP_GROUPS_REGULAR[l1]}
+        assert {l1 for l1, _ in alt} == {1, 2, 4} and not any(gi >= mplan.TP_GROUPS_REGULAR[l1] for l1, gi in kinds(last.tp.plan))
 
     def run(enabled):
         monkeypatch.setattr(pconv, "DEAD_PATH_ELIMINATION", enabled)

@@ -739,3 +739,31 @@ def test_agg_linear_plan_reproduces_lin2_on_the_host():
             ref.weight.copy_(torch.as_tensor(w))
             want = ref(torch.as_tensor(agg), torch.nn.functional.one_hot(torch.as_tensor(species), S).double()).numpy()
         assert np.allclose(out, want, rtol=0, atol=1e-6 * np.abs(want).max()), np.abs(out - want).max()   # (scale is fp32)
+
+
+def test_alternative_coupling_groups_are_taken_only_by_blocks_they_cover():
+    """plan.groups_for_block: an input block runs on ONE alternative group when that group holds all of its couplings (the
+    even-l3 couplings of an odd- / even-parity block: what a layer cut down to 0e + 2e + 4e outputs keeps), on the regular
+    groups otherwise; regular groups partition every coupling of their degree, alternatives come after them in the kind
+    numbering, and the generated header instantiates exactly these kinds."""
+    import re
+    from matten_amd import plan as mplan
+
+    for l1, groups in mplan.TP_GROUPS.items():
+        n_reg = mplan.TP_GROUPS_REGULAR[l1]
+        regular = [c for g in groups[:n_reg] for c in g]
+        every = [(l2, l3) for l2 in range(5) for l3 in range(abs(l1 - l2), min(4, l1 + l2) + 1)]
+        assert sorted(regular) == sorted(every)                       # a partition of the degree's couplings
+        assert len(groups) <= mplan.TP_KIND_STRIDE
+        assert mplan.groups_for_block(l1, every) == list(enumerate(groups[:n_reg]))
+        for gi in range(n_reg, len(groups)):
+            alt = groups[gi]
+            assert all(l3 % 2 == 0 for _, l3 in alt) and len({l2 % 2 for l2, _ in alt}) == 1   # even l3, one parity of l2
+            assert mplan.groups_for_block(l1, alt) == [(gi, alt)]
+            assert mplan.groups_for_block(l1, alt[:1]) == [(gi, alt)]                           # a subset is covered too
+            other = next(c for c in every if c not in alt)
+            assert mplan.groups_for_block(l1, alt + [other]) == list(enumerate(groups[:n_reg]))
+    header = open(os.path.join(ROOT, "matten_amd", "csrc", "cg_gen.h")).read()
+    listed = re.search(r"#define MATTEN_FOR_EACH_GROUP\(X\) (.*)", header).group(1)
+    want = " ".join(f"X({l1}, {gi})" for l1, g in mplan.TP_GROUPS.items() for gi in range(len(g)))
+    assert listed.strip() == want, "cg_gen.h is stale: python matten_amd/csrc/gen_cg.py > matten_amd/csrc/cg_gen.h"
