@@ -772,6 +772,8 @@ template <> struct HotMask<1, 2> { static constexpr unsigned M0 = 0xf, M1 = 0; }
 template <> struct HotMask<1, 3> { static constexpr unsigned M0 = 0x3, M1 = 0; };
 template <> struct HotMask<2, 2> { static constexpr unsigned M0 = 0x7, M1 = 0; };
 template <> struct HotMask<2, 3> { static constexpr unsigned M0 = 0x3f, M1 = 0; };
+template <> struct HotMask<3, 2> { static constexpr unsigned M0 = 0x1f, M1 = 0; };
+template <> struct HotMask<3, 3> { static constexpr unsigned M0 = 0xf, M1 = 0; };
 template <> struct HotMask<4, 2> { static constexpr unsigned M0 = 0x7, M1 = 0; };
 template <> struct HotMask<4, 3> { static constexpr unsigned M0 = 0x3f, M1 = 0; };
 #endif

@@ -55,11 +55,13 @@ TP_GROUPS_SCHEME = os.environ.get("MATTEN_TP_GROUPS", "D")
 # parity input block -- what is left of a block when a layer's output is cut down to 0e + 2e + 4e (the last conv layer behind
 # the elasticity read-out): one entry per block chunk instead of two, i.e. half the units (gathers, stage rows, matrix phase,
 # barriers), and no dead weight column in the entry (the regular groups keep zero columns for absent couplings).  Measured
-# and left out: l1 = 3 (its 2x3o + 2x3e blocks share merged four-lane entries, which need ONE list for both parities: nine
-# couplings, 57 accumulators: last layer 0.60 -> 0.635 ms) and l1 = 0 (three couplings instead of five: 0.604 vs 0.610 ms).
+# and left out: ONE list for both parities of l1 = 3 so that its 2x3o + 2x3e blocks keep their merged four-lane entry (nine
+# couplings, 57 accumulators: last layer 0.60 -> 0.635 ms; the pair runs unmerged on the per-parity lists instead, plan_uvu)
+# and l1 = 0 (three couplings instead of five: 0.604 vs 0.610 ms).
 _ALT_GROUPS = {
     1: [[(1, 0), (1, 2), (3, 2), (3, 4)], [(2, 2), (4, 4)]],
     2: [[(1, 2), (3, 2), (3, 4)], [(0, 2), (2, 0), (2, 2), (2, 4), (4, 2), (4, 4)]],
+    3: [[(1, 2), (1, 4), (3, 0), (3, 2), (3, 4)], [(2, 2), (2, 4), (4, 2), (4, 4)]],
     4: [[(1, 4), (3, 2), (3, 4)], [(0, 4), (2, 2), (2, 4), (4, 0), (4, 2), (4, 4)]],
 }
 TP_ALT_GROUPS = os.environ.get("MATTEN_TP_ALT_GROUPS", "1") != "0"
@@ -420,6 +422,15 @@ def plan_uvu(irreps_in1, irreps_sh, irreps_target) -> UVUPlan:
                 k += 2
             else:
                 k += 1
+    if TP_ALT_GROUPS:
+        # a pair whose halves are EACH covered by an alternative group runs as two plain two-lane entries on those (a merged
+        # entry needs one coupling list for both parities: the regular groups, or a nine-coupling union that measured slower):
+        # last conv layer 0.585 -> 0.521 ms
+        for a_, b_ in list(partner.items()):
+            la = by_block[a_][0].l1
+            own = lambda blk: groups_for_block(la, [(p.l2, p.l3) for p in by_block[blk]])
+            if all(len(own(blk)) == 1 and own(blk)[0][0] >= TP_GROUPS_REGULAR[la] for blk in (a_, b_)):
+                del partner[a_]
     second = set(partner.values())
 
     def add_entry(l1, gi, combos, x_off, u0, mul_c, cu_log2, halves):

@@ -334,7 +334,7 @@ def test_dead_output_elimination_matches_the_full_layer(hp_name, monkeypatch):
             e = np.asarray(p.group_entries).reshape(-1, 32)
             return {((int(k) & 255) // mplan.TP_KIND_STRIDE, (int(k) & 255) % mplan.TP_KIND_STRIDE) for k in e[:, 0] if k >= 0}
         alt = {(l1, gi) for (l1, gi) in kinds(last._view.tp.plan) if gi >= mplan.TP_GROUPS_REGULAR[l1]}
-        assert {l1 for l1, _ in alt} == {1, 2, 4} and not any(gi >= mplan.TP_GROUPS_REGULAR[l1] for l1, gi in kinds(last.tp.plan))
+        assert {l1 for l1, _ in alt} == {1, 2, 3, 4} and not any(gi >= mplan.TP_GROUPS_REGULAR[l1] for l1, gi in kinds(last.tp.plan))
 
     def run(enabled):
         monkeypatch.setattr(pconv, "DEAD_PATH_ELIMINATION", enabled)
