@@ -768,6 +768,9 @@ template <> struct HotMask<0, 0> { static constexpr unsigned M0 = 0x1f, M1 = 0xf
 #if TPF_HOT_ALT
 // the alternative groups (plan._ALT_GROUPS: the even-l3 couplings of an odd- / even-parity block) are taken by blocks that hold
 // ALL their couplings: the full mask at compile time (last conv layer 0.706 -> 0.68 ms with the first of them)
+template <> struct HotMask<0, 1> { static constexpr unsigned M0 = 0x7, M1 = 0; };    // (the lmax-2 lists: 0,1  1,4  2,4)
+template <> struct HotMask<1, 4> { static constexpr unsigned M0 = 0x3f, M1 = 0; };
+template <> struct HotMask<2, 4> { static constexpr unsigned M0 = 0x3f, M1 = 0; };
 template <> struct HotMask<1, 2> { static constexpr unsigned M0 = 0xf, M1 = 0; };
 template <> struct HotMask<1, 3> { static constexpr unsigned M0 = 0x3, M1 = 0; };
 template <> struct HotMask<2, 2> { static constexpr unsigned M0 = 0x7, M1 = 0; };

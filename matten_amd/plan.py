@@ -58,9 +58,13 @@ TP_GROUPS_SCHEME = os.environ.get("MATTEN_TP_GROUPS", "D")
 # and left out: ONE list for both parities of l1 = 3 so that its 2x3o + 2x3e blocks keep their merged four-lane entry (nine
 # couplings, 57 accumulators: last layer 0.60 -> 0.635 ms; the pair runs unmerged on the per-parity lists instead, plan_uvu)
 # and l1 = 0 (three couplings instead of five: 0.604 vs 0.610 ms).
+# The lists of l1 <= 2 end with ALL couplings of degrees <= 2: the groups of an lmax-2 model (configs[3]), whose blocks otherwise
+# sit in the lmax-4 lists with a third to a half of their weight columns dead and, for l1 = 2, in two entries instead of one.
 _ALT_GROUPS = {
-    1: [[(1, 0), (1, 2), (3, 2), (3, 4)], [(2, 2), (4, 4)]],
-    2: [[(1, 2), (3, 2), (3, 4)], [(0, 2), (2, 0), (2, 2), (2, 4), (4, 2), (4, 4)]],
+    0: [[(0, 0), (1, 1), (2, 2)]],
+    1: [[(1, 0), (1, 2), (3, 2), (3, 4)], [(2, 2), (4, 4)], [(0, 1), (1, 0), (1, 1), (1, 2), (2, 1), (2, 2)]],
+    2: [[(1, 2), (3, 2), (3, 4)], [(0, 2), (2, 0), (2, 2), (2, 4), (4, 2), (4, 4)],
+        [(0, 2), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2)]],
     3: [[(1, 2), (1, 4), (3, 0), (3, 2), (3, 4)], [(2, 2), (2, 4), (4, 2), (4, 4)]],
     4: [[(1, 4), (3, 2), (3, 4)], [(0, 4), (2, 2), (2, 4), (4, 0), (4, 2), (4, 4)]],
 }
@@ -76,9 +80,10 @@ def groups_for_block(l1: int, couplings) -> list:
     n_reg = TP_GROUPS_REGULAR[l1]
     couplings = set(couplings)
     if TP_ALT_GROUPS and couplings:
-        for gi in range(n_reg, len(TP_GROUPS[l1])):
-            if couplings <= set(TP_GROUPS[l1][gi]):
-                return [(gi, TP_GROUPS[l1][gi])]
+        cover = [gi for gi in range(n_reg, len(TP_GROUPS[l1])) if couplings <= set(TP_GROUPS[l1][gi])]
+        if cover:
+            gi = min(cover, key=lambda g: (len(TP_GROUPS[l1][g]), g))   # the shortest list that holds them all
+            return [(gi, TP_GROUPS[l1][gi])]
     return list(enumerate(TP_GROUPS[l1][:n_reg]))
 TP_MAX_COMBOS = 12
 TP_MAX_COLS = int(os.environ.get("MATTEN_TP_MAX_COLS", "64"))  # == matten_tp_max_cols() of the library (-DTPF_MAX_COLS)
