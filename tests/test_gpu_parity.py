@@ -1340,22 +1340,27 @@ def test_species_linear_selfcheck_runs_and_detects_a_wrong_result(monkeypatch):
     selfcheck.check_species_linear(DEV)
 
 
-@pytest.mark.parametrize("mode", ["streaming_lin2", "hub_pieces_of_3"])
+@pytest.mark.parametrize("mode", ["streaming_lin2", "hub_pieces_of_3", "fused_training"])
 def test_fuzzed_models_on_poisoned_buffers(mode):
     """tests/fuzz_models.py (random irreps / multiplicities incl. non-powers of two / depth / normalisation on random small
     crystals, product vs oracle) with every torch.empty buffer starting as NaN (NAN_EMPTY=1) and one opt-in or
     size-dependent path forced for every layer and batch size:
       streaming_lin2   component-major neighbour sums + matten_agg_linear (the mode that found the alignment holes of
                        non-power-of-two multiplicities, plan.plan_agg_linear; MATTEN_AGG_KM_MIN_ROWS=0)
-      hub_pieces_of_3  every CSR segment walked in pieces of 3 edges (MATTEN_HUB_SPLIT_LEN=3)"""
+      hub_pieces_of_3  every CSR segment walked in pieces of 3 edges (MATTEN_HUB_SPLIT_LEN=3)
+      fused_training   training forward on matten_tp_fused + the w-free adjoint (MATTEN_TRAIN_TP=fused: the default from 65 536 edges
+                       on) with every parameter gradient against the fp64 oracle -- odd multiplicities, alternative coupling
+                       groups, paths of a block taken in rounds"""
     import subprocess
     import sys
 
     extra = {"streaming_lin2": {"MATTEN_AGG_KM_MIN_ROWS": "0"},
-             "hub_pieces_of_3": {"MATTEN_HUB_SPLIT_LEN": "3"}}[mode]
+             "hub_pieces_of_3": {"MATTEN_HUB_SPLIT_LEN": "3"},
+             "fused_training": {"MATTEN_TRAIN_TP": "fused"}}[mode]
     env = dict(os.environ, NAN_EMPTY="1", **extra)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_models.py"), "24", "4"], env=env,
+    args = ["16", "7", "grad"] if mode == "fused_training" else ["24", "4"]
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_models.py"), *args], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
