@@ -240,6 +240,9 @@ int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s, const flo
 int matten_tp_max_cols(void);   /* weight columns (mul * couplings) a group entry of matten_tp_fused may have */
 int matten_tp_max_cols_l0(void);   /* the same for entries of scalar (l1 = 0) input blocks */
 int matten_tp_max_cols_l1(void);   /* ... and of vector (l1 = 1) input blocks */
+/* 31-bit hash of the coupling-group lists the library's generated coupling code (csrc/cg_gen.h) was built for; the host plans
+ * entries for the lists of matten_amd/plan.py (plan.tp_groups_hash) and refuses a library built for others. */
+int matten_tp_groups_hash(void);
 
 /* ------------------------------------------------------------------------------------------
  * FullyConnectedTensorProduct(x, one_hot(species)) == species-indexed per-irrep linear
@@ -404,10 +407,13 @@ int matten_tp_backward_lit_wfree(const float* x, int64_t d_in, const uint16_t* h
                                  const int32_t* paths, int64_t n_paths, const float* g_agg, int64_t d_mid,
                                  float avg_num_neighbors, const float* num_neigh, int64_t n_edges, float* dx, void* dw,
                                  int64_t dw_ld, int edge_is_bf16, int64_t n_nodes, const int32_t* out_ptr,
-                                 const int32_t* out_perm, float* dx_edges, int64_t lds_floats, int max_l, matten_stream_t stream);
+                                 const int32_t* out_perm, float* dx_edges, int64_t lds_floats, int max_l, int max_mul,
+                                 matten_stream_t stream);
+/* max_mul (w-free only): the channel count of the widest block; a workgroup holds 256 / (lanes per edge) edges, so blocks of more
+ * than 256 channels are refused (MATTEN_EINVAL) -- such a layer runs matten_tp_backward_lit on a materialised w. */
 /* max_l (both functions): the largest degree among the paths' (l1, l2, l3); <= 2 selects the instantiation without the l = 3, 4
  * coupling code (about half the registers, twice the resident waves). */
-/* lds_floats (512 .. 15360): floats of LDS per workgroup for its [edge][path][column] weight tile; a block whose paths do not
+/* lds_floats (2048 .. 15360): floats of LDS per workgroup for its [edge][path][column] weight tile; a block whose paths do not
  * fit takes them in rounds (plan.bw_wfree_lds_floats = what the widest block needs in one round, capped at 4096). */
 
 /* adjoint of matten_species_linear w.r.t. the packed weights (the adjoint w.r.t. x is matten_species_linear

@@ -14,7 +14,7 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmatten_hip.so")
 
-ABI_VERSION = 43
+ABI_VERSION = 44
 
 # name -> (restype, argtypes); must match include/matten_hip.h
 P = c_void_p
@@ -47,6 +47,7 @@ SIGNATURES = {
     "matten_tp_max_cols": (c_int, []),
     "matten_tp_max_cols_l0": (c_int, []),
     "matten_tp_max_cols_l1": (c_int, []),
+    "matten_tp_groups_hash": (c_int, []),
     "matten_tp_fused": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_float, P, P, P, P, P]),
     "matten_species_linear": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
     "matten_species_linear_rows": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
@@ -65,7 +66,7 @@ SIGNATURES = {
     "matten_tp_backward_lit": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, P, c_int64, c_int64, P, c_int64, P, c_int64, c_float,
                                        P, c_int64, P, P, c_int64, c_int, c_int64, P, P, P, c_int, P]),
     "matten_tp_backward_lit_wfree": (c_int, [P, c_int64, P, P, P, P, c_int64, P, P, P, c_int64, c_int64, P, c_int64, P, c_int64, c_float,
-                                             P, c_int64, P, P, c_int64, c_int, c_int64, P, P, P, c_int64, c_int, P]),
+                                             P, c_int64, P, P, c_int64, c_int, c_int64, P, P, P, c_int64, c_int, c_int, P]),
     "matten_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float, P]),
     "matten_species_linear_wgrad": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int64, P, c_int64, c_int64, P, P, P]),
     "matten_gate_bwd": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, P, P]),

@@ -205,7 +205,9 @@ class FusedTensorProductFn(torch.autograd.Function):
         w0p, w1p, w2p, hs, frag, inv = ops.fused_operands(w0, w1, w2, mlp.pack_scales(), mod._tables.get("fused_cols", dev),
                                                           gent, p.fused_a_tiles, r0, r1, mlp.act_cst)
         h2p = ops.radial_hidden(data[DataKey.AMD_GEOM], int(nb), r0, r1, w0p, w1p, hs)
-        if W_FREE_ADJOINT:   # the hidden features (128 B per edge) are what the backward re-evaluates w from
+        # the hidden features (128 B per edge) are what the backward re-evaluates w from; a layer with an input block wider
+        # than the w-free kernel's workgroup (ops.WFREE_MAX_MUL channels) keeps the adjoint on a materialised w instead
+        if W_FREE_ADJOINT and p.bw_max_mul <= ops.WFREE_MAX_MUL:
             ctx.h2p, ctx.hs = h2p, hs
         return ops.tp_fused(x, h2p, w2p, data[DataKey.AMD_SH], data[DataKey.AMD_ROWPTR], data[DataKey.AMD_SRC], gent,
                             mod._tables.get("gumap", dev), len(p.fused_unit_map), p.fused_lds_floats_per_wave, p.d_mid, avg,
@@ -230,8 +232,9 @@ class FusedTensorProductFn(torch.autograd.Function):
                                          mod._tables.get("bw_paths", dev), mod.plan.bw_sum_lanes, g.contiguous(), ctx.avg,
                                          ctx.num_neigh, out_csr=out_csr, blocks_cover_input=covered, wfree=(h2p, frag, inv),
                                          dw_shape=((geom.shape[0], w2p.shape[1]), EDGE_STORAGE_DTYPE),
-                                         lds_floats=mod.plan.bw_wfree_lds_floats, max_l=mod.plan.bw_max_l)
-            ctx.h2p = None
+                                         lds_floats=mod.plan.bw_wfree_lds_floats, max_l=mod.plan.bw_max_l,
+                                         max_mul=mod.plan.bw_max_mul)
+            # (h2p stays on the ctx until autograd releases it: a second backward under retain_graph takes the same route)
         else:
             w_edge = ops.radial_mlp(geom, *ctx.rbf, w0p, w1p, w2p, out_dtype=EDGE_STORAGE_DTYPE)   # transient
             dx, dw = ops.tp_backward_lit(x, w_edge, sh, src, dst, mod._tables.get("bw_blocks", dev),

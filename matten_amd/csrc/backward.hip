@@ -1357,6 +1357,7 @@ __global__ __launch_bounds__(256, (LMAX <= 2 ? WF_MIN_WGS : 1)) void tp_backward
         first += n;
     }
     const int4 blk = blocks[b];
+    if (cu > 256) return;    // (the entry point refuses max_mul > 256; a table that lies about it computes nothing rather than dividing by zero)
     const int64_t e0 = ((int64_t)blockIdx.x - first) * (256 / cu);
     if (e0 >= a.E) return;   // (workgroup-uniform: the excess workgroups behind the last block)
     switch (blk.z) {
@@ -1420,10 +1421,13 @@ extern "C" int matten_tp_backward_lit_wfree(const float* x, int64_t d_in, const 
                                             const float* g_agg, int64_t d_mid, float avg_num_neighbors, const float* num_neigh,
                                             int64_t n_edges, float* dx, void* dw, int64_t dw_ld, int edge_is_bf16,
                                             int64_t n_nodes, const int32_t* out_ptr, const int32_t* out_perm, float* dx_edges,
-                                            int64_t lds_floats, int max_l, matten_stream_t stream_) {
+                                            int64_t lds_floats, int max_l, int max_mul, matten_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    // max_mul: a workgroup is 256 threads = (256 / lanes per edge) edges, so a block wider than 256 channels has no edge per
+    // workgroup (the materialised-w adjoint takes such a layer).  lds_floats >= 2048: the narrowest blocks put 256 edges in
+    // a workgroup with rows of round4(mul) + 4 floats each (1 channel: 256 x 8), and every block needs at least one path per round.
     if (n_edges < 0 || d_in <= 0 || n_blocks <= 0 || n_blocks > 65535 || n_paths <= 0 || d_mid <= 0 || sum_lanes <= 0 ||
-        sum_lanes > 256 * n_blocks || dw_ld <= 0 || lds_floats < 512 || lds_floats > 15 * 1024)
+        sum_lanes > 256 * n_blocks || dw_ld <= 0 || lds_floats < 2048 || lds_floats > 15 * 1024 || max_mul < 1 || max_mul > 256)
         return MATTEN_EINVAL;
     if (dx_edges && (!out_ptr || !out_perm || n_nodes < 0)) return MATTEN_EINVAL;
     if (n_edges == 0) {

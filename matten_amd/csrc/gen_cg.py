@@ -123,7 +123,7 @@ def emit_triple2(l1, l2, l3, out):
 
 
 # l2 ranges fused into one "group" per input block: single source of truth is matten_amd/plan.py
-from matten_amd.plan import TP_GROUPS as GROUPS, TP_MAX_COMBOS as MAX_COMBOS  # noqa: E402
+from matten_amd.plan import TP_GROUPS as GROUPS, TP_MAX_COMBOS as MAX_COMBOS, tp_groups_hash  # noqa: E402
 
 
 def emit_group(l1, gi, combos, out):
@@ -279,6 +279,7 @@ def main():
     out.append("")
     out.append(f"constexpr int GROUP_MAX_COMBOS = {MAX_COMBOS};")
     out.append("constexpr int GROUP_KIND_STRIDE = 8;  // kind = l1 * GROUP_KIND_STRIDE + group index")
+    out.append(f"constexpr int GROUPS_HASH = {tp_groups_hash()};  // plan.tp_groups_hash() of the lists below (matten_tp_groups_hash)")
     out.append("template <int L1, int G> struct Group;")
     out.append("#define MATTEN_FOR_EACH_GROUP(X) " + " ".join(
         f"X({l1}, {gi})" for l1, ranges in GROUPS.items() for gi in range(len(ranges))))

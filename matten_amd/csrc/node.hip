@@ -213,4 +213,4 @@ extern "C" int matten_dense_rows(const float* x, int64_t n_in, const float* q, i
     return MATTEN_OK;
 }
 
-extern "C" int matten_abi_version(void) { return 43; }
+extern "C" int matten_abi_version(void) { return 44; }

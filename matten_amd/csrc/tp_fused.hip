@@ -596,4 +596,5 @@ extern "C" int matten_tp_fused(const float* x, int64_t d_in, const uint16_t* h2s
 extern "C" int matten_tp_max_cols(void) { return TPF_MAX_COLS; }
 extern "C" int matten_tp_max_cols_l0(void) { return TPF_MAX_COLS_L0; }
 extern "C" int matten_tp_max_cols_l1(void) { return TPF_MAX_COLS_L1; }
+extern "C" int matten_tp_groups_hash(void) { return matten::GROUPS_HASH; }
 

@@ -12,7 +12,9 @@ of the forward -- the species / edge_index range check of ``SpeciesEmbedding`` -
 capture and switched off inside it.  Replayed batches are therefore trusted by default (the kernels clamp bad ids:
 memory-safe, but the result of a malformed batch is meaningless); pass ``validate=True`` to ``step`` / ``__call__`` to
 read the flag word the captured forward rewrites on every replay (one host sync after the replay) and get the same
-exception the eager path raises.
+exception the eager path raises.  A batch that carries its own CSR (the device graph builder's `_amd_perm` / `_amd_rowptr` /
+`_amd_src`) is trusted beyond that: the CSR is not re-derived from edge_index, so `validate=True` vouches for the species
+ids only; every replayed batch must hold exactly the tensors of the construction batch (checked, ValueError).
 
 Construction runs `warmup` real optimisation steps on the construction batch (allocator pools, lazily built tables,
 optimiser state).  Model parameters, buffers (BatchNorm running statistics) and the optimiser state are snapshotted
@@ -49,6 +51,28 @@ def _raise_for_flags(embeds, batch) -> None:
     for m in embeds:
         if hasattr(m, "raise_for_last_flags"):
             m.raise_for_last_flags(n_nodes)
+
+
+def _copy_batch(static: Dict, batch: Dict, what: str) -> None:
+    """copy a replayed batch into the captured buffers.  The batch must hold EXACTLY the tensors the capture saw: a batch of
+    the device graph builder carries its destination-sorted CSR (_amd_perm / _amd_rowptr / _amd_src), which the captured
+    forward then reads instead of rebuilding it -- a replayed batch without those keys would silently run on the
+    construction batch's CSR against its own edge_index (and one with extra keys has tensors the graph never reads)."""
+    have = {k for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    want = {k for k, v in static.items() if isinstance(v, torch.Tensor)}
+    if have != want:
+        raise ValueError(f"the captured {what} was built on a batch with tensors {sorted(want)}; this batch "
+                         f"{'lacks ' + str(sorted(want - have)) if want - have else ''}"
+                         f"{' and ' if (want - have and have - want) else ''}"
+                         f"{'adds ' + str(sorted(have - want)) if have - want else ''}: replay batches of the same builder "
+                         f"(after editing edge_index, drop the _amd_* keys from the CONSTRUCTION batch too and capture again)")
+    for k in want:
+        s, v = static[k], batch[k]
+        if s.shape != v.shape or s.dtype != v.dtype:
+            raise ValueError(f"batch['{k}'] is {tuple(v.shape)} {v.dtype}, the captured {what} takes "
+                             f"{tuple(s.shape)} {s.dtype}: capture one per batch shape")
+        if s.data_ptr() != v.data_ptr():
+            s.copy_(v, non_blocking=True)
 
 
 class GraphedTrainStep:
@@ -112,14 +136,7 @@ class GraphedTrainStep:
         """copy the batch into the captured buffers (shapes must match) and replay; returns the captured loss tensor.
         validate=True: afterwards read the replayed forward's species / edge_index flags (a host sync) and raise like
         the eager path -- the parameters have already been updated with the malformed batch by then."""
-        for k, v in batch.items():
-            if isinstance(v, torch.Tensor):
-                s = self._static[k]
-                if s.shape != v.shape or s.dtype != v.dtype:
-                    raise ValueError(f"batch['{k}'] is {tuple(v.shape)} {v.dtype}, the captured step takes "
-                                     f"{tuple(s.shape)} {s.dtype}: capture one GraphedTrainStep per batch shape")
-                if s.data_ptr() != v.data_ptr():
-                    s.copy_(v, non_blocking=True)
+        _copy_batch(self._static, batch, "step")
         if target.data_ptr() != self._target.data_ptr():
             self._target.copy_(target, non_blocking=True)
         self.graph.replay()
@@ -162,14 +179,7 @@ class GraphedForward:
     def __call__(self, batch: Dict[str, torch.Tensor], validate: bool = False) -> torch.Tensor:
         """NOTE: the species / edge_index range checks ran on the batch given at construction only; a replayed batch is
         trusted (same shapes enforced) unless validate=True (one host sync after the replay, same exceptions as eager)."""
-        for k, v in batch.items():
-            if isinstance(v, torch.Tensor):
-                s = self._static[k]
-                if s.shape != v.shape or s.dtype != v.dtype:
-                    raise ValueError(f"batch['{k}'] is {tuple(v.shape)} {v.dtype}, the captured forward takes "
-                                     f"{tuple(s.shape)} {s.dtype}: capture one GraphedForward per batch shape")
-                if s.data_ptr() != v.data_ptr():
-                    s.copy_(v, non_blocking=True)
+        _copy_batch(self._static, batch, "forward")
         self.graph.replay()
         if validate:
             _raise_for_flags(self._embeds, self._static)

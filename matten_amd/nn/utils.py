@@ -285,6 +285,7 @@ class UVUTensorProduct(torch.nn.Module):
         # "paths" : one wave per path over a materialised w[E, W] (same literals, no fusion, the reference's weight
         #           layout): the training forward, and an independent implementation for the tests
         self.impl = os.environ.get("MATTEN_TP_IMPL", "fused")
+        self._train_tp_auto = None   # MATTEN_TRAIN_TP=auto: the route this module's first training batch chose
         if self.impl not in ("fused", "paths"):
             raise ValueError(f"MATTEN_TP_IMPL={self.impl!r}: 'fused' or 'paths' (the table-driven and block kernels of "
                              "rounds 1-2 were removed in round 4)")
@@ -338,7 +339,14 @@ class UVUTensorProduct(torch.nn.Module):
             ensure_training_edge_tensors(data)
             mode = os.environ.get("MATTEN_TRAIN_TP", "auto")
             n_edges = data[DataKey.AMD_SRC].shape[0]
-            if self.impl == "fused" and (mode == "fused" or (mode == "auto" and n_edges >= TRAIN_FUSED_MIN_EDGES)):
+            if mode == "auto":
+                # decided ONCE per module, by the first training batch it sees: the two routes round differently (fused: split-fp16
+                # matrix products for w, fp32-class; paths: fp32 MFMA), and batches around the threshold must not flip a run
+                # between them from step to step (INTEGRATION.md "Training numerics")
+                if self._train_tp_auto is None:
+                    self._train_tp_auto = "fused" if n_edges >= TRAIN_FUSED_MIN_EDGES else "paths"
+                mode = self._train_tp_auto
+            if self.impl == "fused" and mode == "fused":
                 # forward on the production kernel, w[E, W] re-evaluated per layer inside the backward only: the same step time
                 # as the materialised-w forward at batch 2048 (5.14 vs 5.15 ms) with 4 x E x W x 4 bytes less live memory
                 # between the passes; small batches keep the path kernels (fewer launches: 10 % faster at batch 32)

@@ -460,6 +460,10 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
     if (lib.matten_tp_max_cols() != TP_MAX_COLS or lib.matten_tp_max_cols_l0() != TP_MAX_COLS_L0
             or lib.matten_tp_max_cols_l1() != TP_MAX_COLS_L1):
         raise _lib.MattenHipError("plan.TP_MAX_COLS does not match the library's entry width (-DTPF_MAX_COLS)")
+    from .plan import tp_groups_hash
+    if lib.matten_tp_groups_hash() != tp_groups_hash():
+        raise _lib.MattenHipError("the library's coupling code (cg_gen.h) was generated for other coupling groups than plan.TP_GROUPS "
+                                  "(MATTEN_TP_GROUPS / an interrupted tools/*.sh A/B build?): make -C matten_amd/csrc clean all")
     x = _need_rows(x, torch.float32, "node_features")  # a column slice is fine: d_in below is the row stride
     h2p = _need(h2p, torch.float16, "h2s")
     if h2p.dim() != 3 or h2p.shape[1:] != (2, 32):
@@ -683,15 +687,19 @@ def split_a_tiles_dev(w2p, entries, n_tiles: int, h_scale=None):
     return frag, inv
 
 
+WFREE_MAX_MUL = 256   # widest input block (channels) matten_tp_backward_lit_wfree takes: one workgroup = 256 / lanes-per-edge edges
+
+
 def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths, sum_lanes: int, g_agg,
                     avg_num_neighbors: float, num_neigh=None, out_csr=None, blocks_cover_input: bool = True, wfree=None,
-                    dw_shape=None, lds_floats: int = 4096, max_l: int = 4):
+                    dw_shape=None, lds_floats: int = 4096, max_l: int = 4, max_mul: int = 256):
     """the adjoint of tp_backward with literal-coefficient coupling code (include/matten_hip.h matten_tp_backward_lit;
     tables plan.bw_blocks / bw_paths) -> (dx [N,d_in], dw [E, ld of w_edge]).
     out_csr = (out_ptr [N+1] i32, out_perm [E] i32): sorted-edge indices grouped by SOURCE node -- dx is then summed per
     node in that fixed order (bitwise reproducible) instead of through atomics.
     wfree = (h2s [E, 2, 32] fp16, frag, w_inv) with w_edge None: the weights are re-evaluated inside the kernel on the matrix
-    cores (matten_tp_backward_lit_wfree; frag / w_inv from split_a_tiles_dev over plan.bw_w_entries); dw_shape = ((E, ld), dtype)."""
+    cores (matten_tp_backward_lit_wfree; frag / w_inv from split_a_tiles_dev over plan.bw_w_entries); dw_shape = ((E, ld), dtype);
+    max_mul = plan.bw_max_mul, the widest block's channel count (the library refuses > 256: WFREE_MAX_MUL)."""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
     g_agg = _need(g_agg, torch.float32, "grad agg")
@@ -726,7 +734,8 @@ def tp_backward_lit(x, w_edge, sh_sorted, src_sorted, dst_sorted, blocks, paths,
                                                   blocks.shape[0], int(sum_lanes), _ptr(paths), paths.shape[0], _ptr(g_agg),
                                                   g_agg.shape[1], float(avg_num_neighbors or 0.0), _ptr(num_neigh), E, _ptr(dx),
                                                   _ptr(dw), dw_ld, int(dw_dtype == torch.bfloat16), N, _ptr(out_ptr),
-                                                  _ptr(out_perm), _ptr(dx_edges), int(lds_floats), int(max_l), _stream())
+                                                  _ptr(out_perm), _ptr(dx_edges), int(lds_floats), int(max_l), int(max_mul),
+                                                  _stream())
         _lib.check(rc, "matten_tp_backward_lit_wfree")
         return dx, dw
     with _timed(f"tp_backward/d_mid={g_agg.shape[1]}/d_in={d_in}"):

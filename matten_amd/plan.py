@@ -75,6 +75,16 @@ TP_GROUPS = {l1: list(g) + (_ALT_GROUPS.get(l1, []) if TP_GROUPS_SCHEME == "D" e
              for l1, g in _GROUP_SCHEMES[TP_GROUPS_SCHEME].items()}
 
 
+def tp_groups_hash() -> int:
+    """31-bit FNV-1a of the coupling-group lists: cg_gen.h carries the value it was generated for (matten::GROUPS_HASH), the
+    library exports it (matten_tp_groups_hash) and ops.tp_fused refuses a library whose generated code is for other lists --
+    entries planned on one scheme and contracted by the code of another give wrong sums, silently."""
+    h = 0x811C9DC5
+    for b in repr(sorted((l1, [list(map(tuple, g)) for g in gs]) for l1, gs in TP_GROUPS.items())).encode():
+        h = ((h ^ b) * 0x01000193) & 0xFFFFFFFF
+    return h & 0x7FFFFFFF
+
+
 def groups_for_block(l1: int, couplings) -> list:
     """[(group index, couplings of the group)] an input block with these (l2, l3) couplings is contracted by"""
     n_reg = TP_GROUPS_REGULAR[l1]
@@ -901,8 +911,9 @@ AGG_GATE_SETS = 3   # == matten_agg_linear_gate_sets(): table rows of lin2 that 
 
 def _bw_wfree_lds(bw_blocks, cap: int = 4096) -> int:
     """LDS floats per workgroup of the w-free adjoint: (256 / lanes per edge) edges x (paths x columns rounded to 4, + 4) for
-    the block that needs most, between 512 and `cap` (blocks that need more walk their paths in rounds)"""
-    need = 512
+    the block that needs most, between 2048 (the library's floor: 256 one-channel edges x 8 floats) and `cap` (blocks that
+    need more walk their paths in rounds)"""
+    need = 2048
     for _x, mul, _l, w in bw_blocks:
         cu = 1 << max(0, (int(mul) - 1).bit_length())
         need = max(need, (256 // cu) * ((int(w) >> 16) * ((int(mul) + 3) // 4 * 4) + 4))

@@ -177,6 +177,13 @@ def test_hipgraph_forward_is_bit_identical_to_eager():
         for batch in (a, b, a):
             want = model(dict(batch))[0]["elastic_tensor_full"]
             assert torch.equal(g(batch), want)
+    # a replayed batch must hold exactly the tensors of the construction batch: one that carries its own CSR (device graph
+    # builder) replayed without it -- or the other way round -- would run on a stale CSR (round-5 advisor finding)
+    with_csr = dict(a, _amd_rowptr=torch.zeros(a["pos"].shape[0] + 1, dtype=torch.int32, device=DEV))
+    with pytest.raises(ValueError, match="adds .*_amd_rowptr"):
+        g(with_csr)
+    with pytest.raises(ValueError, match="lacks .*num_neigh"):
+        g({k: v for k, v in a.items() if k != "num_neigh"})
 
 
 def test_hipgraph_forward_above_a_million_edges():
@@ -786,3 +793,49 @@ def test_training_on_the_production_tensor_product_kernel(golden_dir, monkeypatc
     for _ in range(5):
         l1 = float(gs.step(batch, tgt))
     assert np.isfinite(l1) and l1 < l0
+
+
+def test_fused_training_with_an_input_block_wider_than_256_channels(golden_dir, monkeypatch):
+    """A workgroup of matten_tp_backward_lit_wfree holds 256 / (lanes per edge) edges: an input block of more than 256 channels
+    has none (round-5 advisor finding: epw = 0, a division by zero, channels >= 256 never visited -- silently wrong gradients).
+    Such a layer keeps the fused forward and takes the materialised-w adjoint; the library refuses the wide block outright."""
+    from matten_amd import _lib, ops
+    from matten_amd.data.graph import collate
+
+    graphs, ds = _graphs(golden_dir, 4)
+    hp = dict(LMAX2, conv_layer_irreps="288x0e+8x0o+16x1o+4x1e+4x2e", num_layers=2)
+    target = torch.randn(len(graphs), 21, generator=torch.Generator().manual_seed(3))
+    grads = {}
+    for mode in ("fused", "paths"):
+        monkeypatch.setenv("MATTEN_TRAIN_TP", mode)
+        ref, model = build_pair(hp, ds, randomize_bn=True)
+        ref.train(), model.train()
+        convs = [m for m in model.modules() if hasattr(m, "plan") and hasattr(m.plan, "bw_max_mul")]
+        assert max(m.plan.bw_max_mul for m in convs) == 288
+        torch.nn.functional.mse_loss(ref.decode(collate(graphs)), target).backward()
+        out = model(collate(graphs, device=DEV))[0]["elastic_tensor_full"]
+        torch.nn.functional.mse_loss(out, target.to(DEV)).backward()
+        named = dict(model.named_parameters())
+        for k, p in ref.named_parameters():
+            if p.grad is not None:
+                _close(named[k].grad, p.grad, 3e-3, f"[{mode}] grad {k}")
+        grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    for k in grads["fused"]:
+        _close(grads["fused"][k], grads["paths"][k], 2e-3, f"fused vs path-kernel grad {k}")
+    # the entry point itself: max_mul > 256 and a weight tile below the narrowest block's 2048 floats are argument errors
+    wide = next(m for m in convs if m.plan.bw_max_mul == 288)
+    p = wide.plan
+    E, N = 64, 8
+    x = torch.randn(N, p.d_in, device=DEV)
+    args = dict(sh_sorted=torch.randn(E, 32, device=DEV), src_sorted=torch.zeros(E, dtype=torch.int32, device=DEV),
+                dst_sorted=torch.zeros(E, dtype=torch.int32, device=DEV))
+    wfree = (torch.zeros(E, 2, 32, dtype=torch.float16, device=DEV), torch.zeros(p.bw_a_tiles * 64 * 16, dtype=torch.float16, device=DEV),
+             torch.ones(len(p.bw_paths), device=DEV))
+    call = lambda **kw: ops.tp_backward_lit(x, None, args["sh_sorted"], args["src_sorted"], args["dst_sorted"],
+                                            wide._tables.get("bw_blocks", torch.device(DEV)), wide._tables.get("bw_paths", torch.device(DEV)),
+                                            p.bw_sum_lanes, torch.randn(N, p.d_mid, device=DEV), 10.0, wfree=wfree,
+                                            dw_shape=((E, 16 * ((p.weight_numel + 15) // 16)), torch.float32), max_l=p.bw_max_l, **kw)
+    with pytest.raises(_lib.MattenHipError, match="EINVAL"):
+        call(lds_floats=p.bw_wfree_lds_floats, max_mul=p.bw_max_mul)
+    with pytest.raises(_lib.MattenHipError, match="EINVAL"):
+        call(lds_floats=1024, max_mul=256)

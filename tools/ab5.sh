@@ -4,6 +4,7 @@
 #   FLAGSETS="|-DTPF_X=1" REPS=2 KINDS=1 [SRC=agg_linear] bash tools/ab5.sh   (SRC: the source file the flag sets rebuild)
 cd "$GRAFT_REPO_ROOT/matten_amd/csrc" || exit 1
 make -j8 > /dev/null 2>&1
+source ../../tools/_restore.sh
 IFS='|' read -ra SETS <<< "${FLAGSETS:-|}"
 i=0
 for fl in "${SETS[@]}"; do
@@ -32,4 +33,4 @@ if [ -n "$KINDS" ]; then
     i=$((i+1))
   done
 fi
-rm -f build/${SRC:-tp_fused}_*.o; touch ${SRC:-tp_fused}.hip; make -j8 > /dev/null 2>&1
+# (the production library is restored by the EXIT trap of tools/_restore.sh)

@@ -3,6 +3,7 @@
 # times of the tensor-product kernels.   FLAGSETS="|-DX=1" SRC=backward REPS=2 bash tools/ab_train.sh
 cd "$GRAFT_REPO_ROOT/matten_amd/csrc" || exit 1
 make -j8 > /dev/null 2>&1
+source ../../tools/_restore.sh
 SRC=${SRC:-backward}
 IFS='|' read -ra SETS <<< "${FLAGSETS:-|}"
 i=0
@@ -19,4 +20,4 @@ for rep in $(seq 1 ${REPS:-2}); do
     i=$((i+1))
   done
 done
-rm -f build/${SRC}_*.o; touch $SRC.hip; make -j8 > /dev/null 2>&1
+# (the production library is restored by the EXIT trap of tools/_restore.sh)

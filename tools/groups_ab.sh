@@ -3,7 +3,7 @@
 #   SCHEMES="A D" REPS=2 bash tools/groups_ab.sh
 cd "$GRAFT_REPO_ROOT/matten_amd/csrc" || exit 1
 make -j8 > /dev/null 2>&1
-cp cg_gen.h /tmp/cg_gen_saved.h
+source ../../tools/_restore.sh
 for sch in ${SCHEMES:-A D}; do
   MATTEN_TP_GROUPS=$sch python3 gen_cg.py > cg_gen.h
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I../../include -I. -c tp_fused.hip -o build/tp_fused_$sch.o 2>&1 | grep -i error
@@ -23,4 +23,4 @@ if [ -n "$TEST_SCHEME" ]; then
   hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v "_[A-E]\.o" | grep -v calib) -o ../libmatten_hip.so
   cd ../..; MATTEN_TP_GROUPS=$TEST_SCHEME python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "tp_kernels or conv_layers or golden or independence or isolated or dead_output" 2>&1 | tail -4; cd matten_amd/csrc
 fi
-cp /tmp/cg_gen_saved.h cg_gen.h; rm -f build/*_[A-E].o; touch tp_fused.hip tp_path.hip; make -j8 > /dev/null 2>&1
+# (the production library is restored by the EXIT trap of tools/_restore.sh)
