@@ -769,3 +769,65 @@ def test_alternative_coupling_groups_are_taken_only_by_blocks_they_cover():
     listed = re.search(r"#define MATTEN_FOR_EACH_GROUP\(X\) (.*)", header).group(1)
     want = " ".join(f"X({l1}, {gi})" for l1, g in mplan.TP_GROUPS.items() for gi in range(len(g)))
     assert listed.strip() == want, "cg_gen.h is stale: python matten_amd/csrc/gen_cg.py > matten_amd/csrc/cg_gen.h"
+
+
+def test_inline_asm_mfma_objects_keep_their_hazard_distance(tmp_path):
+    """species_linear.hip / species_linear_rows.hip issue v_mfma through inline asm, which the compiler's hazard recogniser
+    cannot see: only their own s_nop pads (and -mllvm -simplifycfg-sink-common=false, csrc/Makefile) keep a store from reading an
+    accumulator too early.  tools/isa_mfma_hazard.py walks the CFG of the gfx950 ISA of the BUILT objects and demands LLVM's own
+    distance (passes + 2 = 10 wait states for the 8-pass fp32 instruction) from every v_mfma to every memory instruction that
+    takes one of its destination registers -- so a ROCm upgrade that reschedules these kernels fails here, at build time,
+    instead of in selfcheck.py on a GPU.  Calibration: the objects whose matrix instructions are builtins (scheduled BY that
+    recogniser) pass at 10 and fail at 11; negative controls: a kernel without the drain, and hand-made instruction lists."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_mfma_hazard as isa
+
+    csrc = os.path.join(ROOT, "matten_amd", "csrc")
+    objs = ["species_linear", "species_linear_rows", "agg_linear"]
+    subprocess.run(["make", "-C", csrc] + [f"build/{o}.o" for o in objs], check=True, capture_output=True)
+    for o, min_mfma in (("species_linear", 1000), ("species_linear_rows", 50)):
+        findings, n_mfma, _ = isa.check_object(os.path.join(csrc, "build", f"{o}.o"))
+        assert n_mfma >= min_mfma, (o, n_mfma)          # the disassembly was really found and parsed
+        assert not findings, "\n".join(findings[:10])
+    # calibration on a compiler-scheduled object: exactly LLVM's distance, no more
+    agg = os.path.join(csrc, "build", "agg_linear.o")
+    assert not isa.check_object(agg, required=10)[0]
+    assert isa.check_object(agg, required=11)[0]
+    # negative control 1: the same inline-asm form without the drain in front of the store
+    src = tmp_path / "bad.hip"
+    src.write_text('''#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void bad(const float* a, const float* b, f32x4* out) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float x = a[threadIdx.x], y = b[threadIdx.x];
+    asm volatile("s_nop 1\\n\\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y));
+#ifdef DRAIN
+    asm volatile("s_nop 15" ::: "memory");
+#endif
+    out[threadIdx.x] = acc;
+}
+''')
+    for flags, want_bad in (([], True), (["-DDRAIN"], False)):
+        obj = str(tmp_path / f"bad{len(flags)}.o")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-c", str(src), "-o", obj] + flags, check=True, capture_output=True)
+        findings, n_mfma, _ = isa.check_object(obj)
+        assert n_mfma == 1 and bool(findings) == want_bad, (flags, findings)
+    # negative control 2: hand-made lists -- the short path is found through a loop's back edge, and an s_nop counts N + 1
+    loop = [(0x00, "v_mov_b32_e32", "v9, 0"),
+            (0x04, "global_store_dwordx4", "v[4:5], v[0:3], off"),           # loop head: reached 2 wait states behind the MFMA
+            (0x0c, "s_nop", "15"),
+            (0x10, "v_mfma_f32_16x16x4_f32", "v[0:3], v8, v9, v[0:3]"),
+            (0x18, "s_cmp_lg_u32", "s0, 0"),
+            (0x1c, "s_cbranch_scc1", str(65536 - 7)),                        # back to 0x04
+            (0x20, "s_nop", "8"),
+            (0x24, "s_endpgm", "")]
+    f = isa.check_function("loop", loop)
+    assert len(f) == 1 and "0x4" in f[0] and "v0 2 wait states" in f[0], f
+    ok = [(a, m, ("15" if (m == "s_nop" and a == 0x20) else o)) for a, m, o in loop]
+    ok[5] = (0x1c, "s_cbranch_scc1", "1")                                    # forward over the s_nop to s_endpgm: no store behind it
+    assert not isa.check_function("ok", ok)
+    spill = [(0x00, "v_mfma_f32_16x16x4_f32", "v[0:3], v8, v9, v[0:3]"), (0x08, "s_nop", "8"),
+             (0x0c, "scratch_store_dword", "off, v2, off offset:8"), (0x14, "s_endpgm", "")]
+    assert len(isa.check_function("spill", spill)) == 1                      # 9 < 10
+    spill[1] = (0x08, "s_nop", "9")
+    assert not isa.check_function("spill", spill)
