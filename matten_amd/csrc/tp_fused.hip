@@ -228,6 +228,22 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
         else if (HM::M1 && ge.mask == HM::M1) run_group_shared<L1, GI, TT, TD, P, HM::M1>(MATTEN_RGS_ARGS); \
         else run_group_shared<L1, GI, TT, TD, P, 0u>(MATTEN_RGS_ARGS); \
     } while (0)
+#if defined(MATTEN_LAB) && defined(TPF_ONLY_VARIANT)
+// tools/isa_mix.py: ONE (kind, walk variant, coupling mask) per object, so that every loop of the disassembly has a name.
+//   TPF_ONLY_VARIANT 0 = paired workgroup, 1 = two MFMA tiles per chunk (32 nodes per wave), 2 = two rows in flight, 3 = plain
+//   TPF_ONLY_MASK    0 = the run-time mask (uniform branch per coupling), else that mask at compile time
+#ifndef TPF_ONLY_MASK
+#define TPF_ONLY_MASK 0
+#endif
+#define MATTEN_RGS_ONLY(L1, GI, TT, TD, P) run_group_shared<L1, GI, TT, TD, P, (unsigned)(TPF_ONLY_MASK)>(MATTEN_RGS_ARGS)
+#define MATTEN_GROUP_CASE_SHARED(L1, GI) \
+    case (L1 * matten::GROUP_KIND_STRIDE + GI): \
+        if (TPF_ONLY_VARIANT == 0) MATTEN_RGS_ONLY(L1, GI, 1, false, true); \
+        else if (TPF_ONLY_VARIANT == 1) MATTEN_RGS_ONLY(L1, GI, 2, false, false); \
+        else if (TPF_ONLY_VARIANT == 2) MATTEN_RGS_ONLY(L1, GI, 1, (TwoDeepOk<L1, GI>::value), false); \
+        else MATTEN_RGS_ONLY(L1, GI, 1, false, false); \
+        break;
+#else
 #define MATTEN_GROUP_CASE_SHARED(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): \
         if (paired) MATTEN_RGS(L1, GI, 1, false, true); \
@@ -235,6 +251,7 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
         else if (TwoDeepOk<L1, GI>::value && nodes_per_wave <= 8 && nodes_per_wave >= TPF_TWO_DEEP_MIN_NPW) MATTEN_RGS(L1, GI, 1, (TwoDeepOk<L1, GI>::value), false); \
         else MATTEN_RGS(L1, GI, 1, false, false); \
         break;
+#endif
 
 #define MATTEN_GROUP_CASE(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): run_group<L1, GI>(a, ge, tile, un.node, lane, un.valid, un.beg, un.deg, un.maxdeg); break;
@@ -246,7 +263,9 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
 #define TPF_TWO_DEEP_MIN_NPW 2   // two neighbour rows in flight for 8, 4 and 2 nodes per wave (2, 4, 8 slots per chunk)
 #endif
 // lab builds (tools/fused_kind_ablate.sh, -DMATTEN_LAB): the kernel compiled for a subset of the group kinds only
-#if defined(MATTEN_LAB) && defined(TPF_ONLY_LIGHT)
+#if defined(MATTEN_LAB) && defined(TPF_ONLY_L1) && defined(TPF_ONLY_GI)
+#define TPF_FOR_EACH_GROUP(X) X(TPF_ONLY_L1, TPF_ONLY_GI)
+#elif defined(MATTEN_LAB) && defined(TPF_ONLY_LIGHT)
 #define TPF_FOR_EACH_GROUP(X) X(0, 0) X(1, 0) X(1, 1)
 #elif defined(MATTEN_LAB) && defined(TPF_ONLY_HEAVY)
 #define TPF_FOR_EACH_GROUP(X) X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(4, 0) X(4, 1)
@@ -292,11 +311,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, TPF_MIN_BLOCKS) void tp_fused
         }
         return;
     }
+#if !(defined(MATTEN_LAB) && defined(TPF_ONLY_VARIANT))
     const UnitNodes un = unit_nodes(a, ge, tile_id, r, lane);
     switch (ge.kind & (KIND_MERGED - 1)) {
         TPF_FOR_EACH_GROUP(MATTEN_GROUP_CASE)
         default: break;
     }
+#endif
 }
 
 // Hidden layers of the radial MLP: rbf(|v|) -> 32 -> 32, written as the split fp16 form h2s [E,2,32] (see header comment).

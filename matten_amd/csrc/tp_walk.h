@@ -438,7 +438,11 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const int CH = 1 << ch_log2;
     // the weight block holds the columns of ALL couplings of the group, [u][c] (absent ones: zero columns)
     const int ncols = ge.mul * NC;
+#if defined(MATTEN_LAB) && defined(TPF_ONLY_MT)
+    const int MT = TPF_ONLY_MT;   // tools/isa_mix.py: the tile count of the one entry kind in the object, at compile time
+#else
     const int MT = (ncols + 15) >> 4;
+#endif
 
     const int j = lane >> cu_log2;
     const int u = lane & (cu - 1);
