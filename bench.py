@@ -63,6 +63,9 @@ def parse():
                     help="REHEARSAL only: every local rank runs on cuda:0 (RCCL refuses two ranks on one device, so this "
                          "needs --backend gloo); exercises the N > 1 branch on a 1-GPU box, measures nothing")
     ap.add_argument("--no-calibration", action="store_true", help="skip the fixed VALU / copy calibration kernels")
+    ap.add_argument("--no-full-layers", action="store_true",
+                    help="skip the second timed loop with the FULL last conv layer (value_full_layers): the counter-collection runs "
+                         "(tools/collect_traffic.sh, collect_valu.sh) must see the launches of the headline loop only")
     return ap.parse_args()
 
 
@@ -939,7 +942,7 @@ def run_rank(args):
 
             gc.collect()               # the captured graph and its private memory pool go NOW, not at some collection
             torch.cuda.empty_cache()   # inside a later timed loop (a one-off ~100 ms stall in the extras otherwise)
-        if laste is not lastf and world == 1 and not distributed:
+        if laste is not lastf and world == 1 and not distributed and not args.no_full_layers:
             # the same workload with the FULL last layer, timed by the same loop at the same steps / warm-up (like for like
             # with SURVEY's 4816 B per edge-TP: path_roofline.frac_full_layers)
             pconv.DEAD_PATH_ELIMINATION = False

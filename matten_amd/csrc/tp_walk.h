@@ -766,6 +766,19 @@ template <int L1, int GI> struct HotMask { static constexpr unsigned M0 = 0, M1 
 #ifndef TPF_NO_HOT_MASKS
 template <> struct HotMask<0, 0> { static constexpr unsigned M0 = 0x1f, M1 = 0xf; };
 #endif
+#ifndef TPF_HOT_ALL
+#define TPF_HOT_ALL 0   // round-6 A/B: the masks of the paper model's full layers at compile time too (one basic block per edge step
+#endif                  // instead of one uniform branch per coupling)
+#if TPF_HOT_ALL
+template <> struct HotMask<1, 0> { static constexpr unsigned M0 = 0x7f, M1 = 0; };
+template <> struct HotMask<1, 1> { static constexpr unsigned M0 = 0x1b, M1 = 0xf; };
+template <> struct HotMask<2, 0> { static constexpr unsigned M0 = 0x7ff, M1 = 0x6ff; };
+template <> struct HotMask<2, 1> { static constexpr unsigned M0 = 0x1d, M1 = 0xf; };
+template <> struct HotMask<3, 0> { static constexpr unsigned M0 = 0x3ff, M1 = 0x37f; };
+template <> struct HotMask<3, 1> { static constexpr unsigned M0 = 0x7f, M1 = 0x3f; };
+template <> struct HotMask<4, 0> { static constexpr unsigned M0 = 0xfb, M1 = 0; };
+template <> struct HotMask<4, 1> { static constexpr unsigned M0 = 0x7d, M1 = 0; };
+#endif
 #ifndef TPF_HOT_ALT
 #define TPF_HOT_ALT 1
 #endif

@@ -42,8 +42,25 @@ from matten_amd import plan as mplan  # noqa: E402
 from matten_amd.o3 import Irreps, wigner_3j  # noqa: E402
 
 CSRC = os.path.join(ROOT, "matten_amd", "csrc")
-IRR = "32x0o+32x0e+16x1o+16x1e+4x2o+4x2e+2x3o+2x3e+2x4e"
-LAYERS = [("layer 1", "16x0e", IRR), ("layer 2", IRR, IRR), ("layer 3", IRR, IRR), ("layer 4 (read-out view)", IRR, "32x0e+4x2e+2x4e")]
+
+
+def bench_layers():
+    """[(name, UVUPlan)] of the four tensor-product launches of the bench forward: the paper model built on the CPU (plans are host
+    tables), the last conv layer as inference runs it (dead-output elimination: the read-out's irreps only)"""
+    from __graft_entry__ import PAPER_HPARAMS
+    from matten_amd.data import synthetic
+    from matten_amd.model_factory.tfn_scalar_tensor import ScalarTensorModel
+
+    ds = {"allowed_species": list(synthetic.FCC_METALS), "average_num_neighbors": 18.0}
+    model = ScalarTensorModel(backbone_hparams=dict(PAPER_HPARAMS), dataset_hparams=ds).eval()
+    convs = [m for m in model.backbone.modules() if type(m).__name__ == "PointConv"]
+    out = []
+    for i, c in enumerate(convs):
+        run = c._view if c._view is not None else c
+        out.append((f"layer {i + 1}" + (" (read-out view)" if run is not c else "") + f": W {run.tp.plan.weight_numel}", run.tp.plan))
+    return out
+
+
 DEG = 18   # fcc-64 at 5 A
 
 
@@ -147,14 +164,16 @@ def natural_loops(ins):
                             body.add(p)
                             stack.append(p)
                 by_head.setdefault(h, set()).update(body)
-    return blocks, [frozenset(b) for b in by_head.values()]
+    return blocks, [frozenset(b) for b in by_head.values()], dom, {frozenset(b): h for h, b in by_head.items()}
 
 
 def chunk_loop_mix(ins, inner_trips):
     """instruction classes of ONE iteration of the chunk loop = the smallest natural loop that holds matrix instructions AND the
-    workgroup barrier; loops inside it (the edge slots of a chunk) weighted by inner_trips.
-    -> (Counter per class, instructions in the body, [inner loop sizes])"""
-    blocks, loops = natural_loops(ins)
+    workgroup barrier; loops inside it (the edge slots of a chunk) weighted by inner_trips.  Around it: the node-group loop of a
+    persistent unit (everything of it outside the chunk loop = per node group: segment bounds, first loads, the agg stores) and the
+    blocks that dominate its header (per unit: entry decode, A fragments).
+    -> (Counter per class per chunk, instructions in the body, [inner loop sizes], Counter per node group, Counter per unit)"""
+    blocks, loops, dom, head_of = natural_loops(ins)
     size = lambda body: sum(blocks[b][1] - blocks[b][0] + 1 for b in body)
     has = lambda body, pred: any(pred(ins[k][1]) for b in body for k in range(blocks[b][0], blocks[b][1] + 1))
     cand = [L for L in loops if has(L, lambda m: m.startswith("v_mfma")) and has(L, lambda m: m == "s_barrier")]
@@ -168,7 +187,19 @@ def chunk_loop_mix(ins, inner_trips):
         w = inner_trips if any(b in L for L in inner) else 1
         for k in range(blocks[b][0], blocks[b][1] + 1):
             mix[classify(ins[k][1])] += w
-    return mix, size(chunk), [size(L) for L in inner]
+    outer = [L for L in cand if chunk < L]
+    group, unit = Counter(), Counter()
+    if outer:
+        rep = min(outer, key=size)
+        for b in rep - chunk:
+            for k in range(blocks[b][0], blocks[b][1] + 1):
+                group[classify(ins[k][1])] += 1
+        h = head_of[rep]
+        for b in range(len(blocks)):
+            if b != h and (dom[h] >> b) & 1:
+                for k in range(blocks[b][0], blocks[b][1] + 1):
+                    unit[classify(ins[k][1])] += 1
+    return mix, size(chunk), [size(L) for L in inner], group, unit
 
 
 _NNZ = {}
@@ -209,8 +240,8 @@ def main():
     # ---- what the bench model launches ----
     rows = OrderedDict()   # (l1, gi, variant, cmask) -> {"cu", "layers": {name: (units per tile, chunks per unit)}, "masks": set}
     layer_units = {}
-    for lname, i_in, target in LAYERS:
-        p = mplan.plan_uvu(i_in, Irreps.spherical_harmonics(4), target)
+    LAYERS = bench_layers()
+    for lname, p in LAYERS:
         ge = p.group_entries
         um = mplan.fused_unit_map(ge)
         layer_units[lname] = len(um)
@@ -235,6 +266,8 @@ def main():
             rec = rows.setdefault(key, {"cu": cu, "ch": ch, "layers": Counter(), "masks": set(), "mul": int(r[2]), "merged": bool(int(r[0]) & 256),
                                         "hot": hot, "n_mt": int(r[7])})
             rec["layers"][lname] += chunks
+            rec.setdefault("units", Counter())[lname] += 1
+            rec.setdefault("groups", Counter())[lname] += reps
             rec["masks"].add(mask)
     # ---- one object per row ----
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}",
@@ -263,12 +296,12 @@ def main():
     hdr = f"{'kind':8s} {'walk':9s} {'mask':>7s} {'lanes':>5s} {'slots':>5s} | " + " ".join(f"{c:>5s}" for c in CLASSES) + \
           f" | {'VALU':>5s} {'nnz':>5s} {'gen':>5s} {'xw':>4s} {'D':>3s} | {'nnz/VALU':>8s} {'(gen+xw+D)/VALU':>15s} {'loop':>5s} inner"
     print(hdr)
-    agg = {ln: Counter() for ln, _, _ in LAYERS}
+    agg = {ln: Counter() for ln, _ in LAYERS}
     for key, rec in rows.items():
         l1, gi, var, cmask, n_mt = key
         ch = rec["ch"]
         trips = ch // 2 if var == 2 else ch
-        mix, n_body, inner = chunk_loop_mix(listings[key], trips)
+        mix, n_body, inner, grp, unit = chunk_loop_mix(listings[key], trips)
         combos = G[l1][gi]
         masks = sorted(rec["masks"])
         # per lane and chunk, for the (first) mask of this row
@@ -279,6 +312,8 @@ def main():
         xw = (2 * l1 + 1) * len(live) * ch
         dcomb = 4 * n_mt * (2 if var == 1 else 1)
         valu = sum(mix[c] for c in ("cg", "mov", "int", "xlane", "cvt"))
+        VAL = ("cg", "mov", "int", "xlane", "cvt")
+        g_valu, u_valu = sum(grp[c] for c in VAL), sum(unit[c] for c in VAL)
         print(f"({l1},{gi}){'m' if rec['merged'] else ' '}   {VARIANT_NAME[var]:9s} {('%#x' % cmask) + ('' if rec['hot'] else '*'):>7s} {rec['cu']:5d} {ch:5d} | "
               + " ".join(f"{mix[c]:5.0f}" for c in CLASSES)
               + f" | {valu:5.0f} {nnz:5d} {gen:5d} {xw:4d} {dcomb:3d} | {nnz / valu:8.2f} {(gen + xw + dcomb) / valu:15.2f} {n_body:5d} {inner}"
@@ -289,18 +324,22 @@ def main():
             agg[ln]["nnz"] += nnz * chunks
             agg[ln]["gen"] += (gen + xw + dcomb) * chunks
             agg[ln]["valu"] += valu * chunks
+            agg[ln]["valu_group"] += g_valu * rec["groups"][ln]
+            agg[ln]["valu_unit"] += u_valu * rec["units"][ln]
+            agg[ln]["vmem_group"] += grp["vmem"] * rec["groups"][ln]
     print()
     print("per node tile (64 nodes) and layer, chunk loops only (prologue / epilogue / loader-only units not included): wave instructions")
     print(f"{'layer':26s} " + " ".join(f"{c:>8s}" for c in CLASSES) + f" | {'VALU':>8s} {'nnz/VALU':>8s} {'gen/VALU':>8s}  units/tile")
-    for ln, _, _ in LAYERS:
+    for ln, _ in LAYERS:
         a = agg[ln]
-        print(f"{ln:26s} " + " ".join(f"{a[c]:8.0f}" for c in CLASSES) + f" | {a['valu']:8.0f} {a['nnz'] / a['valu']:8.2f} {a['gen'] / a['valu']:8.2f}  {layer_units[ln]}")
+        print(f"{ln:26s} " + " ".join(f"{a[c]:8.0f}" for c in CLASSES) + f" | {a['valu']:8.0f} {a['nnz'] / a['valu']:8.2f} {a['gen'] / a['valu']:8.2f}  {layer_units[ln]:3d}   outside the chunk loops: {a['valu_group']:7.0f} VALU per node group x groups + {a['valu_unit']:6.0f} per unit x units = {(a['valu_group'] + a['valu_unit']) / a['valu']:.2f} of the loops'; {a['vmem_group']:6.0f} vmem")
     tot = Counter()
     for a in agg.values():
         tot.update(a)
-    print(f"{'all four':26s} " + " ".join(f"{tot[c]:8.0f}" for c in CLASSES) + f" | {tot['valu']:8.0f} {tot['nnz'] / tot['valu']:8.2f} {tot['gen'] / tot['valu']:8.2f}")
+    print(f"{'all four':26s} " + " ".join(f"{tot[c]:8.0f}" for c in CLASSES) + f" | {tot['valu']:8.0f} {tot['nnz'] / tot['valu']:8.2f} {tot['gen'] / tot['valu']:8.2f}        outside the chunk loops: {tot['valu_group'] + tot['valu_unit']:8.0f} VALU = {(tot['valu_group'] + tot['valu_unit']) / tot['valu']:.2f} of the loops'")
     n_tiles = 1000
-    print(f"\nx {n_tiles} node tiles (1000 fcc-64 crystals): {tot['valu'] * n_tiles / 4:.3e} VALU wave instructions per launch (mean of four) in the chunk loops; "
+    print(f"\nx {n_tiles} node tiles (1000 fcc-64 crystals): {tot['valu'] * n_tiles / 4:.3e} VALU wave instructions per launch (mean of four) in the chunk loops "
+          f"+ {(tot['valu_group'] + tot['valu_unit']) * n_tiles / 4:.3e} around them (static count: every block of the node-group loop once per group); "
           f"the SQ counter of the whole kernel is in profiles/*tp_fused_valu.json")
     if not keep:
         import shutil
