@@ -1424,3 +1424,4 @@ def test_hub_segments_are_walked_in_pieces(golden_dir, monkeypatch):
         close_blocks(outs[5], outs[0].cpu(), rtol=5e-6, floor=2e-6, what="pieces of 5 vs whole segments")
         close_blocks(outs[32], want, what="n100 with hub splitting vs oracle", want64=_want64(ref, graphs))
         assert torch.equal(sub, outs[32][40:57]), "a crystal's rows depend on its batch mates"
+

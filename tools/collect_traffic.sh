@@ -38,8 +38,8 @@ for k, d in res.items():
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_traffic.sh via "
                  "tools/round_profile.sh), bench.py --steps 2; gfx950 correction: FETCH_SIZE x2 (MI355X_MICROARCH.md "
                  "section HBM); KB -> bytes x1024; 'per_launch' = largest launch (last conv layer), 'mean_launch' = "
-                 "average over all launches of the kernel in a forward (bench.py --no-full-layers: the launches of the headline loop only; until round 5 the '
-                 'second loop with the full last layer was averaged in); by_layer = per position in the forward",
+                 "average over all launches of the kernel in a forward (bench.py --no-full-layers: the launches of the headline loop only; until round 5 the "
+                 "second loop with the full last layer was averaged in); by_layer = per position in the forward",
        "tag": TAG, "kernels": out}
 try:
     import subprocess
