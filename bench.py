@@ -103,6 +103,20 @@ def _pmc_traffic(kernel: str, field: str = "hbm_bytes_mean_launch"):
         return None, None
 
 
+def _train_traffic(kernel_prefix: str):
+    """(HBM bytes per launch of the training step's kernel, source) from the committed PMC run of tools/train_b2048.py
+    (profiles/train_b2048_traffic.json: tools/collect_train_traffic.sh, separate FETCH_SIZE / WRITE_SIZE passes), or (None, None)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "train_b2048_traffic.json")) as f:
+            d = json.load(f)
+        k = next(k for k in d["kernels"] if k.startswith(kernel_prefix))
+        return float(d["kernels"][k]["hbm_bytes_mean_launch"]), (
+            f"profiles/train_b2048_traffic.json (tag {d.get('tag', '?')}{', commit ' + d['commit'] if d.get('commit') else ''}): "
+            f"a separate rocprofv3 --pmc run of tools/train_b2048.py at batch {d.get('batch')}, not this run; FETCH_SIZE x2 + WRITE_SIZE")
+    except Exception:
+        return None, None
+
+
 def calibrate(dev, copy_floats: int = 1 << 28, valu_iters: int = 4096, reps: int = 5):
     """Fixed, model-independent work timed with HIP events on the current stream (csrc/calib.hip): what THIS box at THIS
     moment sustains.  Two lines of the same commit taken on different pool machines (or DVFS states) differ in these
@@ -371,13 +385,16 @@ def extras(dev):
         if kk:
             bw_l.append(((8.0 + 12.0 + 8.0 * pl.weight_numel + 4.0 * (2 * pl.d_in + pl.d_mid) / (El / Nl)) * El, ev_l[kk]))
     roof_l = None
+    tr_l, tr_src = _train_traffic("tp_backward_lit_wfree_kernel")
     if bw_l:
         bm, mm = sum(b for b, _ in bw_l) / len(bw_l), sum(t for _, t in bw_l) / len(bw_l)
         roof_l = {"kernel": "tp_backward (adjoint of the uvu tensor product, matten_tp_backward_lit_wfree since round 5: w re-evaluated per "
                             "workgroup on the matrix cores, dw written; mean over the conv layers)",
                   "bound": "hbm", "achieved": bm / (mm * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                  "frac": bm / (mm * 1e-3) / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_launch": bm,
-                  "avg_launch_ms": mm,
+                  "frac": bm / (mm * 1e-3) / HBM_PEAK, "traffic": tr_l, "traffic_source": tr_src,
+                  "measured_frac": None if tr_l is None else tr_l / (mm * 1e-3) / HBM_PEAK,
+                  "traffic_over_contract": None if tr_l is None else tr_l / bm,
+                  "algorithmic_bytes_per_launch": bm, "avg_launch_ms": mm,
                   "contract": "ids 8 + vector 12 + w read 4 W + dw written 4 W + (x, dx rows: 2 d_in; grad rows: d_mid) / deg per "
                               "(edge, layer): the two-kernel architecture's bytes (SURVEY 8d); the w-free kernel reads 128 B of hidden "
                               "features per edge instead of the 4 W bytes of w"}

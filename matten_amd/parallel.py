@@ -31,10 +31,16 @@ def gather_predictions(local: torch.Tensor, n_total: int, group=None) -> torch.T
     world = dist.get_world_size(group)
     widest = -(-n_total // world)
     tail = local.shape[1:]
-    buf = local.new_zeros((widest,) + tuple(tail))
-    buf[: local.shape[0]] = local
-    out = local.new_empty((world * widest,) + tuple(tail))
+    # a gloo group (CPU-only collectives: the 2-rank rehearsal on one device, a CPU-side launcher) moves device rows through
+    # the host; RCCL ("nccl") gathers them where they are
+    via_host = local.is_cuda and dist.get_backend(group) == "gloo"
+    src = local.cpu() if via_host else local
+    buf = src.new_zeros((widest,) + tuple(tail))
+    buf[: src.shape[0]] = src
+    out = src.new_empty((world * widest,) + tuple(tail))
     dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
+    if via_host:
+        out = out.to(local.device)
     pieces: List[torch.Tensor] = []
     for r in range(world):
         lo, hi = shard_bounds(n_total, r, world)

@@ -78,3 +78,35 @@ def test_eight_rank_shards_tile_one_set():
             for lo, hi in ((0, 2), (2, 12), (12, 21)):     # per irrep block of the 21 components, against the block's scale
                 err = (part[:, lo:hi] - want[:, lo:hi]).abs().max().item()
                 assert err <= 2e-6 * full[:, lo:hi].abs().max().item() + 1e-12, (r, lo, err)
+
+
+def test_predict_evaluate_sharded_over_two_ranks_on_the_device(tmp_path):
+    """matten_amd.predict.evaluate(distributed=True) itself under two ranks (round-5 verdict: until now only a CPU stand-in went
+    through sharded_apply with more than one rank): both ranks run the device forward on THEIR contiguous shard of 11 crystals
+    (6 + 5: the uneven split pads the gather) -- raw triples, device neighbour lists, batches of 4 -- and every rank gets all 11
+    Cartesian tensors back in input order, equal to a single process's.  gloo group, both ranks on the box's one GPU, the
+    [B, 21] rows cross through host memory (parallel.gather_predictions); on a node the same call gathers over RCCL."""
+    n = 11
+    worker = os.path.join(ROOT, "tests", "dist_predict_worker.py")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    port = str(29500 + os.getpid() % 2000)
+    single = subprocess.run([sys.executable, worker, "0", "1", port, str(tmp_path), str(n)], env=env, capture_output=True,
+                            text=True, timeout=600, cwd=ROOT)
+    assert single.returncode == 0, single.stderr[-3000:]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path), str(n)], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+    want = torch.load(os.path.join(tmp_path, "rank0of1.pt"))
+    assert want["crystals_forwarded"] == n and want["tensors"].shape == (n, 3, 3, 3, 3)
+    scale = want["tensors"].abs().max().item()
+    got = [torch.load(os.path.join(tmp_path, f"rank{r}of2.pt")) for r in range(2)]
+    assert [g["crystals_forwarded"] for g in got] == [6, 5]          # each rank forwarded its own shard only
+    for g in got:
+        assert g["tensors"].shape == want["tensors"].shape and torch.isfinite(g["tensors"]).all()
+        assert (g["tensors"] - want["tensors"]).abs().max().item() <= 1e-5 * scale
+    assert torch.equal(got[0]["tensors"], got[1]["tensors"])
