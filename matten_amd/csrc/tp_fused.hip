@@ -238,18 +238,20 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
 #define MATTEN_RGS_ONLY(L1, GI, TT, TD, P) run_group_shared<L1, GI, TT, TD, P, (unsigned)(TPF_ONLY_MASK)>(MATTEN_RGS_ARGS)
 #define MATTEN_GROUP_CASE_SHARED(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): \
-        if (TPF_ONLY_VARIANT == 0) MATTEN_RGS_ONLY(L1, GI, 1, false, true); \
-        else if (TPF_ONLY_VARIANT == 1) MATTEN_RGS_ONLY(L1, GI, 2, false, false); \
-        else if (TPF_ONLY_VARIANT == 2) MATTEN_RGS_ONLY(L1, GI, 1, (TwoDeepOk<L1, GI>::value), false); \
-        else MATTEN_RGS_ONLY(L1, GI, 1, false, false); \
+        if (TPF_ONLY_VARIANT == 0) MATTEN_RGS_ONLY(L1, GI, 1, (TPF_CHUNK_DEEP && L1 == 0 ? 2 : 0), true); \
+        else if (TPF_ONLY_VARIANT == 1) MATTEN_RGS_ONLY(L1, GI, 2, 0, false); \
+        else if (TPF_ONLY_VARIANT == 2) MATTEN_RGS_ONLY(L1, GI, 1, (TPF_CHUNK_DEEP && L1 == 0 ? 2 : TwoDeepOk<L1, GI>::value ? 1 : 0), false); \
+        else MATTEN_RGS_ONLY(L1, GI, 1, 0, false); \
         break;
 #else
 #define MATTEN_GROUP_CASE_SHARED(L1, GI) \
     case (L1 * matten::GROUP_KIND_STRIDE + GI): \
-        if (paired) MATTEN_RGS(L1, GI, 1, false, true); \
-        else if (nodes_per_wave > 16) MATTEN_RGS(L1, GI, 2, false, false); \
-        else if (TwoDeepOk<L1, GI>::value && nodes_per_wave <= 8 && nodes_per_wave >= TPF_TWO_DEEP_MIN_NPW) MATTEN_RGS(L1, GI, 1, (TwoDeepOk<L1, GI>::value), false); \
-        else MATTEN_RGS(L1, GI, 1, false, false); \
+        if (paired && TPF_CHUNK_DEEP && L1 == 0 && nodes_per_wave <= 8 && nodes_per_wave >= 4) MATTEN_RGS(L1, GI, 1, (L1 == 0 ? 2 : 0), true); \
+        else if (paired) MATTEN_RGS(L1, GI, 1, 0, true); \
+        else if (nodes_per_wave > 16) MATTEN_RGS(L1, GI, 2, 0, false); \
+        else if (TPF_CHUNK_DEEP && L1 == 0 && nodes_per_wave <= 8 && nodes_per_wave >= 4) MATTEN_RGS(L1, GI, 1, (L1 == 0 ? 2 : 0), false); \
+        else if (TwoDeepOk<L1, GI>::value && nodes_per_wave <= 8 && nodes_per_wave >= TPF_TWO_DEEP_MIN_NPW) MATTEN_RGS(L1, GI, 1, (TwoDeepOk<L1, GI>::value ? 1 : 0), false); \
+        else MATTEN_RGS(L1, GI, 1, 0, false); \
         break;
 #endif
 
@@ -258,6 +260,9 @@ __device__ __forceinline__ void run_group(const Args& a, const GroupEntry& ge, f
 
 #ifndef TPF_MIN_BLOCKS
 #define TPF_MIN_BLOCKS 3
+#endif
+#ifndef TPF_CHUNK_DEEP
+#define TPF_CHUNK_DEEP 1   // scalar input blocks with 2 or 4 slots per chunk gather a whole chunk ahead (tp_walk.h, TWO_DEEP = 2)
 #endif
 #ifndef TPF_TWO_DEEP_MIN_NPW
 #define TPF_TWO_DEEP_MIN_NPW 2   // two neighbour rows in flight for 8, 4 and 2 nodes per wave (2, 4, 8 slots per chunk)

@@ -415,7 +415,13 @@ struct TwoDeepOk { static constexpr bool value = L1 == 0 || (L1 == 1 && (GI == 0
 // r0, r0 + 2, ...) -- the A fragments are fetched once, and the agg stores of one node group drain behind the walk of the
 // next instead of holding the wave's slot until they are acknowledged (s_endpgm waits for them: 9-13 % of a wave's life,
 // tools/tp_trace.py).  The host picks reps per lanes-per-node class (plan.fused_unit_map).
-template <int L1, int GI, int TT, bool TWO_DEEP, bool PAIRED, unsigned CMASK, class Epilogue>
+// TWO_DEEP = 2 (scalar input blocks, 2 or 4 edge slots per chunk): the gather runs a WHOLE CHUNK ahead -- at the top of chunk c the
+// rows of chunk c + 1 and the source indices of chunk c + 2 are requested, four of each per lane.  A scalar block's edge step is
+// ~45 vector instructions (~200 cycles of issue): a row requested two steps ahead was asked for ~1300 cycles before its use, less
+// than a gather's latency under load, and the wave waited on every step (phase trace, round 5: 2100-3200 cycles of contraction
+// per four-slot chunk for 150-190 instructions).  The two row buffers swap roles by a two-fold unrolled chunk loop, not by moves:
+// a move out of a register with a load in flight would wait for it.
+template <int L1, int GI, int TT, int TWO_DEEP, bool PAIRED, unsigned CMASK, class Epilogue>
 __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry& ge, float* __restrict__ tile,
                                                  float* __restrict__ stage, int entry, int tile_id, int r0, int reps, int lane,
                                                  const Epilogue& epi) {
@@ -502,7 +508,12 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     // The row pointers of group rep + 1 are requested at the top of group rep's walk.
     typename std::conditional<PAIRED, PairLoader, StageLoader<TT>>::type ld;
     static_assert(!TWO_DEEP || TwoDeepOk<L1, GI>::value, "two rows in flight only for the light kinds");
-    constexpr bool two_deep = TWO_DEEP;   // the caller guarantees CH == 2 (8 lanes per node)
+    static_assert(TWO_DEEP != 2 || G::D1 == 1, "a chunk of rows in flight: scalar input blocks");
+    constexpr bool two_deep = TWO_DEEP == 1;   // the caller guarantees an even number of slots per chunk
+    constexpr bool chunk_deep = TWO_DEEP == 2; // the caller guarantees 2 or 4 slots per chunk
+    constexpr int XQ = 4;                      // rows / indices a lane keeps per chunk in chunk_deep mode
+    float xqa[XQ], xqb[XQ];
+    int sq[XQ];
     int node, beg, deg, maxdeg, e_last;
     bool valid;
     float xn[G::D1], xb[G::D1];
@@ -524,6 +535,19 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         // clamped edge index.
         // (the second row buffer is compiled in only for the kinds with registers to spare: it costs the heavy kinds spills)
         e_last = deg > 0 ? beg + deg - 1 : 0;
+        if constexpr (chunk_deep) {
+            int s0q[XQ];
+#pragma unroll
+            for (int i = 0; i < XQ; ++i) s0q[i] = a.src_sorted[min(beg + i, e_last)];
+#pragma unroll
+            for (int i = 0; i < XQ; ++i) sq[i] = a.src_sorted[min(beg + CH + i, e_last)];
+#pragma unroll
+            for (int i = 0; i < XQ; ++i) {
+                const float* xp = a.x + (int64_t)TPF_SRC(s0q[i]) * a.d_in + xcol;
+                xqa[i] = TPF_XLD(xp, 0, s0q[i]);
+            }
+            return;
+        }
         const int src0 = a.src_sorted[min(beg, e_last)];
         const int src1 = a.src_sorted[min(beg + 1, e_last)];
         const float* xp0 = a.x + (int64_t)src0 * a.d_in + xcol;
@@ -556,8 +580,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     unsigned tr_a = tr_loop;
     tr_pro += (unsigned)(tr_loop - tr_rep);
 #endif
-    int buf = 0;
-    for (int s0 = 0; s0 < maxdeg; s0 += CH, buf ^= 1) {
+    auto chunk_body = [&](const int s0, const int buf, float (&xcur)[XQ], float (&xnext)[XQ]) {
         // the short serial head of a chunk (issue the stage loads, LDS -> MFMA -> LDS) runs at raised priority: it is a
         // latency chain, and every cycle another wave's contraction delays it is added to this wave's chunk (-1 %)
         __builtin_amdgcn_s_setprio(TPF_SETPRIO);
@@ -679,6 +702,19 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
                 }
                 G::apply2(CMASK ? CMASK : mask, xa, ya, wa, xc, yb, wb, acc);
             }
+        } else if constexpr (chunk_deep) {
+            // rows of the NEXT chunk (their indices arrived a chunk ago), then the indices of the chunk after it
+#pragma unroll
+            for (int i = 0; i < XQ; ++i) {
+                const float* xp = a.x + (int64_t)TPF_SRC(sq[i]) * a.d_in + xcol;
+                xnext[i] = TPF_XLD(xp, 0, sq[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < XQ; ++i) sq[i] = a.src_sorted[min(beg + s0 + 2 * CH + i, e_last)];
+#pragma unroll
+            for (int so = 0; so < XQ; ++so) {
+                if (so < CH && s0 + so < deg) contract(so, xcur + so);
+            }
         } else if (two_deep) {
             for (int so = 0; so < CH; so += 2) {   // CH is 2, 4 or 8 here: slot pairs, one row buffer per parity
                 const int s = s0 + so;
@@ -732,6 +768,15 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
         tr_bar += (unsigned)(tr_e - tr_d), tr_chunks += 1;
         tr_a = tr_e;
 #endif
+    };
+    if constexpr (chunk_deep) {
+        for (int s0 = 0; s0 < maxdeg; s0 += 2 * CH) {
+            chunk_body(s0, 0, xqa, xqb);
+            if (s0 + CH < maxdeg) chunk_body(s0 + CH, 1, xqb, xqa);   // (wave-uniform; an odd tail leaves the next group's rows to start_group: buffer a)
+        }
+    } else {
+        int buf = 0;
+        for (int s0 = 0; s0 < maxdeg; s0 += CH, buf ^= 1) chunk_body(s0, buf, xqa, xqb);
     }
 #if TPF_TRACING
     const unsigned tr_end = tpf_stamp();
