@@ -110,3 +110,33 @@ def test_predict_evaluate_sharded_over_two_ranks_on_the_device(tmp_path):
         assert g["tensors"].shape == want["tensors"].shape and torch.isfinite(g["tensors"]).all()
         assert (g["tensors"] - want["tensors"]).abs().max().item() <= 1e-5 * scale
     assert torch.equal(got[0]["tensors"], got[1]["tensors"])
+
+
+def test_data_parallel_training_step_on_the_device(tmp_path):
+    """matten_amd.parallel.DataParallelStep with the real model on the device: two ranks (child processes, gloo group, both on the
+    box's one GPU; on a node the same code all-reduces over RCCL), 8 crystals sharded 4 + 4, FlatAdam -- its flat gradient buffer
+    is the ONE all-reduce of a step.  The ranks start from different weights (aligned by the constructor's broadcast), end on
+    identical parameters bit for bit, and follow the single-process full-batch run (loss per step, parameters after three Adam
+    steps) to rounding."""
+    worker = os.path.join(ROOT, "tests", "dist_train_worker.py")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    port = str(29500 + (os.getpid() + 313) % 2000)
+    single = subprocess.run([sys.executable, worker, "0", "1", port, str(tmp_path)], env=env, capture_output=True, text=True,
+                            timeout=600, cwd=ROOT)
+    assert single.returncode == 0, single.stderr[-3000:]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path)], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+    want = torch.load(os.path.join(tmp_path, "train0of1.pt"))
+    got = [torch.load(os.path.join(tmp_path, f"train{r}of2.pt")) for r in range(2)]
+    assert torch.equal(got[0]["flat"], got[1]["flat"]) and got[0]["losses"] == got[1]["losses"]
+    assert all(abs(a - b) <= 2e-4 * abs(b) for a, b in zip(got[0]["losses"], want["losses"])), (got[0]["losses"], want["losses"])
+    assert want["losses"][-1] < want["losses"][0]
+    scale = want["flat"].abs().max().item()
+    # three Adam steps amplify rounding differences of tiny gradients (g / sqrt(v)): parameters to 1e-3 of the largest weight
+    assert (got[0]["flat"] - want["flat"]).abs().max().item() <= 1e-3 * scale

@@ -831,3 +831,69 @@ __global__ void bad(const float* a, const float* b, f32x4* out) {
     assert len(isa.check_function("spill", spill)) == 1                      # 9 < 10
     spill[1] = (0x08, "s_nop", "9")
     assert not isa.check_function("spill", spill)
+
+
+class _TinyTaskModel(torch.nn.Module):
+    """stand-in with the product models' call convention: model(batch, task_name=) -> ({task: [B, 21]}, labels)"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.lin = torch.nn.Linear(7, 21)
+        self.register_buffer("running", torch.zeros(3))
+
+    def forward(self, batch, task_name="elastic_tensor_full"):
+        return {task_name: self.lin(batch["x"])}, None
+
+
+def _ddp_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from matten_amd.parallel import DataParallelStep, shard_bounds
+
+    g = torch.Generator().manual_seed(11)
+    x, y = torch.randn(5, 7, generator=g), torch.randn(5, 21, generator=g)
+    model = _TinyTaskModel()
+    if rank == 1:   # a rank that starts elsewhere is pulled onto rank 0's parameters by the constructor's broadcast
+        with torch.no_grad():
+            model.lin.weight.add_(1.0)
+    model.running.fill_(float(rank))
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    dp = DataParallelStep(model, opt, lambda preds, t: torch.nn.functional.mse_loss(preds["elastic_tensor_full"], t))
+    lo, hi = shard_bounds(5, rank, world)          # 3 + 2: uneven shards
+    losses = [float(dp.step({"x": x[lo:hi]}, y[lo:hi], 5)) for _ in range(3)]
+    model.running.fill_(float(rank) + 1.0)
+    dp.sync_buffers()
+    torch.save({"w": model.lin.weight.detach().clone(), "b": model.lin.bias.detach().clone(), "losses": losses,
+                "running": model.running.clone()}, os.path.join(tmp, f"ddp{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_equals_the_full_batch_step(tmp_path):
+    """parallel.DataParallelStep over two gloo ranks with uneven shards (3 + 2 samples): local mean loss weighted by
+    n_local / n_global, ONE all-reduce of the gradients, optimiser step == the full-batch step of a single process, three steps
+    in a row; both ranks end on the same parameters bit for bit; sync_buffers averages the floating-point buffers."""
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() + 77) % 2000
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(11)
+    x, y = torch.randn(5, 7, generator=g), torch.randn(5, 21, generator=g)
+    ref = _TinyTaskModel()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    want_losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(ref(dict(x=x))[0]["elastic_tensor_full"], y)
+        loss.backward()
+        opt.step()
+        want_losses.append(float(loss))
+    got = [torch.load(os.path.join(tmp_path, f"ddp{r}.pt")) for r in range(2)]
+    assert torch.equal(got[0]["w"], got[1]["w"]) and torch.equal(got[0]["b"], got[1]["b"])
+    assert torch.allclose(got[0]["w"], ref.lin.weight.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(got[0]["b"], ref.lin.bias.detach(), rtol=1e-5, atol=1e-6)
+    assert np.allclose(got[0]["losses"], want_losses, rtol=1e-5) and got[0]["losses"] == got[1]["losses"]
+    assert torch.equal(got[0]["running"], torch.full((3,), 1.5)) and torch.equal(got[1]["running"], got[0]["running"])
