@@ -124,9 +124,6 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 #ifndef TPF_EXACT_Y0
 #define TPF_EXACT_Y0 0
 #endif
-#ifndef TPF_BRANCHLESS_SLOTS
-#define TPF_BRANCHLESS_SLOTS 0   // round-6 experiment: chunk-deep scalar blocks contract every slot of a chunk unconditionally
-#endif
 
 #ifndef TPF_REP_PREFETCH
 #define TPF_REP_PREFETCH 1   // persistent units: the next node group's loads go out in front of this group's agg stores
@@ -720,24 +717,9 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             }
 #pragma unroll
             for (int i = 0; i < XQ; ++i) sq[i] = a.src_sorted[min(beg + s0 + 2 * CH + i, e_last)];
-            if constexpr (TPF_BRANCHLESS_SLOTS) {
-                // no branch around a slot: a slot past the lane's segment contracts x = 0 (an exact + 0 to every accumulator; its
-                // staged row is the segment's last edge again), so two slots' LDS reads and arithmetic are ONE basic block
-                auto slot = [&](int so) {
-                    const float xz = s0 + so < deg ? xcur[so] : 0.0f;
-                    contract(so, &xz);
-                };
-                slot(0);
-                slot(1);
-                if (CH > 2) {
-                    slot(2);
-                    slot(3);
-                }
-            } else {
 #pragma unroll
-                for (int so = 0; so < XQ; ++so) {
-                    if (so < CH && s0 + so < deg) contract(so, xcur + so);
-                }
+            for (int so = 0; so < XQ; ++so) {
+                if (so < CH && s0 + so < deg) contract(so, xcur + so);
             }
         } else if (two_deep) {
             for (int so = 0; so < CH; so += 2) {   // CH is 2, 4 or 8 here: slot pairs, one row buffer per parity
