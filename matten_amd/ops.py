@@ -447,6 +447,9 @@ def split_a_tiles(w2p: torch.Tensor, group_entries) -> Tuple[torch.Tensor, torch
     return torch.cat(tiles).contiguous(), torch.stack(inv).float().contiguous()
 
 
+_GROUPS_CHECKED = False
+
+
 def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, units_per_tile: int,
              lds_floats_per_wave: int, d_mid: int, avg_num_neighbors: float, num_neigh=None,
              a_split=None) -> torch.Tensor:
@@ -460,10 +463,12 @@ def tp_fused(x, h2p, w2p, sh_sorted, rowptr, src_sorted, entries, unit_map, unit
     if (lib.matten_tp_max_cols() != TP_MAX_COLS or lib.matten_tp_max_cols_l0() != TP_MAX_COLS_L0
             or lib.matten_tp_max_cols_l1() != TP_MAX_COLS_L1):
         raise _lib.MattenHipError("plan.TP_MAX_COLS does not match the library's entry width (-DTPF_MAX_COLS)")
+    global _GROUPS_CHECKED
     from .plan import tp_groups_hash
-    if lib.matten_tp_groups_hash() != tp_groups_hash():
+    if not _GROUPS_CHECKED and lib.matten_tp_groups_hash() != tp_groups_hash():
         raise _lib.MattenHipError("the library's coupling code (cg_gen.h) was generated for other coupling groups than plan.TP_GROUPS "
                                   "(MATTEN_TP_GROUPS / an interrupted tools/*.sh A/B build?): make -C matten_amd/csrc clean all")
+    _GROUPS_CHECKED = True   # (one library per process: checked at the first call)
     x = _need_rows(x, torch.float32, "node_features")  # a column slice is fine: d_in below is the row stride
     h2p = _need(h2p, torch.float16, "h2s")
     if h2p.dim() != 3 or h2p.shape[1:] != (2, 32):

@@ -79,10 +79,16 @@ def tp_groups_hash() -> int:
     """31-bit FNV-1a of the coupling-group lists: cg_gen.h carries the value it was generated for (matten::GROUPS_HASH), the
     library exports it (matten_tp_groups_hash) and ops.tp_fused refuses a library whose generated code is for other lists --
     entries planned on one scheme and contracted by the code of another give wrong sums, silently."""
-    h = 0x811C9DC5
-    for b in repr(sorted((l1, [list(map(tuple, g)) for g in gs]) for l1, gs in TP_GROUPS.items())).encode():
-        h = ((h ^ b) * 0x01000193) & 0xFFFFFFFF
-    return h & 0x7FFFFFFF
+    global _TP_GROUPS_HASH
+    if _TP_GROUPS_HASH is None:   # (TP_GROUPS is fixed at import; ops.tp_fused asks on every call)
+        h = 0x811C9DC5
+        for b in repr(sorted((l1, [list(map(tuple, g)) for g in gs]) for l1, gs in TP_GROUPS.items())).encode():
+            h = ((h ^ b) * 0x01000193) & 0xFFFFFFFF
+        _TP_GROUPS_HASH = h & 0x7FFFFFFF
+    return _TP_GROUPS_HASH
+
+
+_TP_GROUPS_HASH = None
 
 
 def groups_for_block(l1: int, couplings) -> list:
