@@ -78,7 +78,13 @@ class BaseModel(_Base):
 
         @property
         def device(self):
-            return next(self.parameters()).device
+            # (the first Parameter OBJECT is stable across .to() / FlatAdam re-homing; walking parameters() costs ~8 us and
+            # preprocess_batch asks once per forward)
+            p = self.__dict__.get("_amd_first_param")
+            if p is None:
+                p = next(self.parameters())
+                self.__dict__["_amd_first_param"] = p
+            return p.device
 
     # ---- reference model/model.py:234-280 ----
     def compute_loss(self, preds: Dict[str, Tensor], labels: Dict[str, Tensor], weight: Tensor = None):

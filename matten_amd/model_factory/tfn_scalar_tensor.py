@@ -217,7 +217,8 @@ class ScalarTensorModel(BaseModel):
             labels = {name: y[name] for name in self.tasks if name in y}
             graphs = batch.tensor_property_to_dict()
         else:
-            graphs = {k: (v.to(self.device) if isinstance(v, Tensor) else v) for k, v in batch.items()}
+            dev = self.device
+            graphs = {k: (v.to(dev) if isinstance(v, Tensor) and v.device != dev else v) for k, v in batch.items()}
             labels = {name: graphs[name] for name in self.tasks if name in graphs}
         return graphs, labels
 
