@@ -431,6 +431,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const unsigned tr_in_hi = tpf_stamp_hi();
     const unsigned tr_in = tpf_stamp();     // (covers every node group of a persistent unit)
     unsigned tr_mfma = 0, tr_con = 0, tr_pub = 0, tr_bar = 0, tr_chunks = 0, tr_pro = 0, tr_epi = 0;
+    unsigned tr_pro_pre = 0, tr_epi_sg = 0;   // of the prologue: up to its barrier; of the epilogue: the next group's start_group
 #endif
     const int row0 = PAIRED ? 16 * (int)(threadIdx.x >> 7) : 0;       // this wave's half of a paired stage
     constexpr int STAGE_BUF = (PAIRED ? 32 : 16 * TT) * STAGE_ROW;    // floats per stage buffer
@@ -575,6 +576,9 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
 #pragma unroll
     for (int k = 0; k < G::NACC; ++k) acc[k] = 0.0f;
     ld.publish(0);
+#if TPF_TRACING
+    tr_pro_pre += (unsigned)(tpf_stamp() - tr_rep);
+#endif
     __syncthreads();
 #if TPF_TRACING
     const unsigned tr_loop = tpf_stamp();
@@ -790,6 +794,9 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
     const int node_done = node;
     const bool valid_done = valid;
     if (TPF_REP_PREFETCH && more) start_group(unit_nodes_finish(raw_next));
+#if TPF_TRACING
+    tr_epi_sg += (unsigned)(tpf_stamp() - tr_end);
+#endif
     epi.template store<G>(a, ge, acc, a_scale_inv, node_done, j, u, valid_done);
     if (!TPF_REP_PREFETCH && more) start_group(unit_nodes_finish(raw_next));
 #if TPF_TRACING
@@ -803,7 +810,7 @@ __device__ __forceinline__ void run_group_shared(const Args& a, const GroupEntry
             tr[0] = 1u, tr[1] = (unsigned)ge.kind, tr[2] = (unsigned)cu_log2 | (PAIRED ? 256u : 0u) | ((unsigned)reps << 9) | ((unsigned)TT << 12) | ((unsigned)MT << 16);
             tr[3] = tr_chunks, tr[4] = tr_pro, tr[5] = tr_mfma, tr[6] = tr_con, tr[7] = tr_pub, tr[8] = tr_bar;
             tr[9] = tr_epi, tr[10] = (unsigned)(tr_out - tr_in), tr[11] = (unsigned)ge.mask;
-            tr[12] = tr_in, tr[13] = tr_in_hi;
+            tr[12] = tr_in, tr[13] = tr_in_hi, tr[14] = tr_pro_pre, tr[15] = tr_epi_sg;
         }
     }
 #endif

@@ -81,7 +81,8 @@ def report(trace, label):
         per = m[:, 5:9].sum(0) / max(1, m[:, 3].sum())
         print(f"{'(%d,%d)%s' % (kind // 8, kind % 8, 'm' if k[0] & 256 else ''):>10s} {1 << cul:10d} {TT:3d} {MT:3d} {paired:4d} {len(m):7d} {ch:6.1f} | "
               + " ".join(f"{c:10.0f}" for c in cols) + " |            " + " ".join(f"{c:9.0f}" for c in per)
-              + f" | {m[:, 10].sum() / tot_all:6.3f}")
+              + f" | {m[:, 10].sum() / tot_all:6.3f}"
+              + f" | prologue up to its barrier {m[:, 14].mean():7.0f}, epilogue: next group's start {m[:, 15].mean():7.0f}")
     sums = t[:, [4, 5, 6, 7, 8, 9]].sum(0)
     print("all waves: share of wave cycles  " + "  ".join(f"{n} {s / tot_all:.3f}" for n, s in zip(NAMES[:6], sums)))
 
