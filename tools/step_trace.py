@@ -14,6 +14,12 @@ for i in range(i0 + 1, len(rows)):   # the step ends with the last kernel before
         i1 = i
         break
 step = rows[i0:i1]
+# what follows the forward in the process (the bench's finiteness check, the final read-back) is not part of it: cut at the
+# first host-paced hole behind the conv stack
+for k in range(10, len(step)):
+    if int(step[k]["Start_Timestamp"]) - int(step[k - 1]["End_Timestamp"]) > 100_000:
+        step = step[:k]
+        break
 t0 = int(step[0]["Start_Timestamp"])
 prev_end = t0
 tot_busy = tot_gap = 0
